@@ -1,0 +1,138 @@
+"""Generate the golden vectors in tests/golden by RUNNING THE REFERENCE (build container only).
+
+    python -m oracle.gen_golden            # needs /root/reference; writes tests/golden/*.npz
+
+Each fixture is data only: the case parameters, the explicit inputs (cond mel, token ids, y0,
+masks), the weight seed + checksum (weights are regenerated from ``lemas_tts_amd.synth``), and
+the reference's outputs (``out`` and the Euler ``trajectory`` of ``CFM.sample``, cfm.py:206-473).
+Nothing of the reference's source travels.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from lemas_tts_amd.model.layout import DiTArch  # noqa: E402
+from lemas_tts_amd import synth  # noqa: E402
+from oracle import ref_shims  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+VOCAB = 898
+
+MINI = DiTArch(depth=2)
+FULL = DiTArch()
+
+
+def _reference_y0(seed: int, durations) -> torch.Tensor:
+    """What cfm.py:430-435 draws when ``seed`` is given (re-seeded per sample, zero right-pad)."""
+    ys = []
+    for d in durations:
+        torch.manual_seed(seed)
+        ys.append(torch.randn(int(d), 100))
+    return torch.nn.utils.rnn.pad_sequence(ys, padding_value=0, batch_first=True)
+
+
+def run_case(name, arch, *, wseed, B, F, lens, Nt, duration, steps, cfg, coef, noise_seed,
+             edit_spans=None, prosody=False, use_acc_grl=False):
+    sd_np = synth.synth_cfm_state_dict(arch, VOCAB, wseed, prosody=prosody)
+    sd = {k: torch.from_numpy(v) for k, v in sd_np.items()}
+    cfm = ref_shims.build_reference_cfm(arch.reference_kwargs(), VOCAB, sd, use_prosody=prosody)
+
+    cond = np.stack([synth.synth_cond_mel(wseed + 1, F, f"cond{b}") for b in range(B)])
+    text = np.full((B, max(Nt)), -1, dtype=np.int64)
+    for b in range(B):
+        text[b, : Nt[b]] = synth.synth_tokens(wseed + 2, Nt[b], VOCAB, f"tok{b}")
+    lens_t = None if lens is None else torch.tensor(lens, dtype=torch.long)
+    dur_arg = duration if isinstance(duration, int) else torch.tensor(duration, dtype=torch.long)
+
+    edit_mask = None
+    if edit_spans is not None:
+        from oracle.lemas_oracle import build_edit_mask
+        # the mask builder itself (speech_edit_multilingual.py:125-158) is script-level code with no
+        # importable function; the golden pins the *sampler's* use of the mask (cfm.py:293-295).
+        edit_mask = build_edit_mask(F * 256 - 256 + 100, edit_spans)
+        assert edit_mask.shape[1] == F, (edit_mask.shape, F)
+
+    kw = dict(steps=steps, cfg_strength=cfg, sway_sampling_coef=coef, seed=noise_seed,
+              edit_mask=edit_mask, use_acc_grl=use_acc_grl, ref_ratio=1, lens=lens_t)
+    pros = None
+    cond_in = torch.from_numpy(cond)
+    if prosody:
+        # reach cfm.py:248-265,313-318,376-380 without the Pretssel encoder files: raw audio in,
+        # mel / resample / fbank / encoder replaced by lookups keyed on the first audio sample.
+        import lemas_tts.model.cfm as cfm_mod
+        pros = synth.synth_prosody_embed(wseed + 3, B)
+        audio = torch.zeros(B, 4000)
+        audio[:, 0] = torch.arange(B).float()
+        class _MelLookup(torch.nn.Module):
+            target_sample_rate = 24000
+
+            def forward(self, wav):
+                return torch.from_numpy(cond).permute(0, 2, 1)
+
+        cfm.mel_spec = _MelLookup()
+        cfm_mod.torchaudio.functional.resample = lambda a, s, d: a
+        cfm_mod.extract_fbank_16k = lambda a: a[:1]
+        cfm.prosody_encoder = lambda fb, padding_mask=None: [torch.from_numpy(pros[int(fb.flatten()[0])])]
+        cond_in = audio
+        kw["use_prosody_encoder"] = True
+
+    t0 = time.time()
+    out, traj = cfm.sample(cond=cond_in, text=torch.from_numpy(text), duration=dur_arg, **kw)
+    dt = time.time() - t0
+    N = out.shape[1]
+    lens_eff = [F] * B if lens is None else lens
+    durs = torch.maximum(torch.maximum(torch.tensor([int((text[b] != -1).sum()) for b in range(B)]),
+                                       torch.tensor(lens_eff)) + 1,
+                         torch.full((B,), duration) if isinstance(duration, int) else torch.tensor(duration))
+    y0 = _reference_y0(noise_seed, durs.tolist())
+    assert y0.shape == out.shape and torch.equal(y0, traj[0]), "y0 replication drifted"
+
+    if use_acc_grl is False and not prosody and edit_spans is None and B == 1:
+        out2, _ = cfm.sample(cond=cond_in, text=torch.from_numpy(text), duration=dur_arg,
+                             **{**kw, "use_acc_grl": True})
+        assert torch.equal(out, out2), "accent-GRL flag must be a forward no-op at ref_ratio>=1"
+
+    fx = dict(
+        arch_depth=arch.depth, vocab=VOCAB, wseed=wseed, wchecksum=synth.checksum(sd_np),
+        prosody=int(prosody), B=B, F=F, N=N, steps=steps, cfg=cfg,
+        coef=np.float32(np.nan if coef is None else coef),
+        cond=cond, text=text, y0=y0.numpy(), out=out.numpy(), trajectory=traj.numpy(),
+        duration=np.asarray(durs.tolist(), dtype=np.int64),
+        lens=np.asarray(lens_eff, dtype=np.int64),
+    )
+    if edit_mask is not None:
+        fx["edit_mask"] = edit_mask.numpy()
+    if pros is not None:
+        fx["prosody_embeds"] = pros
+    np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), **fx)
+    print(f"{name}: N={N} steps={steps} ref {dt:.1f}s |out| mean {out.abs().mean():.4f} "
+          f"traj[-1] std {traj[-1].std():.4f}")
+
+
+def main():
+    os.makedirs(GOLDEN, exist_ok=True)
+    torch.set_num_threads(8)
+    run_case("mini_plain", MINI, wseed=11, B=1, F=60, lens=None, Nt=[30], duration=160, steps=4,
+             cfg=2.0, coef=5, noise_seed=101)
+    run_case("mini_nocfg_nosway", MINI, wseed=12, B=1, F=40, lens=None, Nt=[20], duration=96, steps=3,
+             cfg=0.0, coef=None, noise_seed=102)
+    run_case("mini_batch", MINI, wseed=13, B=2, F=70, lens=[50, 70], Nt=[24, 31], duration=[120, 150],
+             steps=4, cfg=2.0, coef=5, noise_seed=103)
+    run_case("mini_edit", MINI, wseed=14, B=1, F=200, lens=None, Nt=[40], duration=199, steps=4,
+             cfg=2.0, coef=3.0, noise_seed=104, edit_spans=[(0.4, 0.7), (1.3, 1.6)])
+    run_case("mini_prosody", DiTArch(depth=2), wseed=15, B=2, F=64, lens=None, Nt=[20, 26],
+             duration=[130, 144], steps=3, cfg=2.0, coef=5, noise_seed=105, prosody=True)
+    run_case("full_plain", FULL, wseed=16, B=1, F=150, lens=None, Nt=[60], duration=400, steps=3,
+             cfg=2.0, coef=5, noise_seed=106)
+
+
+if __name__ == "__main__":
+    main()
