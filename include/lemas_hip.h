@@ -1,0 +1,125 @@
+/* liblemas_hip.so -- C ABI of the MI355X-native LEMAS-TTS acoustic-generation hot path.
+ *
+ * The reference (LEMAS-Project/LEMAS-TTS) is pure Python with no FFI/plugin/operator interface for this path
+ * (SURVEY.md section 8b): its boundary is the Python call surface.  This header therefore declares the entry
+ * points a maintainer of the reference would bind (ctypes stub in INTEGRATION.md) to replace, one for one:
+ *
+ *   lemas_dit_create/load_weight/finalize   <- lemas_tts/infer/utils_infer.py:252-303 load_model,
+ *                                              :204-246 load_checkpoint (same key names, strict)
+ *   lemas_dit_sample                        <- lemas_tts/model/cfm.py:206-473 CFM.sample, i.e. the odeint loop
+ *                                              (:456) over fn (:382-425) = 2 x DiT.forward
+ *                                              (lemas_tts/model/backbones/dit.py:194-254) + CFG + clamp
+ *   lemas_dit_forward                       <- lemas_tts/model/backbones/dit.py:194-254 DiT.forward (both CFG branches)
+ *   lemas_vocos_create/load_weight/finalize <- lemas_tts/infer/utils_infer.py:120-143 load_vocoder
+ *   lemas_vocos_decode                      <- vocoder.decode call, lemas_tts/infer/utils_infer.py:549 and
+ *                                              lemas_tts/scripts/speech_edit_multilingual.py:198
+ *   lemas_k_*                               <- single-kernel entry points used by the parity tests
+ *
+ * Conventions: plain pointers and sizes only.  "device" pointers are HIP device addresses on the current device
+ * (e.g. torch.Tensor.data_ptr()); "host" pointers are ordinary memory.  `stream` is a hipStream_t passed as void*
+ * (NULL = default stream); all work is stream-ordered and the library never synchronises the device in the
+ * sample/decode paths.  The caller owns every buffer it passes; the library owns its weights, workspaces and
+ * captured hipGraphs.  Every function returns 0 on success or a negative code (-hipError_t for HIP failures,
+ * LEMAS_E_* otherwise); lemas_last_error() returns a thread-local description.  An object is not thread-safe
+ * (the reference's module is not re-entrant either: dit.py:140,191-192 text cache).
+ */
+#ifndef LEMAS_HIP_H
+#define LEMAS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LEMAS_E_ARG (-10001)      /* bad argument / unsupported shape */
+#define LEMAS_E_STATE (-10002)    /* call order (e.g. sample before finalize) */
+#define LEMAS_E_WEIGHT (-10003)   /* unknown / missing / mis-shaped tensor (strict load) */
+
+typedef struct lemas_dit lemas_dit;
+typedef struct lemas_vocos lemas_vocos;
+
+/* model.arch of lemas_tts/configs/multilingual_grl.yaml:48-58 (+ derived sizes) */
+typedef struct {
+  int32_t dim, depth, heads, dim_head, ff_mult, text_dim, conv_layers, mel_dim;
+  int32_t vocab_rows;       /* text embedding rows = vocab_size + 1 (dit.py:37) */
+  int32_t conv_pos_kernel;  /* 31 */
+  int32_t conv_pos_groups;  /* 16 */
+  int32_t time_freq_dim;    /* 256 */
+  int32_t has_prosody;      /* prosody_to_mel / prosody_text_proj present */
+} lemas_dit_config;
+
+typedef struct {
+  int32_t batch;        /* B */
+  int32_t frames;       /* N  = max duration (cfm.py:305) */
+  int32_t cond_frames;  /* F  = frames of the reference mel before padding (cfm.py:240) */
+  int32_t text_len;     /* Nt = padded token count */
+  int32_t steps;        /* NFE */
+  float cfg_strength;   /* < 1e-5 => single branch, no clamp (cfm.py:404-405) */
+  const float* cond;          /* device [B,N,mel]  reference mel, zero right-padded to N (cfm.py:311) */
+  const uint8_t* cond_mask;   /* device [B,N]      1 = conditioning frame (lens & edit mask, cfm.py:293-295,326) */
+  const int64_t* text;        /* device [B,Nt]     token ids, -1 padded (model/utils.py:87-94) */
+  const int32_t* seq_len;     /* device [B] valid frames per sample = duration (cfm.py:337), or NULL when B == 1 */
+  const float* prosody;       /* device [B,512] utterance prosody embedding or NULL (cfm.py:261-263) */
+  const float* t_grid;        /* HOST   [steps+1] ODE time grid (cfm.py:445-453) */
+  float* y;                   /* device [B,N,mel]  in: y0 noise (cfm.py:430-435); out: trajectory[-1] */
+  float* out;                 /* device [B,N,mel]  where(cond_mask, cond, y) (cfm.py:459-461); may be NULL */
+  float* trajectory;          /* device [steps+1,B,N,mel] or NULL (callers discard it, utils_infer.py:543) */
+} lemas_sample_args;
+
+const char* lemas_last_error(void);
+int lemas_version(void);
+
+/* ---- DiT / CFM sampler ---- */
+int lemas_dit_create(const lemas_dit_config* cfg, lemas_dit** out);
+void lemas_dit_destroy(lemas_dit* m);
+/* fp32 HOST tensor under its checkpoint key (prefix "ema_model." already stripped).  Auxiliary tables the
+ * reference keeps as non-persistent buffers / recomputes are loaded the same way:
+ *   "transformer.text_embed.freqs_cis" [4096, text_dim]  (modules.py:196-207)
+ *   "transformer.time_embed.freqs"     [time_freq_dim/2] (modules.py:157-158) */
+int lemas_dit_load_weight(lemas_dit* m, const char* name, const float* host_data, const int64_t* shape, int32_t ndim);
+int lemas_dit_finalize(lemas_dit* m);
+/* options: "graph" (1 = replay one captured hipGraph per ODE step, default 1), "profile" (1 = per-kernel events) */
+int lemas_dit_set_option(lemas_dit* m, const char* key, int64_t value);
+/* full sampler: hoists + NFE Euler steps (+ final where) */
+int lemas_dit_sample(lemas_dit* m, const lemas_sample_args* a, void* stream);
+/* split form: prepare() runs the per-utterance hoists, solve() the step loop on the prepared state */
+int lemas_dit_prepare(lemas_dit* m, const lemas_sample_args* a, void* stream);
+int lemas_dit_solve(lemas_dit* m, const lemas_sample_args* a, void* stream);
+/* one DiT forward at step index k of the prepared grid: x device [B,N,mel] -> pred device [BB*N, mel]
+ * (BB = 2B with CFG: conditional rows first, then unconditional) */
+int lemas_dit_forward(lemas_dit* m, const float* x, int32_t step_index, float* pred, void* stream);
+/* per-kernel-class timings collected while option "profile" = 1: fills up to `cap` entries, returns the count.
+ * Synchronises the device. */
+int lemas_dit_profile_read(lemas_dit* m, char (*names)[32], double* total_ms, int64_t* launches, int32_t cap);
+
+/* ---- Vocos vocoder ---- */
+int lemas_vocos_create(int32_t input_channels, int32_t dim, int32_t intermediate_dim, int32_t num_layers, int32_t n_fft,
+                       int32_t hop_length, lemas_vocos** out);
+void lemas_vocos_destroy(lemas_vocos* v);
+int lemas_vocos_load_weight(lemas_vocos* v, const char* name, const float* host_data, const int64_t* shape, int32_t ndim);
+int lemas_vocos_finalize(lemas_vocos* v);
+/* mel device [B, C, L] fp32 -> wav device [B, hop*(L-1)] fp32; `gain` multiplies the waveform (rms rescale,
+ * utils_infer.py:552-553; pass 1.0 for none) */
+int lemas_vocos_decode(lemas_vocos* v, const float* mel, int32_t batch, int32_t frames, float gain, float* wav, void* stream);
+
+/* ---- single-kernel entry points (parity tests) ---- all pointers device fp32 unless noted */
+/* out[M,N] = act(A[M,K] . W[N,K]^T + bias) through the bf16 MFMA GEMM (inputs rounded to bf16); act: 0 none, 1 gelu-tanh */
+int lemas_k_linear_bf16(const float* A, const float* W, const float* bias, float* out, int32_t M, int32_t N, int32_t K,
+                        int32_t act, void* stream);
+/* out[M,N] = A . W^T + bias through the exact-fp32 MFMA GEMM; act: 0 none, 1 gelu-erf, 2 silu */
+int lemas_k_linear_f32(const float* A, const float* W, const float* bias, float* out, int32_t M, int32_t N, int32_t K,
+                       int32_t act, void* stream);
+/* q,k,v [B,H,N,64] (already rotated) -> out [B,N,H*64]; seq_len device int32 [B] or NULL */
+int lemas_k_attention(const float* q, const float* k, const float* v, const int32_t* seq_len, float* out, int32_t B,
+                      int32_t H, int32_t N, void* stream);
+/* out = LayerNorm(x; eps 1e-6) * (1 + scale) + shift, rows of 1024; result rounded to bf16 then widened */
+int lemas_k_ln_mod(const float* x, const float* scale, const float* shift, float* out, int32_t M, int32_t D, void* stream);
+/* out = conv_pos_embed(x) + x for x [B,N,C]; w1,w2 [C, C/groups, taps], b1,b2 [C] */
+int lemas_k_convpos(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* out,
+                    int32_t B, int32_t N, int32_t C, int32_t groups, int32_t taps, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LEMAS_HIP_H */

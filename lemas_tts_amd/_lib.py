@@ -1,0 +1,92 @@
+"""ctypes binding of liblemas_hip.so (the C ABI declared in include/lemas_hip.h).
+
+There is NO CPU fallback: if the shared library is missing or no HIP device is present the
+product path raises.  PyTorch is used for device memory and streams only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "liblemas_hip.so")
+
+_lib = None
+
+
+class DitConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "dim", "depth", "heads", "dim_head", "ff_mult", "text_dim", "conv_layers", "mel_dim", "vocab_rows",
+        "conv_pos_kernel", "conv_pos_groups", "time_freq_dim", "has_prosody")]
+
+
+class SampleArgs(C.Structure):
+    _fields_ = [
+        ("batch", C.c_int32), ("frames", C.c_int32), ("cond_frames", C.c_int32), ("text_len", C.c_int32),
+        ("steps", C.c_int32), ("cfg_strength", C.c_float),
+        ("cond", C.c_void_p), ("cond_mask", C.c_void_p), ("text", C.c_void_p), ("seq_len", C.c_void_p),
+        ("prosody", C.c_void_p), ("t_grid", C.POINTER(C.c_float)),
+        ("y", C.c_void_p), ("out", C.c_void_p), ("trajectory", C.c_void_p),
+    ]
+
+
+class LemasError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the library once.  Import torch first so the process-wide HIP runtime is torch's."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  (must come first: one libamdhip64 per process)
+    if not os.path.exists(LIB_PATH):
+        raise LemasError(f"{LIB_PATH} is missing: build it with `python -m lemas_tts_amd.build` "
+                         "(there is no CPU fallback for the acoustic path)")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    sig = {
+        "lemas_last_error": (C.c_char_p, []),
+        "lemas_version": (C.c_int, []),
+        "lemas_dit_create": (C.c_int, [C.POINTER(DitConfig), C.POINTER(vp)]),
+        "lemas_dit_destroy": (None, [vp]),
+        "lemas_dit_load_weight": (C.c_int, [vp, C.c_char_p, vp, C.POINTER(i64), i32]),
+        "lemas_dit_finalize": (C.c_int, [vp]),
+        "lemas_dit_set_option": (C.c_int, [vp, C.c_char_p, i64]),
+        "lemas_dit_sample": (C.c_int, [vp, C.POINTER(SampleArgs), vp]),
+        "lemas_dit_prepare": (C.c_int, [vp, C.POINTER(SampleArgs), vp]),
+        "lemas_dit_solve": (C.c_int, [vp, C.POINTER(SampleArgs), vp]),
+        "lemas_dit_forward": (C.c_int, [vp, vp, i32, vp, vp]),
+        "lemas_dit_profile_read": (C.c_int, [vp, vp, C.POINTER(C.c_double), C.POINTER(i64), i32]),
+        "lemas_vocos_create": (C.c_int, [i32, i32, i32, i32, i32, i32, C.POINTER(vp)]),
+        "lemas_vocos_destroy": (None, [vp]),
+        "lemas_vocos_load_weight": (C.c_int, [vp, C.c_char_p, vp, C.POINTER(i64), i32]),
+        "lemas_vocos_finalize": (C.c_int, [vp]),
+        "lemas_vocos_decode": (C.c_int, [vp, vp, i32, i32, f32, vp, vp]),
+        "lemas_k_linear_bf16": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+        "lemas_k_linear_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+        "lemas_k_attention": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+        "lemas_k_ln_mod": (C.c_int, [vp, vp, vp, vp, i32, i32, vp]),
+        "lemas_k_convpos": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+EXPORTED = [
+    "lemas_last_error", "lemas_version", "lemas_dit_create", "lemas_dit_destroy", "lemas_dit_load_weight",
+    "lemas_dit_finalize", "lemas_dit_set_option", "lemas_dit_sample", "lemas_dit_prepare", "lemas_dit_solve",
+    "lemas_dit_forward", "lemas_dit_profile_read", "lemas_vocos_create", "lemas_vocos_destroy",
+    "lemas_vocos_load_weight", "lemas_vocos_finalize", "lemas_vocos_decode", "lemas_k_linear_bf16",
+    "lemas_k_linear_f32", "lemas_k_attention", "lemas_k_ln_mod", "lemas_k_convpos",
+]
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().lemas_last_error()
+        raise LemasError(f"{what} failed with code {rc}: {msg.decode() if msg else ''}")

@@ -1,0 +1,132 @@
+// Shared device helpers and internal launch prototypes for liblemas_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define LEMAS_WAVE 64
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+  // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)));  tanh(u) = 1 - 2/(1+exp(2u))
+  const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+  const float e = __expf(2.0f * u);
+  const float th = 1.0f - 2.0f / (1.0f + e);
+  return 0.5f * x * (1.0f + th);
+}
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float mish_f(float x) {
+  // x * tanh(softplus(x)); with n = e^x (e^x + 2): tanh(log(1+e^x)) = n / (n + 2).  softplus threshold 20 as torch.
+  const float xe = fminf(x, 20.0f);
+  const float e = __expf(xe);
+  const float n = e * (e + 2.0f);
+  return x * (n / (n + 2.0f));
+}
+
+// ---- epilogue selectors of the bf16 MFMA GEMM -------------------------------------------------
+enum GemmEpi : int {
+  EPI_BIAS_BF16 = 0,       // out_bf16[m][n] = acc + bias
+  EPI_BIAS_GELU_BF16 = 1,  // out_bf16[m][n] = gelu_tanh(acc + bias)
+  EPI_BIAS_F32 = 2,        // out_f32[m][n] = acc + bias      (n < n_valid)
+  EPI_GATE_RES = 3,        // res_f32[m][n] += gate[n] * (acc + bias)   (rows past kv_len contribute 0)
+  EPI_QKV_ROPE = 4,        // +bias, RoPE on q/k, scatter to q/k [B2,H,N,64] and v^T [B2,H,64,Npad]
+};
+
+struct GemmParams {
+  const bf16_t* A;  // [M, K] row-major activations
+  const bf16_t* W;  // [Nw, K] row-major weights (nn.Linear layout), Nw padded to a multiple of 128
+  const float* bias;  // [Nw]
+  int M, N, K;        // N = padded Nw
+  int n_valid;        // columns actually stored
+  // outputs
+  bf16_t* out_bf16;
+  float* out_f32;
+  int ldc;
+  // gate/residual epilogue: gate vector lives in the per-step AdaLN table
+  const float* tab;      // table base (step 0)
+  int tab_stride;        // floats per step
+  int gate_off;          // offset of the gate vector inside a step row
+  const int* step_idx;   // device scalar: current ODE step
+  const int* kv_len;     // [B] valid frames per sample or nullptr
+  int seq_len;           // frames per sample (rows m -> (m / seq_len, m % seq_len))
+  int batch;             // B (kv_len index = (m / seq_len) % batch)
+  // qkv epilogue
+  bf16_t* q;
+  bf16_t* k;
+  bf16_t* vt;
+  const float* rope_cos;  // [seq_len, 32]
+  const float* rope_sin;
+  int heads, npad;
+};
+
+// ---- internal launchers (one per .hip translation unit) ----------------------------------------
+hipError_t launch_gemm_bf16(int epi, const GemmParams& p, hipStream_t s);
+
+struct AttnParams {
+  const bf16_t* q;   // [B2, H, N, 64]
+  const bf16_t* k;   // [B2, H, N, 64]
+  const bf16_t* vt;  // [B2, H, 64, Npad]
+  bf16_t* out;       // [B2*N, H*64]
+  const int* kv_len; // [B] or nullptr
+  int b2, batch, heads, n, npad;
+  float scale;
+};
+hipError_t launch_attention(const AttnParams& p, hipStream_t s);
+
+// out_bf16[m][c] = LN(x[m][:])[c] * (1 + scale[c]) + shift[c]; scale/shift read from the AdaLN table row of the current step
+hipError_t launch_ln_mod(const float* x, bf16_t* out, int M, int D, const float* tab, int tab_stride,
+                         int scale_off, int shift_off, const int* step_idx, hipStream_t s);
+
+struct ConvPosParams {
+  const float* in_f32;    // conv1 input  [B2*N, C] fp32 (nullptr when in_bf16 is used)
+  const bf16_t* in_bf16;  // conv2 input  [B2*N, C] bf16
+  const bf16_t* w;        // [G][taps][C/G (co)][C/G (ci)] bf16
+  const float* bias;      // [C]
+  bf16_t* out_bf16;       // conv1 output: mish(conv)                bf16
+  float* out_f32;         // conv2 output: mish(conv) + residual     fp32
+  const float* residual;  // [B2*N, C] fp32
+  int b2, n, channels, groups, taps;
+};
+hipError_t launch_convpos(const ConvPosParams& p, hipStream_t s);
+
+// y += dt * clamp(pred + (pred - null) * cfg_t, -20, 20); optionally records y into traj[step+1]; step counter++ by one thread
+hipError_t launch_cfg_euler(float* y, const float* pred /*[2B*N,100] cond rows then uncond rows*/, int rows, int cols,
+                            const float* dt_tab, const float* cfg_tab, int* step_idx, float* traj, int use_cfg, hipStream_t s);
+
+// ---- fp32 (exact) GEMM on f32 MFMA for the once-per-utterance and vocoder work --------------------
+enum F32Epi : int {
+  F32_BIAS = 0,        // out = acc + bias
+  F32_BIAS_GELU = 1,   // out = gelu_erf(acc + bias)
+  F32_BIAS_SILU = 2,   // out = silu(acc + bias)
+  F32_BIAS_RES_SCALE = 3,  // out = res + colscale[n] * (acc + bias)      (colscale may be null => 1)
+  F32_BIAS_ADD2 = 4,   // out[m] = acc + bias? + add[m] and out[m + M] = acc + add[m + M]  (input-proj x-part broadcast to cond/uncond)
+};
+struct GemmF32Params {
+  const float* A; int lda;   // [M, K]
+  const float* W; int ldw;   // [N, K]
+  const float* bias;         // [N] or null
+  float* out; int ldc;
+  int M, N, K;
+  const float* res; int ldres;
+  const float* colscale;
+  const float* add;          // for F32_BIAS_ADD2: [2M, N]
+  const uint8_t* rowmask;    // optional: rows with rowmask[m]!=0 are written as 0
+};
+hipError_t launch_gemm_f32(int epi, const GemmF32Params& p, hipStream_t s);

@@ -1,0 +1,83 @@
+// Host-side plumbing shared by the engine translation units: error reporting, device buffers, weight registry.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/lemas_hip.h"
+#include "common.h"
+#include "kernels.h"
+
+namespace lemas {
+
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define HIP_TRY(expr)                                                        \
+  do {                                                                       \
+    hipError_t _e = (expr);                                                  \
+    if (_e != hipSuccess) return ::lemas::hip_fail(_e, #expr, __FILE__, __LINE__); \
+  } while (0)
+
+#define RC_TRY(expr)          \
+  do {                        \
+    int _rc = (expr);         \
+    if (_rc != 0) return _rc; \
+  } while (0)
+
+// Growable device allocation.  `generation` bumps on every (re)allocation so cached hipGraphs that baked the old
+// address can be invalidated.
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  static unsigned long long generation;
+  int ensure(size_t n) {
+    if (n <= bytes) return 0;
+    if (p) HIP_TRY(hipFree(p));
+    p = nullptr;
+    bytes = 0;
+    n = (n + 255) & ~(size_t)255;
+    HIP_TRY(hipMalloc(&p, n));
+    HIP_TRY(hipMemset(p, 0, n));  // pad regions must stay finite (attention v^T tail)
+    bytes = n;
+    ++generation;
+    return 0;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  template <typename T>
+  T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct Tensor {
+  float* dev = nullptr;  // fp32 copy on device
+  std::vector<int64_t> shape;
+  size_t numel = 0;
+};
+
+// name -> fp32 device tensor, with a declared schema for strict loading (utils_infer.py:237 load_state_dict strict)
+struct WeightStore {
+  std::map<std::string, std::vector<int64_t>> schema;
+  std::map<std::string, Tensor> t;
+  void declare(const std::string& name, std::vector<int64_t> shape) { schema[name] = std::move(shape); }
+  int load(const char* name, const float* host, const int64_t* shape, int ndim);
+  int check_complete() const;
+  const Tensor* find(const std::string& name) const {
+    auto it = t.find(name);
+    return it == t.end() ? nullptr : &it->second;
+  }
+  float* ptr(const std::string& name) const {
+    const Tensor* x = find(name);
+    return x ? x->dev : nullptr;
+  }
+  void release();
+};
+
+}  // namespace lemas

@@ -1,0 +1,73 @@
+// Error reporting and the strict fp32 weight registry shared by the DiT and Vocos engines.
+#include "engine_common.h"
+
+#include <cstring>
+
+namespace lemas {
+
+static thread_local char g_err[512] = "";
+unsigned long long DevBuf::generation = 1;
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+  set_error("HIP error %d (%s) at %s:%d in %s", (int)e, hipGetErrorString(e), file, line, what);
+  (void)hipGetLastError();
+  return -(int)e;
+}
+
+int WeightStore::load(const char* name, const float* host, const int64_t* shape, int ndim) {
+  auto it = schema.find(name);
+  if (it == schema.end()) {
+    set_error("unexpected tensor '%s' (strict load)", name);
+    return LEMAS_E_WEIGHT;
+  }
+  const std::vector<int64_t>& want = it->second;
+  bool ok = (int)want.size() == ndim;
+  size_t numel = 1;
+  for (int i = 0; i < ndim && ok; ++i) {
+    ok = want[i] == shape[i];
+    numel *= (size_t)shape[i];
+  }
+  if (!ok) {
+    set_error("tensor '%s' has the wrong shape (ndim %d)", name, ndim);
+    return LEMAS_E_WEIGHT;
+  }
+  Tensor& x = t[name];
+  if (x.dev) HIP_TRY(hipFree(x.dev));
+  x.dev = nullptr;
+  // +64 floats of slack: the fp32 GEMM reads whole float4 groups of offset sub-matrices (input_embed.proj columns)
+  HIP_TRY(hipMalloc((void**)&x.dev, (numel + 64) * sizeof(float)));
+  HIP_TRY(hipMemset(x.dev, 0, (numel + 64) * sizeof(float)));
+  HIP_TRY(hipMemcpy(x.dev, host, numel * sizeof(float), hipMemcpyHostToDevice));
+  x.shape.assign(shape, shape + ndim);
+  x.numel = numel;
+  return 0;
+}
+
+int WeightStore::check_complete() const {
+  for (const auto& kv : schema)
+    if (t.find(kv.first) == t.end()) {
+      set_error("missing tensor '%s' (strict load)", kv.first.c_str());
+      return LEMAS_E_WEIGHT;
+    }
+  return 0;
+}
+
+void WeightStore::release() {
+  for (auto& kv : t)
+    if (kv.second.dev) (void)hipFree(kv.second.dev);
+  t.clear();
+}
+
+}  // namespace lemas
+
+extern "C" {
+const char* lemas_last_error(void) { return lemas::g_err; }
+int lemas_version(void) { return 100; }
+}

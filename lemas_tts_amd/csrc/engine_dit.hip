@@ -1,0 +1,599 @@
+// lemas_dit: the flow-matching sampler engine (CFM.sample, lemas_tts/model/cfm.py:206-473) on MI355X.
+//
+// Structure of one utterance batch (B samples, N frames, S = NFE steps):
+//   prepare():  everything that does not depend on the ODE state, computed ONCE in fp32
+//       - conditioning: cond (+ prosody_to_mel), step_cond = where(mask, cond, 0)        cfm.py:311-318,388-390
+//       - text embedding for the text and dropped-text CFG branches                       dit.py:51-81 (reference caches per branch, :212-220)
+//       - prosody text conditioning added to both branches                               dit.py:225-233
+//       - the [cond | text] part of the input projection + bias (exact algebraic split)  dit.py:97
+//       - time MLP and ALL AdaLN modulation vectors for all S steps (depend on t only)   modules.py:311,332,727-731
+//       - rotary cos/sin table for N                                                     dit.py:236
+//   solve():    S Euler steps; one step = one DiT forward over 2B rows-batches (CFG folded into the batch, the
+//               reference runs the two branches sequentially, cfm.py:393-417) + fused CFG/clamp/Euler update.
+//               The step's ~165 launches are captured once per shape into a hipGraph and replayed; the step
+//               index lives in device memory so the same graph serves every step.
+#include <cmath>
+#include <cstring>
+
+#include "engine_common.h"
+
+namespace lemas {
+
+enum ProfClass { PC_INPROJ, PC_CONVPOS, PC_LN, PC_GEMM_QKV, PC_ATTN, PC_GEMM_OUT, PC_GEMM_FF1, PC_GEMM_FF2, PC_GEMM_FINAL,
+                 PC_CFG_EULER, PC_COUNT };
+static const char* kProfNames[PC_COUNT] = {"inproj_f32", "convpos", "ln_mod", "gemm_qkv_rope", "attention", "gemm_attn_out",
+                                           "gemm_ff1_gelu", "gemm_ff2", "gemm_proj_out", "cfg_euler"};
+
+struct BlockW {
+  DevBuf wqkv, wo, w1, w2;  // bf16
+  DevBuf bqkv;              // fp32 [3*inner]
+  const float *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
+};
+
+}  // namespace lemas
+
+using namespace lemas;
+
+struct lemas_dit {
+  lemas_dit_config cfg{};
+  WeightStore ws;
+  bool finalized = false;
+  bool use_graph = true;
+  bool profile = false;
+
+  std::vector<BlockW> blocks;
+  DevBuf wproj_out, bproj_out;  // padded to 128 rows
+  DevBuf wconv[2];              // [G][taps][64][64] bf16
+
+  // --- per-shape state (valid after prepare)
+  int B = 0, N = 0, F = 0, Nt = 0, S = 0, BB = 0, npad = 0;
+  bool use_cfg = true, has_len = false, prepared = false;
+  std::vector<float> tgrid_cached;
+  int rope_n = 0;
+  std::vector<float> h_dt, h_cfg, h_t;
+
+  DevBuf d_step, d_dt, d_cfg, d_t, d_tab, d_rope_cos, d_rope_sin, d_len;
+  DevBuf d_sin, d_h1, d_temb, d_st;                       // time path scratch
+  DevBuf d_cond_eff, d_step_cond, d_pm, d_pt;             // conditioning
+  DevBuf d_te, d_rowmask, d_t1, d_t2, d_t3, d_gx, d_ct;   // text embedding scratch
+  DevBuf d_pconst, d_y, d_xres, d_hbf, d_q, d_k, d_vt, d_abf, d_ff, d_cmid, d_pred;
+  int tab_stride = 0;
+
+  std::map<std::string, hipGraphExec_t> graphs;
+  unsigned long long graph_generation = 0;
+
+  struct ProfRec { hipEvent_t a, b; int cls; };
+  std::vector<ProfRec> prof;
+
+  ~lemas_dit() {
+    for (auto& g : graphs) (void)hipGraphExecDestroy(g.second);
+    for (auto& r : prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (DevBuf* b : {&wproj_out, &bproj_out, &wconv[0], &wconv[1], &d_step, &d_dt, &d_cfg, &d_t, &d_tab, &d_rope_cos,
+                      &d_rope_sin, &d_len, &d_sin, &d_h1, &d_temb, &d_st, &d_cond_eff, &d_step_cond, &d_pm, &d_pt, &d_te,
+                      &d_rowmask, &d_t1, &d_t2, &d_t3, &d_gx, &d_ct, &d_pconst, &d_y, &d_xres, &d_hbf, &d_q, &d_k, &d_vt,
+                      &d_abf, &d_ff, &d_cmid, &d_pred})
+      b->release();
+    for (auto& b : blocks) { b.wqkv.release(); b.wo.release(); b.w1.release(); b.w2.release(); b.bqkv.release(); }
+    ws.release();
+  }
+
+  int inner() const { return cfg.heads * cfg.dim_head; }
+  std::string T(const std::string& s) const { return "transformer." + s; }
+
+  void declare_schema();
+  int finalize();
+  int prepare(const lemas_sample_args* a, hipStream_t s);
+  int solve(const lemas_sample_args* a, hipStream_t s);
+  int enqueue_forward(hipStream_t s);
+  int enqueue_update(float* traj, hipStream_t s);
+  int build_tables(const lemas_sample_args* a, hipStream_t s);
+  int text_embed(const lemas_sample_args* a, hipStream_t s);
+
+  // profiling helpers
+  int pbegin(int cls, hipStream_t s) {
+    if (!profile) return 0;
+    ProfRec r;
+    r.cls = cls;
+    HIP_TRY(hipEventCreate(&r.a));
+    HIP_TRY(hipEventCreate(&r.b));
+    HIP_TRY(hipEventRecord(r.a, s));
+    prof.push_back(r);
+    return 0;
+  }
+  int pend(hipStream_t s) {
+    if (!profile) return 0;
+    HIP_TRY(hipEventRecord(prof.back().b, s));
+    return 0;
+  }
+};
+
+void lemas_dit::declare_schema() {
+  const int64_t d = cfg.dim, td = cfg.text_dim, in = inner(), md = cfg.mel_dim;
+  auto D = [&](const std::string& n, std::vector<int64_t> sh) { ws.declare(n, std::move(sh)); };
+  D(T("time_embed.time_mlp.0.weight"), {d, cfg.time_freq_dim});
+  D(T("time_embed.time_mlp.0.bias"), {d});
+  D(T("time_embed.time_mlp.2.weight"), {d, d});
+  D(T("time_embed.time_mlp.2.bias"), {d});
+  D(T("time_embed.freqs"), {cfg.time_freq_dim / 2});
+  D(T("text_embed.text_embed.weight"), {cfg.vocab_rows, td});
+  D(T("text_embed.freqs_cis"), {4096, td});
+  for (int i = 0; i < cfg.conv_layers; ++i) {
+    const std::string p = T("text_embed.text_blocks." + std::to_string(i) + ".");
+    D(p + "dwconv.weight", {td, 1, 7});
+    D(p + "dwconv.bias", {td});
+    D(p + "norm.weight", {td});
+    D(p + "norm.bias", {td});
+    D(p + "pwconv1.weight", {2 * td, td});
+    D(p + "pwconv1.bias", {2 * td});
+    D(p + "grn.gamma", {1, 1, 2 * td});
+    D(p + "grn.beta", {1, 1, 2 * td});
+    D(p + "pwconv2.weight", {td, 2 * td});
+    D(p + "pwconv2.bias", {td});
+  }
+  if (cfg.has_prosody) {
+    D(T("prosody_text_proj.weight"), {td, 512});
+    D(T("prosody_text_proj.bias"), {td});
+    D("prosody_to_mel.weight", {md, 512});
+    D("prosody_to_mel.bias", {md});
+  }
+  D(T("input_embed.proj.weight"), {d, 2 * md + td});
+  D(T("input_embed.proj.bias"), {d});
+  for (int j : {0, 2}) {
+    D(T("input_embed.conv_pos_embed.conv1d." + std::to_string(j) + ".weight"), {d, d / cfg.conv_pos_groups, cfg.conv_pos_kernel});
+    D(T("input_embed.conv_pos_embed.conv1d." + std::to_string(j) + ".bias"), {d});
+  }
+  D(T("rotary_embed.inv_freq"), {cfg.dim_head / 2});
+  for (int i = 0; i < cfg.depth; ++i) {
+    const std::string p = T("transformer_blocks." + std::to_string(i) + ".");
+    D(p + "attn_norm.linear.weight", {6 * d, d});
+    D(p + "attn_norm.linear.bias", {6 * d});
+    for (const char* n : {"to_q", "to_k", "to_v"}) {
+      D(p + "attn." + n + ".weight", {in, d});
+      D(p + "attn." + n + ".bias", {in});
+    }
+    D(p + "attn.to_out.0.weight", {d, in});
+    D(p + "attn.to_out.0.bias", {d});
+    D(p + "ff.ff.0.0.weight", {(int64_t)cfg.ff_mult * d, d});
+    D(p + "ff.ff.0.0.bias", {(int64_t)cfg.ff_mult * d});
+    D(p + "ff.ff.2.weight", {d, (int64_t)cfg.ff_mult * d});
+    D(p + "ff.ff.2.bias", {d});
+  }
+  D(T("norm_out.linear.weight"), {2 * d, d});
+  D(T("norm_out.linear.bias"), {2 * d});
+  D(T("proj_out.weight"), {md, d});
+  D(T("proj_out.bias"), {md});
+}
+
+int lemas_dit::finalize() {
+  RC_TRY(ws.check_complete());
+  const int d = cfg.dim, in = inner(), ffd = cfg.ff_mult * d;
+  hipStream_t s = nullptr;
+  blocks.resize(cfg.depth);
+  for (int i = 0; i < cfg.depth; ++i) {
+    const std::string p = T("transformer_blocks." + std::to_string(i) + ".");
+    BlockW& b = blocks[i];
+    RC_TRY(b.wqkv.ensure((size_t)3 * in * d * 2));
+    RC_TRY(b.bqkv.ensure((size_t)3 * in * 4));
+    int j = 0;
+    for (const char* n : {"to_q", "to_k", "to_v"}) {
+      HIP_TRY(launch_f32_to_bf16(ws.ptr(p + "attn." + n + ".weight"), b.wqkv.as<bf16_t>() + (size_t)j * in * d, (size_t)in * d, s));
+      HIP_TRY(hipMemcpyAsync(b.bqkv.as<float>() + (size_t)j * in, ws.ptr(p + "attn." + n + ".bias"), (size_t)in * 4,
+                             hipMemcpyDeviceToDevice, s));
+      ++j;
+    }
+    RC_TRY(b.wo.ensure((size_t)d * in * 2));
+    HIP_TRY(launch_f32_to_bf16(ws.ptr(p + "attn.to_out.0.weight"), b.wo.as<bf16_t>(), (size_t)d * in, s));
+    RC_TRY(b.w1.ensure((size_t)ffd * d * 2));
+    HIP_TRY(launch_f32_to_bf16(ws.ptr(p + "ff.ff.0.0.weight"), b.w1.as<bf16_t>(), (size_t)ffd * d, s));
+    RC_TRY(b.w2.ensure((size_t)d * ffd * 2));
+    HIP_TRY(launch_f32_to_bf16(ws.ptr(p + "ff.ff.2.weight"), b.w2.as<bf16_t>(), (size_t)d * ffd, s));
+    b.bo = ws.ptr(p + "attn.to_out.0.bias");
+    b.b1 = ws.ptr(p + "ff.ff.0.0.bias");
+    b.b2 = ws.ptr(p + "ff.ff.2.bias");
+  }
+  // proj_out padded to 128 output rows (zero rows beyond mel_dim; DevBuf memsets to 0)
+  RC_TRY(wproj_out.ensure((size_t)128 * d * 2));
+  RC_TRY(bproj_out.ensure((size_t)128 * 4));
+  HIP_TRY(launch_f32_to_bf16(ws.ptr(T("proj_out.weight")), wproj_out.as<bf16_t>(), (size_t)cfg.mel_dim * d, s));
+  HIP_TRY(hipMemcpyAsync(bproj_out.p, ws.ptr(T("proj_out.bias")), (size_t)cfg.mel_dim * 4, hipMemcpyDeviceToDevice, s));
+  const int cg = d / cfg.conv_pos_groups;
+  for (int j = 0; j < 2; ++j) {
+    RC_TRY(wconv[j].ensure((size_t)d * cg * cfg.conv_pos_kernel * 2));
+    HIP_TRY(launch_convpos_weight(ws.ptr(T("input_embed.conv_pos_embed.conv1d." + std::to_string(j * 2) + ".weight")),
+                                  wconv[j].as<bf16_t>(), d, cg, cfg.conv_pos_kernel, s));
+  }
+  RC_TRY(d_step.ensure(64));
+  HIP_TRY(hipStreamSynchronize(s));
+  tab_stride = cfg.depth * 6 * d + 2 * d;
+  finalized = true;
+  return 0;
+}
+
+// time MLP + AdaLN vectors for every step, dt / cfg_t tables, rotary table
+int lemas_dit::build_tables(const lemas_sample_args* a, hipStream_t s) {
+  const int d = cfg.dim;
+  const int Snew = a->steps;
+  std::vector<float> tg(a->t_grid, a->t_grid + Snew + 1);
+  h_dt.resize(Snew);
+  h_cfg.resize(Snew);
+  for (int k = 0; k < Snew; ++k) {
+    h_dt[k] = tg[k + 1] - tg[k];                 // torchdiffeq: dt = t1 - t0 in the grid dtype (fp32)
+    const float omt = 1.0f - tg[k];
+    h_cfg[k] = a->cfg_strength * (omt * omt);    // cfm.py:420
+  }
+  RC_TRY(d_dt.ensure((size_t)Snew * 4));
+  RC_TRY(d_cfg.ensure((size_t)Snew * 4));
+  HIP_TRY(hipMemcpyAsync(d_dt.p, h_dt.data(), (size_t)Snew * 4, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(d_cfg.p, h_cfg.data(), (size_t)Snew * 4, hipMemcpyHostToDevice, s));
+
+  if (tg != tgrid_cached) {
+    h_t = tg;
+    RC_TRY(d_t.ensure((size_t)(Snew + 1) * 4));
+    HIP_TRY(hipMemcpyAsync(d_t.p, h_t.data(), (size_t)(Snew + 1) * 4, hipMemcpyHostToDevice, s));
+    const int fd = cfg.time_freq_dim;
+    RC_TRY(d_sin.ensure((size_t)Snew * fd * 4));
+    RC_TRY(d_h1.ensure((size_t)Snew * d * 4));
+    RC_TRY(d_temb.ensure((size_t)Snew * d * 4));
+    RC_TRY(d_st.ensure((size_t)Snew * d * 4));
+    RC_TRY(d_tab.ensure((size_t)Snew * tab_stride * 4));
+    HIP_TRY(launch_time_sinus(d_t.as<float>(), ws.ptr(T("time_embed.freqs")), Snew, fd / 2, d_sin.as<float>(), s));
+    GemmF32Params g{};
+    g.A = d_sin.as<float>(); g.lda = fd; g.W = ws.ptr(T("time_embed.time_mlp.0.weight")); g.ldw = fd;
+    g.bias = ws.ptr(T("time_embed.time_mlp.0.bias")); g.out = d_h1.as<float>(); g.ldc = d; g.M = Snew; g.N = d; g.K = fd;
+    HIP_TRY(launch_gemm_f32(F32_BIAS_SILU, g, s));
+    g.A = d_h1.as<float>(); g.lda = d; g.W = ws.ptr(T("time_embed.time_mlp.2.weight")); g.ldw = d;
+    g.bias = ws.ptr(T("time_embed.time_mlp.2.bias")); g.out = d_temb.as<float>(); g.K = d;
+    HIP_TRY(launch_gemm_f32(F32_BIAS, g, s));
+    HIP_TRY(launch_silu(d_temb.as<float>(), d_st.as<float>(), (size_t)Snew * d, s));
+    g.A = d_st.as<float>(); g.lda = d; g.ldw = d; g.K = d; g.ldc = tab_stride;
+    for (int l = 0; l < cfg.depth; ++l) {
+      const std::string p = T("transformer_blocks." + std::to_string(l) + ".attn_norm.linear.");
+      g.W = ws.ptr(p + "weight"); g.bias = ws.ptr(p + "bias"); g.N = 6 * d;
+      g.out = d_tab.as<float>() + (size_t)l * 6 * d;
+      HIP_TRY(launch_gemm_f32(F32_BIAS, g, s));
+    }
+    g.W = ws.ptr(T("norm_out.linear.weight")); g.bias = ws.ptr(T("norm_out.linear.bias")); g.N = 2 * d;
+    g.out = d_tab.as<float>() + (size_t)cfg.depth * 6 * d;
+    HIP_TRY(launch_gemm_f32(F32_BIAS, g, s));
+    tgrid_cached = tg;
+  }
+  if (rope_n != a->frames) {
+    const int half = cfg.dim_head / 2;
+    RC_TRY(d_rope_cos.ensure((size_t)a->frames * half * 4));
+    RC_TRY(d_rope_sin.ensure((size_t)a->frames * half * 4));
+    HIP_TRY(launch_rope_table(d_rope_cos.as<float>(), d_rope_sin.as<float>(), a->frames, half, ws.ptr(T("rotary_embed.inv_freq")), s));
+    rope_n = a->frames;
+  }
+  return 0;
+}
+
+// TextEmbedding for both CFG branches (dit.py:51-81) + prosody text conditioning (dit.py:225-233)
+int lemas_dit::text_embed(const lemas_sample_args* a, hipStream_t s) {
+  const int td = cfg.text_dim, rows = BB * N, branches = BB / B;
+  RC_TRY(d_te.ensure((size_t)rows * td * 4));
+  RC_TRY(d_rowmask.ensure((size_t)rows));
+  HIP_TRY(launch_text_gather(a->text, B, Nt, N, td, branches, ws.ptr(T("text_embed.text_embed.weight")),
+                             ws.ptr(T("text_embed.freqs_cis")), 4096, d_te.as<float>(), d_rowmask.as<uint8_t>(), s));
+  if (cfg.conv_layers > 0) {
+    RC_TRY(d_t1.ensure((size_t)rows * td * 4));
+    RC_TRY(d_t2.ensure((size_t)rows * td * 4));
+    RC_TRY(d_t3.ensure((size_t)rows * 2 * td * 4));
+    RC_TRY(d_gx.ensure((size_t)BB * 2 * td * 4));
+    for (int i = 0; i < cfg.conv_layers; ++i) {
+      const std::string p = T("text_embed.text_blocks." + std::to_string(i) + ".");
+      HIP_TRY(launch_dwconv7(d_te.as<float>(), ws.ptr(p + "dwconv.weight"), ws.ptr(p + "dwconv.bias"), d_t1.as<float>(), BB, N, td, s));
+      HIP_TRY(launch_ln_affine(d_t1.as<float>(), ws.ptr(p + "norm.weight"), ws.ptr(p + "norm.bias"), d_t2.as<float>(), rows, td, s));
+      GemmF32Params g{};
+      g.A = d_t2.as<float>(); g.lda = td; g.W = ws.ptr(p + "pwconv1.weight"); g.ldw = td; g.bias = ws.ptr(p + "pwconv1.bias");
+      g.out = d_t3.as<float>(); g.ldc = 2 * td; g.M = rows; g.N = 2 * td; g.K = td;
+      HIP_TRY(launch_gemm_f32(F32_BIAS_GELU, g, s));
+      HIP_TRY(launch_grn(d_t3.as<float>(), d_gx.as<float>(), ws.ptr(p + "grn.gamma"), ws.ptr(p + "grn.beta"), BB, N, 2 * td, s));
+      GemmF32Params h{};
+      h.A = d_t3.as<float>(); h.lda = 2 * td; h.W = ws.ptr(p + "pwconv2.weight"); h.ldw = 2 * td; h.bias = ws.ptr(p + "pwconv2.bias");
+      h.out = d_te.as<float>(); h.ldc = td; h.M = rows; h.N = td; h.K = 2 * td;
+      h.res = d_te.as<float>(); h.ldres = td; h.rowmask = d_rowmask.as<uint8_t>();
+      HIP_TRY(launch_gemm_f32(F32_BIAS_RES_SCALE, h, s));
+    }
+  }
+  if (a->prosody && cfg.has_prosody) {
+    RC_TRY(d_pt.ensure((size_t)B * td * 4));
+    GemmF32Params g{};
+    g.A = a->prosody; g.lda = 512; g.W = ws.ptr(T("prosody_text_proj.weight")); g.ldw = 512; g.bias = ws.ptr(T("prosody_text_proj.bias"));
+    g.out = d_pt.as<float>(); g.ldc = td; g.M = B; g.N = td; g.K = 512;
+    HIP_TRY(launch_gemm_f32(F32_BIAS, g, s));
+    const int nlim = Nt < N ? Nt : N;
+    HIP_TRY(launch_add_rowvec(d_te.as<float>(), d_pt.as<float>(), BB, B, N, td, nlim, s));
+  }
+  return 0;
+}
+
+int lemas_dit::prepare(const lemas_sample_args* a, hipStream_t s) {
+  if (!finalized) { set_error("lemas_dit_prepare: weights not finalized"); return LEMAS_E_STATE; }
+  if (a->batch <= 0 || a->frames <= 0 || a->frames > 4096 || a->steps <= 0 || a->text_len <= 0 || !a->cond || !a->cond_mask ||
+      !a->text || !a->t_grid || a->cond_frames <= 0 || a->cond_frames > a->frames) {
+    set_error("lemas_dit_prepare: bad arguments (B=%d N=%d F=%d Nt=%d S=%d)", a->batch, a->frames, a->cond_frames, a->text_len, a->steps);
+    return LEMAS_E_ARG;
+  }
+  if (cfg.dim != 1024 || cfg.dim_head != 64 || cfg.dim / cfg.conv_pos_groups != 64) {
+    set_error("lemas_dit: kernels are specialised for dim 1024, dim_head 64, 64 channels per conv group");
+    return LEMAS_E_ARG;
+  }
+  B = a->batch; N = a->frames; F = a->cond_frames; Nt = a->text_len; S = a->steps;
+  use_cfg = !(a->cfg_strength < 1e-5f);
+  BB = use_cfg ? 2 * B : B;
+  has_len = a->seq_len != nullptr;
+  npad = (N + 63) & ~63;
+  const int d = cfg.dim, md = cfg.mel_dim, td = cfg.text_dim, rows = BB * N, in = inner();
+
+  RC_TRY(build_tables(a, s));
+  if (has_len) {
+    RC_TRY(d_len.ensure((size_t)B * 4));
+    HIP_TRY(hipMemcpyAsync(d_len.p, a->seq_len, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+  }
+  // conditioning
+  RC_TRY(d_cond_eff.ensure((size_t)B * N * md * 4));
+  RC_TRY(d_step_cond.ensure((size_t)B * N * md * 4));
+  const float* pm = nullptr;
+  if (a->prosody && cfg.has_prosody) {
+    RC_TRY(d_pm.ensure((size_t)B * md * 4));
+    GemmF32Params g{};
+    g.A = a->prosody; g.lda = 512; g.W = ws.ptr("prosody_to_mel.weight"); g.ldw = 512; g.bias = nullptr;
+    g.out = d_pm.as<float>(); g.ldc = md; g.M = B; g.N = md; g.K = 512;
+    HIP_TRY(launch_gemm_f32(F32_BIAS, g, s));
+    pm = d_pm.as<float>();
+  }
+  HIP_TRY(launch_cond_prepare(a->cond, a->cond_mask, pm, pm ? ws.ptr("prosody_to_mel.bias") : nullptr, B, N, F, md,
+                              d_cond_eff.as<float>(), d_step_cond.as<float>(), s));
+  RC_TRY(text_embed(a, s));
+  // hoisted [cond | text] part of the input projection
+  RC_TRY(d_ct.ensure((size_t)rows * (md + td) * 4));
+  RC_TRY(d_pconst.ensure((size_t)rows * d * 4));
+  HIP_TRY(launch_concat_ct(d_step_cond.as<float>(), d_te.as<float>(), B, N, md, td, BB / B, d_ct.as<float>(), s));
+  {
+    GemmF32Params g{};
+    g.A = d_ct.as<float>(); g.lda = md + td; g.W = ws.ptr(T("input_embed.proj.weight")) + md; g.ldw = 2 * md + td;
+    g.bias = ws.ptr(T("input_embed.proj.bias")); g.out = d_pconst.as<float>(); g.ldc = d; g.M = rows; g.N = d; g.K = md + td;
+    HIP_TRY(launch_gemm_f32(F32_BIAS, g, s));
+  }
+  // step-loop workspaces
+  RC_TRY(d_y.ensure((size_t)B * N * md * 4));
+  RC_TRY(d_xres.ensure((size_t)rows * d * 4));
+  RC_TRY(d_hbf.ensure((size_t)rows * d * 2));
+  RC_TRY(d_abf.ensure((size_t)rows * in * 2));
+  RC_TRY(d_q.ensure((size_t)rows * in * 2));
+  RC_TRY(d_k.ensure((size_t)rows * in * 2));
+  RC_TRY(d_vt.ensure((size_t)BB * cfg.heads * 64 * npad * 2));
+  RC_TRY(d_ff.ensure((size_t)rows * cfg.ff_mult * d * 2));
+  RC_TRY(d_cmid.ensure((size_t)rows * d * 2));
+  RC_TRY(d_pred.ensure((size_t)rows * md * 4));
+  prepared = true;
+  return 0;
+}
+
+int lemas_dit::enqueue_forward(hipStream_t s) {
+  const int d = cfg.dim, md = cfg.mel_dim, rows = BB * N, in = inner(), ffd = cfg.ff_mult * d;
+  const int* step = d_step.as<int>();
+  const float* tab = d_tab.as<float>();
+  // input projection, x part (K = mel_dim) in fp32, broadcast onto both CFG branches  (dit.py:97)
+  {
+    RC_TRY(pbegin(PC_INPROJ, s));
+    GemmF32Params g{};
+    g.A = d_y.as<float>(); g.lda = md; g.W = ws.ptr(T("input_embed.proj.weight")); g.ldw = 2 * md + cfg.text_dim;
+    g.out = d_xres.as<float>(); g.ldc = d; g.M = B * N; g.N = d; g.K = md;
+    if (use_cfg) {
+      g.add = d_pconst.as<float>();
+      HIP_TRY(launch_gemm_f32(F32_BIAS_ADD2, g, s));
+    } else {
+      g.res = d_pconst.as<float>(); g.ldres = d;
+      HIP_TRY(launch_gemm_f32(F32_BIAS_RES_SCALE, g, s));
+    }
+    RC_TRY(pend(s));
+  }
+  // conv position embedding + residual (dit.py:98)
+  {
+    RC_TRY(pbegin(PC_CONVPOS, s));
+    ConvPosParams c{};
+    c.b2 = BB; c.n = N; c.channels = d; c.groups = cfg.conv_pos_groups; c.taps = cfg.conv_pos_kernel;
+    c.in_f32 = d_xres.as<float>(); c.w = wconv[0].as<bf16_t>(); c.bias = ws.ptr(T("input_embed.conv_pos_embed.conv1d.0.bias"));
+    c.out_bf16 = d_cmid.as<bf16_t>();
+    HIP_TRY(launch_convpos(c, s));
+    c.in_f32 = nullptr; c.in_bf16 = d_cmid.as<bf16_t>(); c.w = wconv[1].as<bf16_t>();
+    c.bias = ws.ptr(T("input_embed.conv_pos_embed.conv1d.2.bias")); c.out_bf16 = nullptr;
+    c.out_f32 = d_xres.as<float>(); c.residual = d_xres.as<float>();
+    HIP_TRY(launch_convpos(c, s));
+    RC_TRY(pend(s));
+  }
+  GemmParams g{};
+  g.M = rows; g.tab = tab; g.tab_stride = tab_stride; g.step_idx = step; g.seq_len = N; g.batch = B;
+  g.heads = cfg.heads; g.npad = npad; g.rope_cos = d_rope_cos.as<float>(); g.rope_sin = d_rope_sin.as<float>();
+  g.q = d_q.as<bf16_t>(); g.k = d_k.as<bf16_t>(); g.vt = d_vt.as<bf16_t>();
+  AttnParams at{};
+  at.q = d_q.as<bf16_t>(); at.k = d_k.as<bf16_t>(); at.vt = d_vt.as<bf16_t>(); at.out = d_abf.as<bf16_t>();
+  at.kv_len = has_len ? d_len.as<int>() : nullptr; at.b2 = BB; at.batch = B; at.heads = cfg.heads; at.n = N; at.npad = npad;
+  at.scale = 1.0f / sqrtf((float)cfg.dim_head);
+  for (int l = 0; l < cfg.depth; ++l) {
+    const BlockW& w = blocks[l];
+    const int base = l * 6 * d;  // [shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp] (modules.py:312)
+    RC_TRY(pbegin(PC_LN, s));
+    HIP_TRY(launch_ln_mod(d_xres.as<float>(), d_hbf.as<bf16_t>(), rows, d, tab, tab_stride, base + d, base, step, s));
+    RC_TRY(pend(s));
+    RC_TRY(pbegin(PC_GEMM_QKV, s));
+    g.A = d_hbf.as<bf16_t>(); g.W = w.wqkv.as<bf16_t>(); g.bias = w.bqkv.as<float>(); g.N = 3 * in; g.K = d; g.n_valid = 3 * in;
+    g.kv_len = nullptr;
+    HIP_TRY(launch_gemm_bf16(EPI_QKV_ROPE, g, s));
+    RC_TRY(pend(s));
+    RC_TRY(pbegin(PC_ATTN, s));
+    HIP_TRY(launch_attention(at, s));
+    RC_TRY(pend(s));
+    RC_TRY(pbegin(PC_GEMM_OUT, s));
+    g.A = d_abf.as<bf16_t>(); g.W = w.wo.as<bf16_t>(); g.bias = w.bo; g.N = d; g.K = in; g.n_valid = d;
+    g.out_f32 = d_xres.as<float>(); g.ldc = d; g.gate_off = base + 2 * d; g.kv_len = has_len ? d_len.as<int>() : nullptr;
+    HIP_TRY(launch_gemm_bf16(EPI_GATE_RES, g, s));
+    RC_TRY(pend(s));
+    RC_TRY(pbegin(PC_LN, s));
+    HIP_TRY(launch_ln_mod(d_xres.as<float>(), d_hbf.as<bf16_t>(), rows, d, tab, tab_stride, base + 4 * d, base + 3 * d, step, s));
+    RC_TRY(pend(s));
+    RC_TRY(pbegin(PC_GEMM_FF1, s));
+    g.A = d_hbf.as<bf16_t>(); g.W = w.w1.as<bf16_t>(); g.bias = w.b1; g.N = ffd; g.K = d; g.n_valid = ffd;
+    g.out_bf16 = d_ff.as<bf16_t>(); g.ldc = ffd; g.kv_len = nullptr;
+    HIP_TRY(launch_gemm_bf16(EPI_BIAS_GELU_BF16, g, s));
+    RC_TRY(pend(s));
+    RC_TRY(pbegin(PC_GEMM_FF2, s));
+    g.A = d_ff.as<bf16_t>(); g.W = w.w2.as<bf16_t>(); g.bias = w.b2; g.N = d; g.K = ffd; g.n_valid = d;
+    g.out_f32 = d_xres.as<float>(); g.ldc = d; g.gate_off = base + 5 * d;
+    HIP_TRY(launch_gemm_bf16(EPI_GATE_RES, g, s));
+    RC_TRY(pend(s));
+  }
+  // final AdaLN (order scale, shift: modules.py:333) + proj_out
+  const int fb = cfg.depth * 6 * d;
+  RC_TRY(pbegin(PC_LN, s));
+  HIP_TRY(launch_ln_mod(d_xres.as<float>(), d_hbf.as<bf16_t>(), rows, d, tab, tab_stride, fb, fb + d, step, s));
+  RC_TRY(pend(s));
+  RC_TRY(pbegin(PC_GEMM_FINAL, s));
+  g.A = d_hbf.as<bf16_t>(); g.W = wproj_out.as<bf16_t>(); g.bias = bproj_out.as<float>(); g.N = 128; g.K = d; g.n_valid = md;
+  g.out_f32 = d_pred.as<float>(); g.ldc = md; g.kv_len = nullptr;
+  HIP_TRY(launch_gemm_bf16(EPI_BIAS_F32, g, s));
+  RC_TRY(pend(s));
+  return 0;
+}
+
+int lemas_dit::enqueue_update(float* traj, hipStream_t s) {
+  RC_TRY(pbegin(PC_CFG_EULER, s));
+  HIP_TRY(launch_cfg_euler(d_y.as<float>(), d_pred.as<float>(), B * N, cfg.mel_dim, d_dt.as<float>(), d_cfg.as<float>(),
+                           d_step.as<int>(), traj, use_cfg ? 1 : 0, s));
+  RC_TRY(pend(s));
+  return 0;
+}
+
+int lemas_dit::solve(const lemas_sample_args* a, hipStream_t s) {
+  if (!prepared) { set_error("lemas_dit_solve: prepare() has not run"); return LEMAS_E_STATE; }
+  if (a->batch != B || a->frames != N || a->steps != S || !a->y) { set_error("lemas_dit_solve: arguments differ from prepare()"); return LEMAS_E_ARG; }
+  const size_t ybytes = (size_t)B * N * cfg.mel_dim * 4;
+  HIP_TRY(hipMemcpyAsync(d_y.p, a->y, ybytes, hipMemcpyDeviceToDevice, s));
+  if (a->trajectory) HIP_TRY(hipMemcpyAsync(a->trajectory, a->y, ybytes, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(launch_step_set(d_step.as<int>(), 0, s));
+
+  const bool graph_ok = use_graph && !profile && !a->trajectory && s != nullptr;  // the legacy NULL stream cannot be captured
+  if (graph_ok) {
+    if (graph_generation != DevBuf::generation) {  // some buffer moved: every captured address is suspect
+      for (auto& g : graphs) (void)hipGraphExecDestroy(g.second);
+      graphs.clear();
+      graph_generation = DevBuf::generation;
+    }
+    char key[96];
+    snprintf(key, sizeof key, "B%d_N%d_cfg%d_len%d", B, N, (int)use_cfg, (int)has_len);
+    auto it = graphs.find(key);
+    if (it == graphs.end()) {
+      hipGraph_t graph = nullptr;
+      HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+      int rc = enqueue_forward(s);
+      if (rc == 0) rc = enqueue_update(nullptr, s);
+      hipError_t e = hipStreamEndCapture(s, &graph);
+      if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+      HIP_TRY(e);
+      hipGraphExec_t exec = nullptr;
+      HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+      HIP_TRY(hipGraphDestroy(graph));
+      it = graphs.emplace(key, exec).first;
+    }
+    for (int k = 0; k < S; ++k) HIP_TRY(hipGraphLaunch(it->second, s));
+  } else {
+    for (int k = 0; k < S; ++k) {
+      RC_TRY(enqueue_forward(s));
+      RC_TRY(enqueue_update(a->trajectory, s));
+    }
+  }
+  HIP_TRY(hipMemcpyAsync(a->y, d_y.p, ybytes, hipMemcpyDeviceToDevice, s));
+  if (a->out)
+    HIP_TRY(launch_select_rows(a->out, d_cond_eff.as<float>(), d_y.as<float>(), a->cond_mask, B * N, cfg.mel_dim, s));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------ C ABI
+extern "C" {
+
+int lemas_dit_create(const lemas_dit_config* cfg, lemas_dit** out) {
+  if (!cfg || !out) { set_error("lemas_dit_create: null argument"); return LEMAS_E_ARG; }
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0) {
+    set_error("lemas_dit_create: no HIP device (this library has no CPU path)");
+    return e != hipSuccess ? -(int)e : LEMAS_E_STATE;
+  }
+  lemas_dit* m = new lemas_dit();
+  m->cfg = *cfg;
+  m->declare_schema();
+  *out = m;
+  return 0;
+}
+void lemas_dit_destroy(lemas_dit* m) { delete m; }
+
+int lemas_dit_load_weight(lemas_dit* m, const char* name, const float* host, const int64_t* shape, int32_t ndim) {
+  if (!m || !name || !host) { set_error("lemas_dit_load_weight: null argument"); return LEMAS_E_ARG; }
+  // loaded-but-unused tensors of the reference checkpoint (cfm.py:171 accent classifier) are accepted and dropped
+  if (strncmp(name, "accent_classifier.", 18) == 0) return 0;
+  m->finalized = false;
+  return m->ws.load(name, host, shape, ndim);
+}
+int lemas_dit_finalize(lemas_dit* m) { return m ? m->finalize() : LEMAS_E_ARG; }
+
+int lemas_dit_set_option(lemas_dit* m, const char* key, int64_t value) {
+  if (!m || !key) return LEMAS_E_ARG;
+  if (!strcmp(key, "graph")) { m->use_graph = value != 0; return 0; }
+  if (!strcmp(key, "profile")) {
+    m->profile = value != 0;
+    for (auto& r : m->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    m->prof.clear();
+    return 0;
+  }
+  set_error("lemas_dit_set_option: unknown option '%s'", key);
+  return LEMAS_E_ARG;
+}
+
+int lemas_dit_prepare(lemas_dit* m, const lemas_sample_args* a, void* stream) {
+  if (!m || !a) return LEMAS_E_ARG;
+  return m->prepare(a, (hipStream_t)stream);
+}
+int lemas_dit_solve(lemas_dit* m, const lemas_sample_args* a, void* stream) {
+  if (!m || !a) return LEMAS_E_ARG;
+  return m->solve(a, (hipStream_t)stream);
+}
+int lemas_dit_sample(lemas_dit* m, const lemas_sample_args* a, void* stream) {
+  if (!m || !a) return LEMAS_E_ARG;
+  RC_TRY(m->prepare(a, (hipStream_t)stream));
+  return m->solve(a, (hipStream_t)stream);
+}
+
+int lemas_dit_forward(lemas_dit* m, const float* x, int32_t step_index, float* pred, void* stream) {
+  if (!m || !x || !pred) return LEMAS_E_ARG;
+  if (!m->prepared) { set_error("lemas_dit_forward: prepare() has not run"); return LEMAS_E_STATE; }
+  if (step_index < 0 || step_index >= m->S) { set_error("lemas_dit_forward: step index out of range"); return LEMAS_E_ARG; }
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(hipMemcpyAsync(m->d_y.p, x, (size_t)m->B * m->N * m->cfg.mel_dim * 4, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(launch_step_set(m->d_step.as<int>(), step_index, s));
+  RC_TRY(m->enqueue_forward(s));
+  HIP_TRY(hipMemcpyAsync(pred, m->d_pred.p, (size_t)m->BB * m->N * m->cfg.mel_dim * 4, hipMemcpyDeviceToDevice, s));
+  return 0;
+}
+
+int lemas_dit_profile_read(lemas_dit* m, char (*names)[32], double* total_ms, int64_t* launches, int32_t cap) {
+  if (!m || !names || !total_ms || !launches) return LEMAS_E_ARG;
+  HIP_TRY(hipDeviceSynchronize());
+  double acc[PC_COUNT] = {0};
+  int64_t cnt[PC_COUNT] = {0};
+  for (auto& r : m->prof) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, r.a, r.b));
+    acc[r.cls] += ms;
+    cnt[r.cls] += 1;
+  }
+  int n = 0;
+  for (int c = 0; c < PC_COUNT && n < cap; ++c, ++n) {
+    snprintf(names[n], 32, "%s", kProfNames[c]);
+    total_ms[n] = acc[c];
+    launches[n] = cnt[c];
+  }
+  return n;
+}
+
+}  // extern "C"

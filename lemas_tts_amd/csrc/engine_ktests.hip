@@ -1,0 +1,143 @@
+// Single-kernel entry points of the C ABI (lemas_k_*): thin drivers that feed fp32 device arrays through the
+// production kernels so the parity tests can localise a failure to one kernel.  They allocate scratch with
+// hipMalloc and synchronise -- test infrastructure, never on the sampling path.
+#include <cmath>
+#include <vector>
+
+#include "engine_common.h"
+
+using namespace lemas;
+
+namespace {
+
+struct Scratch {
+  std::vector<void*> ptrs;
+  ~Scratch() {
+    for (void* p : ptrs) (void)hipFree(p);
+  }
+  template <typename T>
+  T* get(size_t n) {
+    void* p = nullptr;
+    if (hipMalloc(&p, n * sizeof(T) + 256) != hipSuccess) return nullptr;
+    (void)hipMemset(p, 0, n * sizeof(T) + 256);
+    ptrs.push_back(p);
+    return reinterpret_cast<T*>(p);
+  }
+};
+
+__global__ void transpose_v_kernel(const float* v, bf16_t* vt, int BH, int N, int npad) {
+  // v [BH, N, 64] fp32 -> vt [BH, 64, npad] bf16
+  const size_t total = (size_t)BH * N * 64;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int d = (int)(i % 64);
+    const int n = (int)((i / 64) % N);
+    const int bh = (int)(i / ((size_t)64 * N));
+    vt[((size_t)bh * 64 + d) * npad + n] = (bf16_t)v[i];
+  }
+}
+__global__ void widen_kernel(const bf16_t* src, float* dst, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = (float)src[i];
+}
+__global__ void fill_i32_kernel(int* p, int v) { p[0] = v; }
+
+}  // namespace
+
+extern "C" {
+
+int lemas_k_linear_bf16(const float* A, const float* W, const float* bias, float* out, int32_t M, int32_t N, int32_t K,
+                        int32_t act, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (K % 64 != 0) { set_error("lemas_k_linear_bf16: K must be a multiple of 64"); return LEMAS_E_ARG; }
+  Scratch sc;
+  const int Np = (N + 127) & ~127;
+  bf16_t* a = sc.get<bf16_t>((size_t)M * K);
+  bf16_t* w = sc.get<bf16_t>((size_t)Np * K);
+  float* b = sc.get<float>(Np);
+  bf16_t* ob = sc.get<bf16_t>((size_t)M * N);
+  if (!a || !w || !b || !ob) { set_error("lemas_k_linear_bf16: out of memory"); return LEMAS_E_STATE; }
+  HIP_TRY(launch_f32_to_bf16(A, a, (size_t)M * K, s));
+  HIP_TRY(launch_f32_to_bf16(W, w, (size_t)N * K, s));
+  if (bias) HIP_TRY(hipMemcpyAsync(b, bias, (size_t)N * 4, hipMemcpyDeviceToDevice, s));
+  GemmParams p{};
+  p.A = a; p.W = w; p.bias = b; p.M = M; p.N = Np; p.K = K; p.n_valid = N; p.ldc = N;
+  if (act == 1) {
+    p.out_bf16 = ob;
+    HIP_TRY(launch_gemm_bf16(EPI_BIAS_GELU_BF16, p, s));
+    hipLaunchKernelGGL(widen_kernel, dim3(1024), dim3(256), 0, s, ob, out, (size_t)M * N);
+  } else {
+    p.out_f32 = out;
+    HIP_TRY(launch_gemm_bf16(EPI_BIAS_F32, p, s));
+  }
+  HIP_TRY(hipStreamSynchronize(s));
+  return 0;
+}
+
+int lemas_k_linear_f32(const float* A, const float* W, const float* bias, float* out, int32_t M, int32_t N, int32_t K,
+                       int32_t act, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  GemmF32Params p{};
+  p.A = A; p.lda = K; p.W = W; p.ldw = K; p.bias = bias; p.out = out; p.ldc = N; p.M = M; p.N = N; p.K = K;
+  HIP_TRY(launch_gemm_f32(act == 1 ? F32_BIAS_GELU : act == 2 ? F32_BIAS_SILU : F32_BIAS, p, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return 0;
+}
+
+int lemas_k_attention(const float* q, const float* k, const float* v, const int32_t* seq_len, float* out, int32_t B,
+                      int32_t H, int32_t N, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  Scratch sc;
+  const int npad = (N + 63) & ~63;
+  const size_t n = (size_t)B * H * N * 64;
+  bf16_t* qb = sc.get<bf16_t>(n);
+  bf16_t* kb = sc.get<bf16_t>(n);
+  bf16_t* vt = sc.get<bf16_t>((size_t)B * H * 64 * npad);
+  bf16_t* ob = sc.get<bf16_t>(n);
+  if (!qb || !kb || !vt || !ob) { set_error("lemas_k_attention: out of memory"); return LEMAS_E_STATE; }
+  HIP_TRY(launch_f32_to_bf16(q, qb, n, s));
+  HIP_TRY(launch_f32_to_bf16(k, kb, n, s));
+  hipLaunchKernelGGL(transpose_v_kernel, dim3(2048), dim3(256), 0, s, v, vt, B * H, N, npad);
+  AttnParams p{};
+  p.q = qb; p.k = kb; p.vt = vt; p.out = ob; p.kv_len = seq_len; p.b2 = B; p.batch = B; p.heads = H; p.n = N; p.npad = npad;
+  p.scale = 0.125f;
+  HIP_TRY(launch_attention(p, s));
+  hipLaunchKernelGGL(widen_kernel, dim3(1024), dim3(256), 0, s, ob, out, n);
+  HIP_TRY(hipStreamSynchronize(s));
+  return 0;
+}
+
+int lemas_k_ln_mod(const float* x, const float* scale, const float* shift, float* out, int32_t M, int32_t D, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  Scratch sc;
+  float* tab = sc.get<float>((size_t)2 * D);
+  bf16_t* ob = sc.get<bf16_t>((size_t)M * D);
+  if (!tab || !ob) { set_error("lemas_k_ln_mod: out of memory"); return LEMAS_E_STATE; }
+  HIP_TRY(hipMemcpyAsync(tab, scale, (size_t)D * 4, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipMemcpyAsync(tab + D, shift, (size_t)D * 4, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(launch_ln_mod(x, ob, M, D, tab, 0, 0, D, nullptr, s));
+  hipLaunchKernelGGL(widen_kernel, dim3(1024), dim3(256), 0, s, ob, out, (size_t)M * D);
+  HIP_TRY(hipStreamSynchronize(s));
+  return 0;
+}
+
+int lemas_k_convpos(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* out,
+                    int32_t B, int32_t N, int32_t C, int32_t groups, int32_t taps, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  Scratch sc;
+  const int cg = C / groups;
+  bf16_t* wa = sc.get<bf16_t>((size_t)C * cg * taps);
+  bf16_t* wb = sc.get<bf16_t>((size_t)C * cg * taps);
+  bf16_t* mid = sc.get<bf16_t>((size_t)B * N * C);
+  if (!wa || !wb || !mid) { set_error("lemas_k_convpos: out of memory"); return LEMAS_E_STATE; }
+  HIP_TRY(launch_convpos_weight(w1, wa, C, cg, taps, s));
+  HIP_TRY(launch_convpos_weight(w2, wb, C, cg, taps, s));
+  ConvPosParams c{};
+  c.b2 = B; c.n = N; c.channels = C; c.groups = groups; c.taps = taps;
+  c.in_f32 = x; c.w = wa; c.bias = b1; c.out_bf16 = mid;
+  HIP_TRY(launch_convpos(c, s));
+  c.in_f32 = nullptr; c.in_bf16 = mid; c.w = wb; c.bias = b2; c.out_bf16 = nullptr; c.out_f32 = out; c.residual = x;
+  HIP_TRY(launch_convpos(c, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return 0;
+}
+
+}  // extern "C"

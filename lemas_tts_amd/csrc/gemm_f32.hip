@@ -1,0 +1,115 @@
+// Exact-fp32 GEMM on the f32-input matrix cores (v_mfma_f32_16x16x4_f32), with small fused epilogues (gfx950).
+//
+//   out[M, N] = A[M, K] . W[N, K]^T (+ bias ...)        fp32 in, fp32 accumulate == an fmaf chain
+//
+// Used where the path must stay fp32 and the FLOPs are negligible next to the bf16 step loop:
+//   * once per utterance: text ConvNeXtV2 linears (dit.py:73-77), the hoisted cond/text part of the input
+//     projection (dit.py:97), prosody projections, the time MLP + all AdaLN modulation vectors for every ODE
+//     step (modules.py:311,332,727-731) -- the t-grid is known up front;
+//   * once per ODE step: the K=100 "x" part of the input projection (keeps the ODE state path in fp32);
+//   * the Vocos vocoder (all of it: embed conv as im2col GEMM, pointwise convs, head, inverse DFT).
+// Tile 64x64x16, 4 waves as 2x2, each wave 32x32 = 2x2 MFMA tiles.  LDS tiles are stored K-major so the
+// one-float-per-lane fragments are consecutive words (conflict-free ds_read_b32).
+#include "common.h"
+
+namespace {
+
+constexpr int TM = 64, TN = 64, TK = 16, LD = TM + 4;
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Params p) {
+  __shared__ float As[TK][LD];
+  __shared__ float Bs[TK][LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l15 = lane & 15, lk = lane >> 4;
+  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+
+  const int lrow = tid >> 2, lk4 = (tid & 3) * 4;
+  const bool a_ok = (m0 + lrow) < p.M, b_ok = (n0 + lrow) < p.N;
+  const float* ap = p.A + (size_t)(a_ok ? m0 + lrow : 0) * p.lda + lk4;
+  const float* bp = p.W + (size_t)(b_ok ? n0 + lrow : 0) * p.ldw + lk4;
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (p.K + TK - 1) / TK;
+  float4 ra, rb;
+  auto gload = [&](int kt) {
+    const int k = kt * TK + lk4;
+    ra = (a_ok && k < p.K) ? *reinterpret_cast<const float4*>(ap + kt * TK) : make_float4(0.f, 0.f, 0.f, 0.f);
+    rb = (b_ok && k < p.K) ? *reinterpret_cast<const float4*>(bp + kt * TK) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  gload(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    As[lk4 + 0][lrow] = ra.x; As[lk4 + 1][lrow] = ra.y; As[lk4 + 2][lrow] = ra.z; As[lk4 + 3][lrow] = ra.w;
+    Bs[lk4 + 0][lrow] = rb.x; Bs[lk4 + 1][lrow] = rb.y; Bs[lk4 + 2][lrow] = rb.z; Bs[lk4 + 3][lrow] = rb.w;
+    __syncthreads();
+    if (kt + 1 < nk) gload(kt + 1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      float a[2], b[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        a[t] = As[ks * 4 + lk][wm * 32 + t * 16 + l15];
+        b[t] = Bs[ks * 4 + lk][wn * 32 + t * 16 + l15];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // C fragment: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wn * 32 + j * 16 + l15;
+    if (n >= p.N) continue;
+    const float bias = p.bias ? p.bias[n] : 0.f;
+    const float cs = (EPI == F32_BIAS_RES_SCALE && p.colscale) ? p.colscale[n] : 1.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * 32 + i * 16 + lk * 4 + r;
+        if (m >= p.M) continue;
+        float v = acc[i][j][r] + bias;
+        if (EPI == F32_BIAS_GELU) v = gelu_erf_f(v);
+        if (EPI == F32_BIAS_SILU) v = silu_f(v);
+        if (EPI == F32_BIAS_RES_SCALE) v = p.res[(size_t)m * p.ldres + n] + cs * v;
+        if (EPI == F32_BIAS_ADD2) {
+          p.out[(size_t)m * p.ldc + n] = v + p.add[(size_t)m * p.ldc + n];
+          p.out[(size_t)(m + p.M) * p.ldc + n] = v + p.add[(size_t)(m + p.M) * p.ldc + n];
+        } else {
+          if (p.rowmask && p.rowmask[m]) v = 0.f;
+          p.out[(size_t)m * p.ldc + n] = v;
+        }
+      }
+  }
+}
+
+template <int EPI>
+hipError_t launch(const GemmF32Params& p, hipStream_t s) {
+  dim3 grid((p.N + TN - 1) / TN, (p.M + TM - 1) / TM);
+  hipLaunchKernelGGL(gemm_f32_kernel<EPI>, grid, dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_gemm_f32(int epi, const GemmF32Params& p, hipStream_t s) {
+  if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K & 3) || (p.lda & 3) || (p.ldw & 3)) return hipErrorInvalidValue;
+  switch (epi) {
+    case F32_BIAS: return launch<F32_BIAS>(p, s);
+    case F32_BIAS_GELU: return launch<F32_BIAS_GELU>(p, s);
+    case F32_BIAS_SILU: return launch<F32_BIAS_SILU>(p, s);
+    case F32_BIAS_RES_SCALE: return launch<F32_BIAS_RES_SCALE>(p, s);
+    case F32_BIAS_ADD2: return launch<F32_BIAS_ADD2>(p, s);
+  }
+  return hipErrorInvalidValue;
+}

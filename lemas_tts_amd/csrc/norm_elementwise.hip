@@ -1,0 +1,158 @@
+// HBM-bound row/elementwise kernels of the DiT step loop and its per-utterance setup (gfx950).
+//   ln_mod        modules.py:314,637 / :335  LayerNorm(no affine, eps 1e-6) * (1 + scale) + shift  -> bf16
+//   cfg_euler     cfm.py:420-424 + the Euler update of torchdiffeq (call site cfm.py:456)
+//   rope_table    x_transformers RotaryEmbedding.forward_from_seq_len (call site dit.py:236)
+//   misc          fp32->bf16 conversion / weight re-layout used when weights are loaded
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+// one wave per row; D = 1024 -> 16 elements per lane as 4 float4 (coalesced 1 KiB per wave-instruction)
+template <int D>
+__global__ __launch_bounds__(256) void ln_mod_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, int M,
+                                                     const float* __restrict__ tab, int tab_stride, int scale_off,
+                                                     int shift_off, const int* __restrict__ step_idx) {
+  constexpr int PER = D / 256;  // float4 per lane
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int lane = threadIdx.x & 63;
+  const float* base = tab + (step_idx ? (size_t)step_idx[0] * tab_stride : 0);
+  const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * D);
+  float4 v[PER];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    v[i] = xr[lane + 64 * i];
+    s += v[i].x + v[i].y + v[i].z + v[i].w;
+  }
+  const float mean = wave_sum(s) * (1.0f / D);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+    q += a * a + b * b + c * c + d * d;
+  }
+  const float rstd = rsqrtf(wave_sum(q) * (1.0f / D) + 1e-6f);
+  const float4* sc = reinterpret_cast<const float4*>(base + scale_off);
+  const float4* sh = reinterpret_cast<const float4*>(base + shift_off);
+  bf16x4* orow = reinterpret_cast<bf16x4*>(out + (size_t)row * D);
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const float4 a = sc[lane + 64 * i], b = sh[lane + 64 * i];
+    bf16x4 o;
+    o[0] = (bf16_t)((v[i].x - mean) * rstd * (1.0f + a.x) + b.x);
+    o[1] = (bf16_t)((v[i].y - mean) * rstd * (1.0f + a.y) + b.y);
+    o[2] = (bf16_t)((v[i].z - mean) * rstd * (1.0f + a.z) + b.z);
+    o[3] = (bf16_t)((v[i].w - mean) * rstd * (1.0f + a.w) + b.w);
+    orow[lane + 64 * i] = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void cfg_euler_kernel(float* __restrict__ y, const float* __restrict__ pred, int rows,
+                                                        int cols, const float* __restrict__ dt_tab,
+                                                        const float* __restrict__ cfg_tab, int* step_idx,
+                                                        float* __restrict__ traj, int use_cfg) {
+  const int k = step_idx[0];
+  const float dt = dt_tab[k], cg = cfg_tab[k];
+  const size_t total = (size_t)rows * cols;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const float pc = pred[i];
+    float f = pc;
+    if (use_cfg) {
+      const float pu = pred[total + i];
+      f = pc + (pc - pu) * cg;
+      f = fminf(fmaxf(f, -20.0f), 20.0f);
+    }
+    const float yn = y[i] + dt * f;
+    y[i] = yn;
+    if (traj) traj[(size_t)(k + 1) * total + i] = yn;
+  }
+}
+
+// the step counter is advanced by its own 1-thread kernel so that every kernel of step k reads the same value
+__global__ void step_advance_kernel(int* step_idx, int value, int set) { step_idx[0] = set ? value : step_idx[0] + 1; }
+
+__global__ void rope_table_kernel(float* __restrict__ cs, float* __restrict__ sn, int n, int half,
+                                  const float* __restrict__ inv_freq) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * half) return;
+  const int pos = i / half, j = i - pos * half;
+  const float ang = (float)pos * inv_freq[j];  // fp32 product like einsum('i,j->ij') in the reference
+  cs[i] = cosf(ang);
+  sn[i] = sinf(ang);
+}
+
+__global__ void f32_to_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = (bf16_t)src[i];
+}
+
+// conv weight [C_out][Cg (ci)][taps] fp32 -> [G][taps][Cg (co)][Cg (ci)] bf16
+__global__ void convpos_weight_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int C, int cg, int taps) {
+  const size_t total = (size_t)C * cg * taps;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int tap = (int)(i % taps);
+    const int ci = (int)((i / taps) % cg);
+    const int cout = (int)(i / ((size_t)taps * cg));
+    const int g = cout / cg, co = cout - g * cg;
+    dst[(((size_t)g * taps + tap) * cg + co) * cg + ci] = (bf16_t)src[i];
+  }
+}
+
+// step_cond = where(cond_mask, cond, 0) etc. are host-side one-offs; the final out = where(mask, cond, y):
+__global__ void select_rows_kernel(float* __restrict__ out, const float* __restrict__ a, const float* __restrict__ b,
+                                   const uint8_t* __restrict__ mask, int rows, int cols) {
+  const size_t total = (size_t)rows * cols;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = mask[i / cols] ? a[i] : b[i];
+}
+
+inline int grid_for(size_t n, int block = 256) {
+  size_t g = (n + block - 1) / block;
+  return (int)(g < 2048 ? (g ? g : 1) : 2048);
+}
+
+}  // namespace
+
+hipError_t launch_ln_mod(const float* x, bf16_t* out, int M, int D, const float* tab, int tab_stride, int scale_off,
+                         int shift_off, const int* step_idx, hipStream_t s) {
+  if (D != 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(ln_mod_kernel<1024>, dim3((M + 3) / 4), dim3(256), 0, s, x, out, M, tab, tab_stride, scale_off,
+                     shift_off, step_idx);
+  return hipGetLastError();
+}
+
+hipError_t launch_cfg_euler(float* y, const float* pred, int rows, int cols, const float* dt_tab, const float* cfg_tab,
+                            int* step_idx, float* traj, int use_cfg, hipStream_t s) {
+  hipLaunchKernelGGL(cfg_euler_kernel, dim3(grid_for((size_t)rows * cols)), dim3(256), 0, s, y, pred, rows, cols, dt_tab,
+                     cfg_tab, step_idx, traj, use_cfg);
+  hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, step_idx, 0, 0);
+  return hipGetLastError();
+}
+
+hipError_t launch_step_set(int* step_idx, int value, hipStream_t s) {
+  hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, step_idx, value, 1);
+  return hipGetLastError();
+}
+
+hipError_t launch_rope_table(float* cs, float* sn, int n, int half, const float* inv_freq, hipStream_t s) {
+  hipLaunchKernelGGL(rope_table_kernel, dim3((n * half + 255) / 256), dim3(256), 0, s, cs, sn, n, half, inv_freq);
+  return hipGetLastError();
+}
+
+hipError_t launch_f32_to_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, s, src, dst, n);
+  return hipGetLastError();
+}
+
+hipError_t launch_convpos_weight(const float* src, bf16_t* dst, int C, int cg, int taps, hipStream_t s) {
+  hipLaunchKernelGGL(convpos_weight_kernel, dim3(grid_for((size_t)C * cg * taps)), dim3(256), 0, s, src, dst, C, cg, taps);
+  return hipGetLastError();
+}
+
+hipError_t launch_select_rows(float* out, const float* a, const float* b, const uint8_t* mask, int rows, int cols,
+                              hipStream_t s) {
+  hipLaunchKernelGGL(select_rows_kernel, dim3(grid_for((size_t)rows * cols)), dim3(256), 0, s, out, a, b, mask, rows, cols);
+  return hipGetLastError();
+}

@@ -1,0 +1,230 @@
+"""Python handles over the C ABI objects ``lemas_dit`` and ``lemas_vocos``.
+
+Host code here is plumbing only: it moves weights to the library, owns input/output torch tensors
+and a non-default HIP stream (a captured hipGraph cannot live on the legacy NULL stream).  All
+arithmetic of the acoustic path happens inside liblemas_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .model.layout import DiTArch, VocosArch
+
+
+def _as_f32_host(v) -> np.ndarray:
+    if isinstance(v, torch.Tensor):
+        v = v.detach().to("cpu", torch.float32).numpy()
+    return np.ascontiguousarray(np.asarray(v, dtype=np.float32))
+
+
+def _load(fn, handle, name: str, arr) -> None:
+    a = _as_f32_host(arr)
+    shape = (C.c_int64 * a.ndim)(*a.shape)
+    _lib.check(fn(handle, name.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim), f"load_weight({name})")
+
+
+def _aux_tables(arch: DiTArch) -> dict:
+    """Tables the reference holds as non-persistent buffers or recomputes per call, built with the very
+    same torch expressions so they are bit-identical to the reference's:
+    ``precompute_freqs_cis(text_dim, 4096)`` (modules.py:196-207) and the sinusoid frequencies of
+    ``SinusPositionEmbedding`` (modules.py:156-158)."""
+    td = arch.text_dim
+    freqs = 1.0 / (10000.0 ** (torch.arange(0, td, 2)[: (td // 2)].float() / td))
+    ang = torch.outer(torch.arange(4096), freqs).float()
+    half = arch.time_freq_dim // 2
+    tf = torch.exp(torch.arange(half).float() * -(math.log(10000) / (half - 1)))
+    return {"transformer.text_embed.freqs_cis": torch.cat([ang.cos(), ang.sin()], dim=-1),
+            "transformer.time_embed.freqs": tf}
+
+
+class _Streamed:
+    """Run library calls on a private non-default stream, ordered after/before torch's current stream."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.LemasError("the MI355X engine needs a HIP device ('cuda:N'); there is no CPU path")
+        self.stream = torch.cuda.Stream(self.device)
+
+    def _enter(self, *tensors):
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        for t in tensors:
+            if t is not None:
+                t.record_stream(self.stream)
+        return C.c_void_p(self.stream.cuda_stream)
+
+    def _exit(self):
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+
+
+class DiTEngine(_Streamed):
+    """Owns one ``lemas_dit`` (weights, workspaces, hipGraphs) on one device."""
+
+    def __init__(self, arch: DiTArch, vocab_size: int, state_dict: dict, device="cuda:0", prosody: bool = False):
+        super().__init__(device)
+        self.arch, self.vocab_size, self.prosody = arch, vocab_size, prosody
+        L = _lib.lib()
+        cfg = _lib.DitConfig(arch.dim, arch.depth, arch.heads, arch.dim_head, arch.ff_mult, arch.text_dim,
+                             arch.conv_layers, arch.mel_dim, vocab_size + 1, arch.conv_pos_kernel,
+                             arch.conv_pos_groups, arch.time_freq_dim, int(prosody))
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(L.lemas_dit_create(C.byref(cfg), C.byref(self._h)), "lemas_dit_create")
+            for name, v in state_dict.items():
+                if name.startswith("prosody_encoder.") or name.startswith("mel_spec."):
+                    continue  # the prosody ENCODER is a "next" row; mel_spec keys are dropped by the reference loader
+                if not prosody and (name.startswith("prosody_to_mel.") or ".prosody_text_proj." in name):
+                    raise _lib.LemasError(f"checkpoint has prosody tensor '{name}' but the model was built without it")
+                _load(L.lemas_dit_load_weight, self._h, name, v)
+            for name, v in _aux_tables(arch).items():
+                _load(L.lemas_dit_load_weight, self._h, name, v)
+            _lib.check(L.lemas_dit_finalize(self._h), "lemas_dit_finalize")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().lemas_dit_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, key: str, value: int):
+        _lib.check(_lib.lib().lemas_dit_set_option(self._h, key.encode(), int(value)), f"set_option({key})")
+
+    # ------------------------------------------------------------------------------------------
+    def _args(self, cond, cond_mask, text, seq_len, prosody, t_grid, cfg_strength, cond_frames, y, out, traj):
+        B, N, _ = cond.shape
+        tg = np.ascontiguousarray(np.asarray(t_grid, dtype=np.float32))
+        self._tg_keep = tg
+        a = _lib.SampleArgs()
+        a.batch, a.frames, a.cond_frames, a.text_len, a.steps = B, N, int(cond_frames), text.shape[1], tg.shape[0] - 1
+        a.cfg_strength = float(cfg_strength)
+        a.cond, a.cond_mask, a.text = cond.data_ptr(), cond_mask.data_ptr(), text.data_ptr()
+        a.seq_len = seq_len.data_ptr() if seq_len is not None else None
+        a.prosody = prosody.data_ptr() if prosody is not None else None
+        a.t_grid = tg.ctypes.data_as(C.POINTER(C.c_float))
+        a.y = y.data_ptr() if y is not None else None
+        a.out = out.data_ptr() if out is not None else None
+        a.trajectory = traj.data_ptr() if traj is not None else None
+        return a
+
+    def _canon(self, cond, cond_mask, text, seq_len, prosody):
+        dev = self.device
+        cond = cond.to(dev, torch.float32).contiguous()
+        cond_mask = cond_mask.to(dev).to(torch.uint8).contiguous()
+        text = text.to(dev, torch.int64).contiguous()
+        seq_len = None if seq_len is None else seq_len.to(dev, torch.int32).contiguous()
+        prosody = None if prosody is None else prosody.to(dev, torch.float32).contiguous()
+        return cond, cond_mask, text, seq_len, prosody
+
+    def sample(self, cond, cond_mask, text, t_grid, y0, *, cond_frames: int, cfg_strength: float,
+               seq_len: Optional[torch.Tensor] = None, prosody: Optional[torch.Tensor] = None,
+               want_trajectory: bool = False):
+        """cond [B,N,mel] zero-padded mel; cond_mask [B,N] bool; text [B,Nt] int64 (-1 pad); y0 [B,N,mel].
+        Returns (out, y_final, trajectory|None) as device tensors."""
+        cond, cond_mask, text, seq_len, prosody = self._canon(cond, cond_mask, text, seq_len, prosody)
+        with torch.cuda.device(self.device):
+            y = y0.to(self.device, torch.float32).contiguous().clone()
+            out = torch.empty_like(y)
+            S = len(t_grid) - 1
+            traj = torch.empty((S + 1,) + tuple(y.shape), device=self.device, dtype=torch.float32) if want_trajectory else None
+            a = self._args(cond, cond_mask, text, seq_len, prosody, t_grid, cfg_strength, cond_frames, y, out, traj)
+            s = self._enter(cond, cond_mask, text, seq_len, prosody, y, out, traj)
+            _lib.check(_lib.lib().lemas_dit_sample(self._h, C.byref(a), s), "lemas_dit_sample")
+            self._exit()
+        return out, y, traj
+
+    def prepare(self, cond, cond_mask, text, t_grid, *, cond_frames: int, cfg_strength: float,
+                seq_len=None, prosody=None):
+        cond, cond_mask, text, seq_len, prosody = self._canon(cond, cond_mask, text, seq_len, prosody)
+        self._prep_keep = (cond, cond_mask, text, seq_len, prosody)
+        with torch.cuda.device(self.device):
+            a = self._args(cond, cond_mask, text, seq_len, prosody, t_grid, cfg_strength, cond_frames, None, None, None)
+            s = self._enter(cond, cond_mask, text, seq_len, prosody)
+            _lib.check(_lib.lib().lemas_dit_prepare(self._h, C.byref(a), s), "lemas_dit_prepare")
+            self._exit()
+        self._prep_args = a
+
+    def solve(self, y0, want_out: bool = True):
+        """Step loop on the prepared state (bench hot region).  Returns (out|None, y_final)."""
+        cond, cond_mask, *_ = self._prep_keep
+        with torch.cuda.device(self.device):
+            y = y0.to(self.device, torch.float32).contiguous().clone()
+            out = torch.empty_like(y) if want_out else None
+            a = self._prep_args
+            a.y, a.out, a.trajectory = y.data_ptr(), (out.data_ptr() if out is not None else None), None
+            s = self._enter(y, out)
+            _lib.check(_lib.lib().lemas_dit_solve(self._h, C.byref(a), s), "lemas_dit_solve")
+            self._exit()
+        return out, y
+
+    def forward(self, x, step_index: int):
+        """One DiT forward (both CFG branches) at step ``step_index`` of the prepared grid -> [BB, N, mel]."""
+        cond = self._prep_keep[0]
+        B, N, md = cond.shape
+        with torch.cuda.device(self.device):
+            x = x.to(self.device, torch.float32).contiguous()
+            bb = 2 * B if self._prep_args.cfg_strength >= 1e-5 else B
+            pred = torch.empty((bb, N, md), device=self.device, dtype=torch.float32)
+            s = self._enter(x, pred)
+            _lib.check(_lib.lib().lemas_dit_forward(self._h, x.data_ptr(), int(step_index), pred.data_ptr(), s),
+                       "lemas_dit_forward")
+            self._exit()
+        return pred
+
+    def profile_read(self) -> dict:
+        names = (C.c_char * 32 * 16)()
+        ms = (C.c_double * 16)()
+        cnt = (C.c_int64 * 16)()
+        n = _lib.lib().lemas_dit_profile_read(self._h, C.cast(names, C.c_void_p), ms, cnt, 16)
+        if n < 0:
+            _lib.check(n, "lemas_dit_profile_read")
+        return {bytes(names[i]).split(b"\0")[0].decode(): (ms[i], cnt[i]) for i in range(n)}
+
+
+class VocosEngine(_Streamed):
+    """``vocoder.decode`` replacement (lemas_tts/infer/utils_infer.py:549)."""
+
+    def __init__(self, state_dict: dict, device="cuda:0", arch: VocosArch = VocosArch()):
+        super().__init__(device)
+        self.arch = arch
+        L = _lib.lib()
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(L.lemas_vocos_create(arch.input_channels, arch.dim, arch.intermediate_dim, arch.num_layers,
+                                            arch.n_fft, arch.hop_length, C.byref(self._h)), "lemas_vocos_create")
+            for name, v in state_dict.items():
+                _load(L.lemas_vocos_load_weight, self._h, name, v)
+            _lib.check(L.lemas_vocos_finalize(self._h), "lemas_vocos_finalize")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().lemas_vocos_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def decode(self, mel: torch.Tensor, gain: float = 1.0) -> torch.Tensor:
+        """mel [B, 100, L] -> wav [B, 256 (L-1)] on the engine's device."""
+        with torch.cuda.device(self.device):
+            mel = mel.to(self.device, torch.float32).contiguous()
+            B, _, L = mel.shape
+            wav = torch.empty((B, self.arch.hop_length * (L - 1)), device=self.device, dtype=torch.float32)
+            s = self._enter(mel, wav)
+            _lib.check(_lib.lib().lemas_vocos_decode(self._h, mel.data_ptr(), B, L, float(gain), wav.data_ptr(), s),
+                       "lemas_vocos_decode")
+            self._exit()
+        return wav

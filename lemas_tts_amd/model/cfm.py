@@ -1,0 +1,143 @@
+"""Host-side mirror of the reference sampler object: ``lemas_tts.model.cfm.CFM`` (inference only).
+
+Same constructor role and the same ``sample(...)`` signature, argument meaning, defaults and error
+behaviour as ``lemas_tts/model/cfm.py:206-227``; the body only does the integer/boolean bookkeeping
+of ``cfm.py:284-339`` (token ids, lengths, masks, duration) and the t-grid (``:445-453``) on the
+host, then hands the batch to the MI355X engine, which runs the hoists, the NFE-step Euler loop with
+CFG folded into the batch, and the final ``where``.  There is no CPU path.
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Optional
+
+import torch
+import torch.nn.functional as F
+
+from ..engine import DiTEngine
+from .layout import DiTArch
+
+
+def lens_to_mask(lens: torch.Tensor, length: Optional[int] = None) -> torch.Tensor:
+    """``model/utils.py:42-47``."""
+    if length is None:
+        length = int(lens.amax())
+    return torch.arange(length, device=lens.device)[None, :] < lens[:, None]
+
+
+def list_str_to_idx(text, vocab_char_map: dict, padding_value: int = -1) -> torch.Tensor:
+    """``model/utils.py:87-94``: unknown token -> 0, right-pad with -1."""
+    rows = [torch.tensor([vocab_char_map.get(c, 0) for c in t], dtype=torch.long) for t in text]
+    return torch.nn.utils.rnn.pad_sequence(rows, padding_value=padding_value, batch_first=True)
+
+
+def list_str_to_tensor(text, padding_value: int = -1) -> torch.Tensor:
+    """``model/utils.py:81-84`` (byte tokenizer)."""
+    rows = [torch.tensor([*bytes(t, "UTF-8")], dtype=torch.long) for t in text]
+    return torch.nn.utils.rnn.pad_sequence(rows, padding_value=padding_value, batch_first=True)
+
+
+def compute_sway_max(steps: int, t_start: float = 0.0, min_ratio: float = 1e-9, safety_factor: float = 0.7) -> float:
+    """``cfm.py:343-373`` with the arguments of the call at ``:447``."""
+    assert 0.0 <= t_start < 1.0
+    dt = (1.0 - t_start) / max(1, steps)
+    p_max = 11.0 if dt >= 0.9 else math.log(min_ratio) / math.log(dt)
+    return max(0.0, p_max - 1.0) * float(safety_factor)
+
+
+def time_grid(steps: int, sway_sampling_coef) -> torch.Tensor:
+    """``cfm.py:445-453``: linspace(0,1,steps+1) ** (1 + min(sway_max, coef)), fp32, python ``min`` semantics."""
+    t = torch.linspace(0, 1, int(steps + 1), dtype=torch.float32)
+    sway_max = torch.tensor(compute_sway_max(steps), dtype=torch.float32)
+    if sway_sampling_coef is not None:
+        return t ** (1 + min(sway_max, sway_sampling_coef))
+    return t ** (1 + sway_max)
+
+
+class CFM:
+    """Inference-time stand-in for ``lemas_tts.model.cfm.CFM``: ``transformer`` is the weight holder
+    (arch + state dict) and the compute lives in a :class:`DiTEngine`."""
+
+    def __init__(self, arch: DiTArch, vocab_size: int, state_dict: dict, *, vocab_char_map: Optional[dict] = None,
+                 device="cuda:0", use_prosody_encoder: bool = False, num_channels: int = 100,
+                 odeint_kwargs: dict = dict(method="euler"), mel_spec_module=None):
+        if odeint_kwargs.get("method", "euler") != "euler":
+            raise NotImplementedError("only the fixed-grid Euler solver of the shipped configs is built")
+        self.arch = arch
+        self.num_channels = num_channels
+        self.vocab_char_map = vocab_char_map
+        self.use_prosody_encoder = use_prosody_encoder
+        self.mel_spec = mel_spec_module          # wav -> mel front edge: a "next" row
+        self.prosody_encoder = None              # Pretssel ECAPA encoder: a "next" row
+        self.odeint_kwargs = odeint_kwargs
+        self.engine = DiTEngine(arch, vocab_size, state_dict, device=device, prosody=use_prosody_encoder)
+
+    @property
+    def device(self):
+        return self.engine.device
+
+    def eval(self):
+        return self
+
+    @torch.no_grad()
+    def sample(self, cond, text, duration, *, lens=None, steps=32, cfg_strength=1.0, sway_sampling_coef=None,
+               seed=None, max_duration=4096, vocoder: Optional[Callable] = None, no_ref_audio=False,
+               duplicate_test=False, t_inter=0.1, edit_mask=None, use_acc_grl=True, use_prosody_encoder=True,
+               ref_ratio=1, y0: Optional[torch.Tensor] = None, prosody_embeds: Optional[torch.Tensor] = None,
+               return_trajectory: bool = False):
+        """Extra keyword-only inputs over the reference: ``y0`` (explicit ODE start; the reference draws it on
+        its own device, cfm.py:430-435), ``prosody_embeds`` [B,512] (what the prosody encoder would return,
+        cfm.py:261-263) and ``return_trajectory`` (the reference always returns it; its callers discard it)."""
+        if no_ref_audio or duplicate_test:
+            raise NotImplementedError("no_ref_audio / duplicate_test debug corners are outside the hot path")
+        if use_acc_grl and ref_ratio is None:
+            raise TypeError("'<' not supported between instances of 'NoneType' and 'int'")  # cfm.py:273 hazard
+        if use_acc_grl and ref_ratio < 1:
+            raise NotImplementedError("ref_ratio < 1 (random clip-and-shuffle of the prompt) is outside the hot path")
+        dev = self.device
+        if cond.ndim == 2:
+            if self.mel_spec is None:
+                raise NotImplementedError("raw-audio cond needs the wav->mel front edge ('next' row); pass a mel [B,F,100]")
+            cond = self.mel_spec(cond).permute(0, 2, 1)
+        assert cond.shape[-1] == self.num_channels
+        cond = cond.to(dev, torch.float32)
+        batch, cond_seq_len = cond.shape[:2]
+        if lens is None:
+            lens = torch.full((batch,), cond_seq_len, dtype=torch.long)
+        lens = lens.to("cpu", torch.long)
+
+        if isinstance(text, list):
+            text = list_str_to_idx(text, self.vocab_char_map) if self.vocab_char_map is not None else list_str_to_tensor(text)
+            assert text.shape[0] == batch
+        text = text.to("cpu", torch.long)
+
+        cond_mask = lens_to_mask(lens)
+        if edit_mask is not None:
+            cond_mask = cond_mask & edit_mask.to("cpu")
+        if isinstance(duration, int):
+            duration = torch.full((batch,), duration, dtype=torch.long)
+        duration = duration.to("cpu", torch.long)
+        duration = torch.maximum(torch.maximum((text != -1).sum(dim=-1), lens) + 1, duration).clamp(max=max_duration)
+        n = int(duration.amax())
+
+        cond = F.pad(cond, (0, 0, 0, n - cond_seq_len), value=0.0)
+        cond_mask = F.pad(cond_mask, (0, n - cond_mask.shape[-1]), value=False)
+        seq_len = duration.to(torch.int32) if batch > 1 else None          # cfm.py:336-339
+
+        if y0 is None:
+            ys = []
+            for dur in duration:
+                if seed is not None:
+                    torch.manual_seed(seed)
+                ys.append(torch.randn(int(dur), self.num_channels, device=dev, dtype=torch.float32))
+            y0 = torch.nn.utils.rnn.pad_sequence(ys, padding_value=0, batch_first=True)
+        assert tuple(y0.shape) == (batch, n, self.num_channels), (tuple(y0.shape), (batch, n, self.num_channels))
+
+        t = time_grid(steps, sway_sampling_coef)
+        pros = prosody_embeds if (use_prosody_encoder and self.use_prosody_encoder) else None
+        out, y_final, traj = self.engine.sample(
+            cond, cond_mask, text, t.numpy(), y0, cond_frames=cond_seq_len, cfg_strength=float(cfg_strength),
+            seq_len=seq_len, prosody=pros, want_trajectory=return_trajectory)
+        if vocoder is not None:
+            out = vocoder(out.permute(0, 2, 1))
+        return out, traj
