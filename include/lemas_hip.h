@@ -79,7 +79,8 @@ void lemas_dit_destroy(lemas_dit* m);
  *   "transformer.time_embed.freqs"     [time_freq_dim/2] (modules.py:157-158) */
 int lemas_dit_load_weight(lemas_dit* m, const char* name, const float* host_data, const int64_t* shape, int32_t ndim);
 int lemas_dit_finalize(lemas_dit* m);
-/* options: "graph" (1 = replay one captured hipGraph per ODE step, default 1), "profile" (1 = per-kernel events) */
+/* options: "graph" (1 = replay one captured hipGraph per ODE step, default 1), "profile" (1 = per-kernel events),
+ * "table_cache" (1 = keep the time/AdaLN tables while the t-grid is unchanged, default 1) */
 int lemas_dit_set_option(lemas_dit* m, const char* key, int64_t value);
 /* full sampler: hoists + NFE Euler steps (+ final where) */
 int lemas_dit_sample(lemas_dit* m, const lemas_sample_args* a, void* stream);
@@ -118,6 +119,12 @@ int lemas_k_ln_mod(const float* x, const float* scale, const float* shift, float
 /* out = conv_pos_embed(x) + x for x [B,N,C]; w1,w2 [C, C/groups, taps], b1,b2 [C] */
 int lemas_k_convpos(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* out,
                     int32_t B, int32_t N, int32_t C, int32_t groups, int32_t taps, void* stream);
+
+/* micro-benchmark of one step-loop kernel on synthetic operands: what = "gemm_gelu" | "gemm_gate" | "gemm_qk" | "gemm_v" |
+ * "gemm_f32out" (M,N,K = GEMM shape) or "attention" (M = frames, N = batch*heads); returns the average launch
+ * duration in microseconds over `iters` back-to-back launches (HIP events).  `variant` selects a kernel variant
+ * (0 = production choice). */
+int lemas_k_bench(const char* what, int32_t M, int32_t N, int32_t K, int32_t iters, int32_t variant, double* avg_us);
 
 #ifdef __cplusplus
 }

@@ -3,8 +3,9 @@
 // Reference semantics: lemas_tts/model/modules.py:483-491 -- F.scaled_dot_product_attention(q, k, v,
 // attn_mask = key-padding mask [B,1,1,N], is_causal=False), scale 1/sqrt(64); q,k already rotated.
 //
-// Layout contract (produced by the QKV GEMM epilogue): q, k [B2, H, N, 64] bf16; v^T [B2, H, 64, Npad] bf16
-// (Npad % 64 == 0, the tail is finite); out [B2*N, H*64] bf16 (token-major, feeds the out-proj GEMM).
+// Layout contract (produced by the QKV GEMM epilogue): q, k [B2, H, pitch, 64] bf16; v^T [B2, H, 64, npad] bf16
+// (npad % 64 == 0, the tail is finite); out [B2*pitch, H*64] bf16 (token-major, feeds the out-proj GEMM); pitch >= N
+// is the per-sample row pitch of the activation row space (a multiple of 128).
 //
 // Work split: one workgroup = 128 queries of one (batch, head) = 4 waves x 32 queries; K and V^T tiles of 64 keys
 // go global -> registers -> LDS one tile ahead (double-buffered, one barrier per tile).
@@ -39,8 +40,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
   const int kvlen = p.kv_len ? p.kv_len[b2 % p.batch] : N;
   const int q_base = blockIdx.x * QB + wave * 32;
 
-  const bf16_t* Qg = p.q + (size_t)bh * N * 64;
-  const bf16_t* Kg = p.k + (size_t)bh * N * 64;
+  const bf16_t* Qg = p.q + (size_t)bh * p.pitch * 64;
+  const bf16_t* Kg = p.k + (size_t)bh * p.pitch * 64;
   const bf16_t* Vg = p.vt + (size_t)bh * 64 * p.npad;
 
   // Q fragment (B operand of S^T = K.Q^T): lane (q = l31, hi) holds Q[q][kk*16 + hi*8 .. +7]
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
   const float inv = 1.0f / l_tot;
   const int q = q_base + l31;
   if (q < N) {
-    bf16_t* dst = p.out + ((size_t)b2 * N + q) * (p.heads * 64) + h * 64;
+    bf16_t* dst = p.out + ((size_t)b2 * p.pitch + q) * (p.heads * 64) + h * 64;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
 }  // namespace
 
 hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
-  if (p.npad % 64 != 0 || p.n <= 0) return hipErrorInvalidValue;
+  if (p.npad % 64 != 0 || p.n <= 0 || p.pitch < p.n) return hipErrorInvalidValue;
   dim3 grid((p.n + QB - 1) / QB, p.b2 * p.heads);
   hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, s, p);
   return hipGetLastError();

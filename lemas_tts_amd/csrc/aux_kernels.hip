@@ -151,17 +151,21 @@ __global__ void cond_prepare_kernel(const float* __restrict__ cond, const uint8_
 }
 
 // CT[bb, n, :] = [ step_cond (branch 0) or 0 (branch 1) | text_embed[bb, n, :] ]   (dit.py:94-97, x part hoisted out)
+// output rows live in the padded row space [bb][pitch]; rows n >= N are zero
 __global__ void concat_ct_kernel(const float* __restrict__ step_cond, const float* __restrict__ te, int B, int N, int md,
-                                 int td, int branches, float* __restrict__ ct) {
+                                 int td, int branches, int pitch, float* __restrict__ ct) {
   const int W = md + td;
-  const size_t total = (size_t)branches * B * N * W;
+  const size_t total = (size_t)branches * B * pitch * W;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % W);
-    const size_t row = i / W;
-    const int bb = (int)(row / N);
-    float v;
-    if (c < md) v = bb < B ? step_cond[row * md + c] : 0.f;
-    else v = te[row * td + (c - md)];
+    const size_t prow = i / W;
+    const int bb = (int)(prow / pitch), n = (int)(prow % pitch);
+    float v = 0.f;
+    if (n < N) {
+      const size_t row = (size_t)bb * N + n;
+      if (c < md) v = bb < B ? step_cond[row * md + c] : 0.f;
+      else v = te[row * td + (c - md)];
+    }
     ct[i] = v;
   }
 }
@@ -291,9 +295,9 @@ hipError_t launch_cond_prepare(const float* cond, const uint8_t* mask, const flo
                                int F, int md, float* cond_eff, float* step_cond, hipStream_t s) {
   LAUNCH(cond_prepare_kernel, (size_t)B * N * md, cond, mask, pm, pbias, B, N, F, md, cond_eff, step_cond)
 }
-hipError_t launch_concat_ct(const float* step_cond, const float* te, int B, int N, int md, int td, int branches, float* ct,
-                            hipStream_t s) {
-  LAUNCH(concat_ct_kernel, (size_t)branches * B * N * (md + td), step_cond, te, B, N, md, td, branches, ct)
+hipError_t launch_concat_ct(const float* step_cond, const float* te, int B, int N, int md, int td, int branches, int pitch,
+                            float* ct, hipStream_t s) {
+  LAUNCH(concat_ct_kernel, (size_t)branches * B * pitch * (md + td), step_cond, te, B, N, md, td, branches, pitch, ct)
 }
 hipError_t launch_time_sinus(const float* t, const float* freqs, int S, int half, float* out, hipStream_t s) {
   hipLaunchKernelGGL(time_sinus_kernel, dim3((S * half + 255) / 256), dim3(256), 0, s, t, freqs, S, half, out);

@@ -46,7 +46,8 @@ enum GemmEpi : int {
   EPI_BIAS_GELU_BF16 = 1,  // out_bf16[m][n] = gelu_tanh(acc + bias)
   EPI_BIAS_F32 = 2,        // out_f32[m][n] = acc + bias      (n < n_valid)
   EPI_GATE_RES = 3,        // res_f32[m][n] += gate[n] * (acc + bias)   (rows past kv_len contribute 0)
-  EPI_QKV_ROPE = 4,        // +bias, RoPE on q/k, scatter to q/k [B2,H,N,64] and v^T [B2,H,64,Npad]
+  EPI_QK_ROPE = 4,         // N = 2*inner: +bias, RoPE, scatter to q / k [B2,H,pitch,64]
+  EPI_V_T = 5,             // N = inner:   +bias, scatter to v^T [B2,H,64,npad]
 };
 
 struct GemmParams {
@@ -65,27 +66,30 @@ struct GemmParams {
   int gate_off;          // offset of the gate vector inside a step row
   const int* step_idx;   // device scalar: current ODE step
   const int* kv_len;     // [B] valid frames per sample or nullptr
-  int seq_len;           // frames per sample (rows m -> (m / seq_len, m % seq_len))
-  int batch;             // B (kv_len index = (m / seq_len) % batch)
+  int seq_pitch;         // rows per sample in the activation row space (multiple of 128): m -> (m / pitch, m % pitch)
+  int seq_valid;         // real frames per sample (rows with m % pitch >= seq_valid are padding)
+  int batch;             // B (kv_len index = (m / seq_pitch) % batch)
   // qkv epilogue
   bf16_t* q;
   bf16_t* k;
   bf16_t* vt;
-  const float* rope_cos;  // [seq_len, 32]
+  const float* rope_cos;  // [seq_valid, 32]
   const float* rope_sin;
   int heads, npad;
 };
 
 // ---- internal launchers (one per .hip translation unit) ----------------------------------------
 hipError_t launch_gemm_bf16(int epi, const GemmParams& p, hipStream_t s);
+hipError_t launch_gemm_bf16_variant(int epi, const GemmParams& p, int variant, hipStream_t s);  // development: pick a kernel variant
 
 struct AttnParams {
-  const bf16_t* q;   // [B2, H, N, 64]
-  const bf16_t* k;   // [B2, H, N, 64]
-  const bf16_t* vt;  // [B2, H, 64, Npad]
-  bf16_t* out;       // [B2*N, H*64]
+  const bf16_t* q;   // [B2, H, pitch, 64]
+  const bf16_t* k;   // [B2, H, pitch, 64]
+  const bf16_t* vt;  // [B2, H, 64, npad]
+  bf16_t* out;       // [B2*pitch, H*64]
   const int* kv_len; // [B] or nullptr
   int b2, batch, heads, n, npad;
+  int pitch;         // rows per sample of q / k / out (>= n)
   float scale;
 };
 hipError_t launch_attention(const AttnParams& p, hipStream_t s);
@@ -103,6 +107,7 @@ struct ConvPosParams {
   float* out_f32;         // conv2 output: mish(conv) + residual     fp32
   const float* residual;  // [B2*N, C] fp32
   int b2, n, channels, groups, taps;
+  int pitch;              // rows per sample of every [B2*pitch, C] operand (>= n)
 };
 hipError_t launch_convpos(const ConvPosParams& p, hipStream_t s);
 

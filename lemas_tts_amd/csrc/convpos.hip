@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256, 2) void convpos_kernel(const ConvPosParams p) 
     const int f = f0 - half + r;
     u32x4 v = u32x4{0u, 0u, 0u, 0u};
     if (f >= 0 && f < N && r < FB + taps - 1) {
-      const size_t off = ((size_t)b * N + f) * C + g * CG + ch * 8;
+      const size_t off = ((size_t)b * p.pitch + f) * C + g * CG + ch * 8;
       if (FIRST) {
         const float4 a = *reinterpret_cast<const float4*>(p.in_f32 + off);
         const float4 c = *reinterpret_cast<const float4*>(p.in_f32 + off + 4);
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void convpos_kernel(const ConvPosParams p) 
     for (int r = 0; r < 16; ++r) {
       const int f = f0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
       if (f < N) {
-        const size_t off = ((size_t)b * N + f) * C + c;
+        const size_t off = ((size_t)b * p.pitch + f) * C + c;
         const float v = mish_f(acc[j][r] + bias);
         if (FIRST) p.out_bf16[off] = (bf16_t)v;
         else p.out_f32[off] = v + p.residual[off];
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void convpos_kernel(const ConvPosParams p) 
 }  // namespace
 
 hipError_t launch_convpos(const ConvPosParams& p, hipStream_t s) {
-  if (p.channels / p.groups != CG || p.taps > MAXTAPS || (p.taps & 1) == 0) return hipErrorInvalidValue;
+  if (p.channels / p.groups != CG || p.taps > MAXTAPS || (p.taps & 1) == 0 || p.pitch < p.n) return hipErrorInvalidValue;
   dim3 grid((p.n + FB - 1) / FB, p.groups, p.b2);
   if (p.in_f32) hipLaunchKernelGGL(convpos_kernel<true>, grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL(convpos_kernel<false>, grid, dim3(256), 0, s, p);

@@ -40,6 +40,7 @@ struct lemas_dit {
   bool finalized = false;
   bool use_graph = true;
   bool profile = false;
+  bool table_cache = true;  // reuse the AdaLN/time tables while the t-grid is unchanged
 
   std::vector<BlockW> blocks;
   DevBuf wproj_out, bproj_out;  // padded to 128 rows
@@ -47,6 +48,7 @@ struct lemas_dit {
 
   // --- per-shape state (valid after prepare)
   int B = 0, N = 0, F = 0, Nt = 0, S = 0, BB = 0, npad = 0;
+  int pitch = 0;  // rows per sample in the activation row space: N rounded up to 128 (tiles never straddle samples)
   bool use_cfg = true, has_len = false, prepared = false;
   std::vector<float> tgrid_cached;
   int rope_n = 0;
@@ -226,7 +228,7 @@ int lemas_dit::build_tables(const lemas_sample_args* a, hipStream_t s) {
   HIP_TRY(hipMemcpyAsync(d_dt.p, h_dt.data(), (size_t)Snew * 4, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(d_cfg.p, h_cfg.data(), (size_t)Snew * 4, hipMemcpyHostToDevice, s));
 
-  if (tg != tgrid_cached) {
+  if (!table_cache || tg != tgrid_cached) {
     h_t = tg;
     RC_TRY(d_t.ensure((size_t)(Snew + 1) * 4));
     HIP_TRY(hipMemcpyAsync(d_t.p, h_t.data(), (size_t)(Snew + 1) * 4, hipMemcpyHostToDevice, s));
@@ -322,8 +324,9 @@ int lemas_dit::prepare(const lemas_sample_args* a, hipStream_t s) {
   use_cfg = !(a->cfg_strength < 1e-5f);
   BB = use_cfg ? 2 * B : B;
   has_len = a->seq_len != nullptr;
-  npad = (N + 63) & ~63;
-  const int d = cfg.dim, md = cfg.mel_dim, td = cfg.text_dim, rows = BB * N, in = inner();
+  pitch = (N + 127) & ~127;
+  npad = pitch;
+  const int d = cfg.dim, md = cfg.mel_dim, td = cfg.text_dim, rows = BB * pitch, in = inner();
 
   RC_TRY(build_tables(a, s));
   if (has_len) {
@@ -348,7 +351,7 @@ int lemas_dit::prepare(const lemas_sample_args* a, hipStream_t s) {
   // hoisted [cond | text] part of the input projection
   RC_TRY(d_ct.ensure((size_t)rows * (md + td) * 4));
   RC_TRY(d_pconst.ensure((size_t)rows * d * 4));
-  HIP_TRY(launch_concat_ct(d_step_cond.as<float>(), d_te.as<float>(), B, N, md, td, BB / B, d_ct.as<float>(), s));
+  HIP_TRY(launch_concat_ct(d_step_cond.as<float>(), d_te.as<float>(), B, N, md, td, BB / B, pitch, d_ct.as<float>(), s));
   {
     GemmF32Params g{};
     g.A = d_ct.as<float>(); g.lda = md + td; g.W = ws.ptr(T("input_embed.proj.weight")) + md; g.ldw = 2 * md + td;
@@ -356,7 +359,7 @@ int lemas_dit::prepare(const lemas_sample_args* a, hipStream_t s) {
     HIP_TRY(launch_gemm_f32(F32_BIAS, g, s));
   }
   // step-loop workspaces
-  RC_TRY(d_y.ensure((size_t)B * N * md * 4));
+  RC_TRY(d_y.ensure((size_t)B * pitch * md * 4));
   RC_TRY(d_xres.ensure((size_t)rows * d * 4));
   RC_TRY(d_hbf.ensure((size_t)rows * d * 2));
   RC_TRY(d_abf.ensure((size_t)rows * in * 2));
@@ -371,7 +374,7 @@ int lemas_dit::prepare(const lemas_sample_args* a, hipStream_t s) {
 }
 
 int lemas_dit::enqueue_forward(hipStream_t s) {
-  const int d = cfg.dim, md = cfg.mel_dim, rows = BB * N, in = inner(), ffd = cfg.ff_mult * d;
+  const int d = cfg.dim, md = cfg.mel_dim, rows = BB * pitch, in = inner(), ffd = cfg.ff_mult * d;
   const int* step = d_step.as<int>();
   const float* tab = d_tab.as<float>();
   // input projection, x part (K = mel_dim) in fp32, broadcast onto both CFG branches  (dit.py:97)
@@ -379,7 +382,7 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     RC_TRY(pbegin(PC_INPROJ, s));
     GemmF32Params g{};
     g.A = d_y.as<float>(); g.lda = md; g.W = ws.ptr(T("input_embed.proj.weight")); g.ldw = 2 * md + cfg.text_dim;
-    g.out = d_xres.as<float>(); g.ldc = d; g.M = B * N; g.N = d; g.K = md;
+    g.out = d_xres.as<float>(); g.ldc = d; g.M = B * pitch; g.N = d; g.K = md;
     if (use_cfg) {
       g.add = d_pconst.as<float>();
       HIP_TRY(launch_gemm_f32(F32_BIAS_ADD2, g, s));
@@ -393,7 +396,7 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
   {
     RC_TRY(pbegin(PC_CONVPOS, s));
     ConvPosParams c{};
-    c.b2 = BB; c.n = N; c.channels = d; c.groups = cfg.conv_pos_groups; c.taps = cfg.conv_pos_kernel;
+    c.b2 = BB; c.n = N; c.pitch = pitch; c.channels = d; c.groups = cfg.conv_pos_groups; c.taps = cfg.conv_pos_kernel;
     c.in_f32 = d_xres.as<float>(); c.w = wconv[0].as<bf16_t>(); c.bias = ws.ptr(T("input_embed.conv_pos_embed.conv1d.0.bias"));
     c.out_bf16 = d_cmid.as<bf16_t>();
     HIP_TRY(launch_convpos(c, s));
@@ -404,12 +407,12 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     RC_TRY(pend(s));
   }
   GemmParams g{};
-  g.M = rows; g.tab = tab; g.tab_stride = tab_stride; g.step_idx = step; g.seq_len = N; g.batch = B;
+  g.M = rows; g.tab = tab; g.tab_stride = tab_stride; g.step_idx = step; g.seq_pitch = pitch; g.seq_valid = N; g.batch = B;
   g.heads = cfg.heads; g.npad = npad; g.rope_cos = d_rope_cos.as<float>(); g.rope_sin = d_rope_sin.as<float>();
   g.q = d_q.as<bf16_t>(); g.k = d_k.as<bf16_t>(); g.vt = d_vt.as<bf16_t>();
   AttnParams at{};
   at.q = d_q.as<bf16_t>(); at.k = d_k.as<bf16_t>(); at.vt = d_vt.as<bf16_t>(); at.out = d_abf.as<bf16_t>();
-  at.kv_len = has_len ? d_len.as<int>() : nullptr; at.b2 = BB; at.batch = B; at.heads = cfg.heads; at.n = N; at.npad = npad;
+  at.kv_len = has_len ? d_len.as<int>() : nullptr; at.b2 = BB; at.batch = B; at.heads = cfg.heads; at.n = N; at.npad = npad; at.pitch = pitch;
   at.scale = 1.0f / sqrtf((float)cfg.dim_head);
   for (int l = 0; l < cfg.depth; ++l) {
     const BlockW& w = blocks[l];
@@ -418,9 +421,11 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     HIP_TRY(launch_ln_mod(d_xres.as<float>(), d_hbf.as<bf16_t>(), rows, d, tab, tab_stride, base + d, base, step, s));
     RC_TRY(pend(s));
     RC_TRY(pbegin(PC_GEMM_QKV, s));
-    g.A = d_hbf.as<bf16_t>(); g.W = w.wqkv.as<bf16_t>(); g.bias = w.bqkv.as<float>(); g.N = 3 * in; g.K = d; g.n_valid = 3 * in;
+    g.A = d_hbf.as<bf16_t>(); g.W = w.wqkv.as<bf16_t>(); g.bias = w.bqkv.as<float>(); g.N = 2 * in; g.K = d; g.n_valid = 2 * in;
     g.kv_len = nullptr;
-    HIP_TRY(launch_gemm_bf16(EPI_QKV_ROPE, g, s));
+    HIP_TRY(launch_gemm_bf16(EPI_QK_ROPE, g, s));
+    g.W = w.wqkv.as<bf16_t>() + (size_t)2 * in * d; g.bias = w.bqkv.as<float>() + 2 * in; g.N = in; g.n_valid = in;
+    HIP_TRY(launch_gemm_bf16(EPI_V_T, g, s));
     RC_TRY(pend(s));
     RC_TRY(pbegin(PC_ATTN, s));
     HIP_TRY(launch_attention(at, s));
@@ -459,9 +464,14 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
 
 int lemas_dit::enqueue_update(float* traj, hipStream_t s) {
   RC_TRY(pbegin(PC_CFG_EULER, s));
-  HIP_TRY(launch_cfg_euler(d_y.as<float>(), d_pred.as<float>(), B * N, cfg.mel_dim, d_dt.as<float>(), d_cfg.as<float>(),
-                           d_step.as<int>(), traj, use_cfg ? 1 : 0, s));
+  // traj: caller's dense [S+1, B, N, mel]; the step index is host-known only in the eager path (traj_k)
+  HIP_TRY(launch_cfg_euler(d_y.as<float>(), d_pred.as<float>(), B * pitch, cfg.mel_dim, d_dt.as<float>(), d_cfg.as<float>(),
+                           d_step.as<int>(), nullptr, use_cfg ? 1 : 0, s));
   RC_TRY(pend(s));
+  if (traj) {
+    const size_t w = (size_t)N * cfg.mel_dim * 4;
+    HIP_TRY(hipMemcpy2DAsync(traj, w, d_y.p, (size_t)pitch * cfg.mel_dim * 4, w, B, hipMemcpyDeviceToDevice, s));
+  }
   return 0;
 }
 
@@ -469,7 +479,9 @@ int lemas_dit::solve(const lemas_sample_args* a, hipStream_t s) {
   if (!prepared) { set_error("lemas_dit_solve: prepare() has not run"); return LEMAS_E_STATE; }
   if (a->batch != B || a->frames != N || a->steps != S || !a->y) { set_error("lemas_dit_solve: arguments differ from prepare()"); return LEMAS_E_ARG; }
   const size_t ybytes = (size_t)B * N * cfg.mel_dim * 4;
-  HIP_TRY(hipMemcpyAsync(d_y.p, a->y, ybytes, hipMemcpyDeviceToDevice, s));
+  const size_t yw = (size_t)N * cfg.mel_dim * 4, ypitch = (size_t)pitch * cfg.mel_dim * 4;
+  HIP_TRY(hipMemsetAsync(d_y.p, 0, (size_t)B * ypitch, s));   // padding rows restart from 0 every utterance
+  HIP_TRY(hipMemcpy2DAsync(d_y.p, ypitch, a->y, yw, yw, B, hipMemcpyDeviceToDevice, s));
   if (a->trajectory) HIP_TRY(hipMemcpyAsync(a->trajectory, a->y, ybytes, hipMemcpyDeviceToDevice, s));
   HIP_TRY(launch_step_set(d_step.as<int>(), 0, s));
 
@@ -500,12 +512,12 @@ int lemas_dit::solve(const lemas_sample_args* a, hipStream_t s) {
   } else {
     for (int k = 0; k < S; ++k) {
       RC_TRY(enqueue_forward(s));
-      RC_TRY(enqueue_update(a->trajectory, s));
+      RC_TRY(enqueue_update(a->trajectory ? a->trajectory + (size_t)(k + 1) * B * N * cfg.mel_dim : nullptr, s));
     }
   }
-  HIP_TRY(hipMemcpyAsync(a->y, d_y.p, ybytes, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipMemcpy2DAsync(a->y, yw, d_y.p, ypitch, yw, B, hipMemcpyDeviceToDevice, s));
   if (a->out)
-    HIP_TRY(launch_select_rows(a->out, d_cond_eff.as<float>(), d_y.as<float>(), a->cond_mask, B * N, cfg.mel_dim, s));
+    HIP_TRY(launch_select_rows(a->out, d_cond_eff.as<float>(), d_y.as<float>(), a->cond_mask, B, N, pitch, cfg.mel_dim, s));
   return 0;
 }
 
@@ -540,6 +552,7 @@ int lemas_dit_finalize(lemas_dit* m) { return m ? m->finalize() : LEMAS_E_ARG; }
 int lemas_dit_set_option(lemas_dit* m, const char* key, int64_t value) {
   if (!m || !key) return LEMAS_E_ARG;
   if (!strcmp(key, "graph")) { m->use_graph = value != 0; return 0; }
+  if (!strcmp(key, "table_cache")) { m->table_cache = value != 0; return 0; }
   if (!strcmp(key, "profile")) {
     m->profile = value != 0;
     for (auto& r : m->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -569,10 +582,12 @@ int lemas_dit_forward(lemas_dit* m, const float* x, int32_t step_index, float* p
   if (!m->prepared) { set_error("lemas_dit_forward: prepare() has not run"); return LEMAS_E_STATE; }
   if (step_index < 0 || step_index >= m->S) { set_error("lemas_dit_forward: step index out of range"); return LEMAS_E_ARG; }
   hipStream_t s = (hipStream_t)stream;
-  HIP_TRY(hipMemcpyAsync(m->d_y.p, x, (size_t)m->B * m->N * m->cfg.mel_dim * 4, hipMemcpyDeviceToDevice, s));
+  const size_t w = (size_t)m->N * m->cfg.mel_dim * 4, wp = (size_t)m->pitch * m->cfg.mel_dim * 4;
+  HIP_TRY(hipMemsetAsync(m->d_y.p, 0, (size_t)m->B * wp, s));
+  HIP_TRY(hipMemcpy2DAsync(m->d_y.p, wp, x, w, w, m->B, hipMemcpyDeviceToDevice, s));
   HIP_TRY(launch_step_set(m->d_step.as<int>(), step_index, s));
   RC_TRY(m->enqueue_forward(s));
-  HIP_TRY(hipMemcpyAsync(pred, m->d_pred.p, (size_t)m->BB * m->N * m->cfg.mel_dim * 4, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipMemcpy2DAsync(pred, w, m->d_pred.p, wp, w, m->BB, hipMemcpyDeviceToDevice, s));
   return 0;
 }
 

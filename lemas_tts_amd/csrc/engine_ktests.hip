@@ -39,6 +39,14 @@ __global__ void widen_kernel(const bf16_t* src, float* dst, size_t n) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = (float)src[i];
 }
 __global__ void fill_i32_kernel(int* p, int v) { p[0] = v; }
+// pseudo-random bf16 in [-1, 1): benchmarks must not run on zero-filled operands (clock/power artefacts)
+__global__ void fill_pattern_kernel(bf16_t* p, size_t n, unsigned seed) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned x = (unsigned)i * 2654435761u + seed * 40503u;
+    x ^= x >> 15; x *= 2246822519u; x ^= x >> 13;
+    p[i] = (bf16_t)((float)(x & 0xffff) / 32768.0f - 1.0f);
+  }
+}
 
 }  // namespace
 
@@ -59,7 +67,7 @@ int lemas_k_linear_bf16(const float* A, const float* W, const float* bias, float
   HIP_TRY(launch_f32_to_bf16(W, w, (size_t)N * K, s));
   if (bias) HIP_TRY(hipMemcpyAsync(b, bias, (size_t)N * 4, hipMemcpyDeviceToDevice, s));
   GemmParams p{};
-  p.A = a; p.W = w; p.bias = b; p.M = M; p.N = Np; p.K = K; p.n_valid = N; p.ldc = N;
+  p.A = a; p.W = w; p.bias = b; p.M = M; p.N = Np; p.K = K; p.n_valid = N; p.ldc = N; p.seq_pitch = M; p.seq_valid = M; p.batch = 1;
   if (act == 1) {
     p.out_bf16 = ob;
     HIP_TRY(launch_gemm_bf16(EPI_BIAS_GELU_BF16, p, s));
@@ -97,7 +105,7 @@ int lemas_k_attention(const float* q, const float* k, const float* v, const int3
   HIP_TRY(launch_f32_to_bf16(k, kb, n, s));
   hipLaunchKernelGGL(transpose_v_kernel, dim3(2048), dim3(256), 0, s, v, vt, B * H, N, npad);
   AttnParams p{};
-  p.q = qb; p.k = kb; p.vt = vt; p.out = ob; p.kv_len = seq_len; p.b2 = B; p.batch = B; p.heads = H; p.n = N; p.npad = npad;
+  p.q = qb; p.k = kb; p.vt = vt; p.out = ob; p.kv_len = seq_len; p.b2 = B; p.batch = B; p.heads = H; p.n = N; p.npad = npad; p.pitch = N;
   p.scale = 0.125f;
   HIP_TRY(launch_attention(p, s));
   hipLaunchKernelGGL(widen_kernel, dim3(1024), dim3(256), 0, s, ob, out, n);
@@ -131,7 +139,7 @@ int lemas_k_convpos(const float* x, const float* w1, const float* b1, const floa
   HIP_TRY(launch_convpos_weight(w1, wa, C, cg, taps, s));
   HIP_TRY(launch_convpos_weight(w2, wb, C, cg, taps, s));
   ConvPosParams c{};
-  c.b2 = B; c.n = N; c.channels = C; c.groups = groups; c.taps = taps;
+  c.b2 = B; c.n = N; c.channels = C; c.groups = groups; c.taps = taps; c.pitch = N;
   c.in_f32 = x; c.w = wa; c.bias = b1; c.out_bf16 = mid;
   HIP_TRY(launch_convpos(c, s));
   c.in_f32 = nullptr; c.in_bf16 = mid; c.w = wb; c.bias = b2; c.out_bf16 = nullptr; c.out_f32 = out; c.residual = x;
@@ -141,3 +149,77 @@ int lemas_k_convpos(const float* x, const float* w1, const float* b1, const floa
 }
 
 }  // extern "C"
+
+// ---- micro-benchmarks of the step-loop kernels at arbitrary shapes (development aid + bench.py roofline cross-check)
+extern "C" int lemas_k_bench(const char* what, int32_t M, int32_t N, int32_t K, int32_t iters, int32_t variant, double* avg_us) {
+  hipStream_t s = nullptr;
+  hipStream_t own = nullptr;
+  HIP_TRY(hipStreamCreate(&own));
+  s = own;
+  Scratch sc;
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  const std::string w(what);
+  float ms = 0.f;
+  int rc = 0;
+  auto time_it = [&](auto&& fn) -> int {
+    for (int i = 0; i < 3; ++i) { hipError_t e = fn(); if (e != hipSuccess) return hip_fail(e, "bench warmup", __FILE__, __LINE__); }
+    HIP_TRY(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) (void)fn();
+    HIP_TRY(hipEventRecord(e1, s));
+    HIP_TRY(hipEventSynchronize(e1));
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    return 0;
+  };
+  if (w == "gemm_gelu" || w == "gemm_gate" || w == "gemm_qk" || w == "gemm_v" || w == "gemm_f32out") {
+    const int Np = (N + 127) & ~127;
+    bf16_t* a = sc.get<bf16_t>((size_t)M * K);
+    bf16_t* wt = sc.get<bf16_t>((size_t)Np * K);
+    float* b = sc.get<float>(Np);
+    bf16_t* ob = sc.get<bf16_t>((size_t)M * Np);
+    float* of = sc.get<float>((size_t)M * Np);
+    float* tab = sc.get<float>(Np);
+    int* step = sc.get<int>(16);
+    const int npad = (M + 127) & ~127;
+    bf16_t* q = sc.get<bf16_t>((size_t)M * 1024);
+    bf16_t* k = sc.get<bf16_t>((size_t)M * 1024);
+    bf16_t* vt = sc.get<bf16_t>((size_t)16 * 64 * npad);
+    float* rc_ = sc.get<float>((size_t)M * 32);
+    float* rs_ = sc.get<float>((size_t)M * 32);
+    if (!a || !wt || !b || !ob || !of || !tab || !step || !q || !k || !vt || !rc_ || !rs_) { set_error("bench: out of memory"); return LEMAS_E_STATE; }
+    // non-trivial operand bits (DVFS: zero-filled operands clock higher and overstate throughput)
+    hipLaunchKernelGGL(fill_pattern_kernel, dim3(1024), dim3(256), 0, s, a, (size_t)M * K, 1u);
+    hipLaunchKernelGGL(fill_pattern_kernel, dim3(1024), dim3(256), 0, s, wt, (size_t)Np * K, 2u);
+    GemmParams p{};
+    p.A = a; p.W = wt; p.bias = b; p.M = M; p.N = Np; p.K = K; p.n_valid = N; p.ldc = N; p.out_bf16 = ob; p.out_f32 = of;
+    p.tab = tab; p.tab_stride = 0; p.gate_off = 0; p.step_idx = step; p.seq_pitch = M; p.seq_valid = M; p.batch = 1; p.heads = 16; p.npad = npad;
+    p.q = q; p.k = k; p.vt = vt; p.rope_cos = rc_; p.rope_sin = rs_;
+    const int epi = w == "gemm_gelu" ? EPI_BIAS_GELU_BF16 : w == "gemm_gate" ? EPI_GATE_RES : w == "gemm_qk" ? EPI_QK_ROPE : w == "gemm_v" ? EPI_V_T : EPI_BIAS_F32;
+    if ((epi == EPI_QK_ROPE && N != 2048) || (epi == EPI_V_T && N != 1024)) { set_error("bench: gemm_qk needs N = 2048, gemm_v N = 1024"); return LEMAS_E_ARG; }
+    rc = time_it([&]() { return launch_gemm_bf16_variant(epi, p, variant, s); });
+  } else if (w == "attention") {
+    // M = sequence length, N = batch*heads
+    const int n = M, bh = N, npad = (n + 63) & ~63;
+    bf16_t* q = sc.get<bf16_t>((size_t)bh * n * 64);
+    bf16_t* k = sc.get<bf16_t>((size_t)bh * n * 64);
+    bf16_t* vt = sc.get<bf16_t>((size_t)bh * 64 * npad);
+    bf16_t* o = sc.get<bf16_t>((size_t)bh * n * 64);
+    if (!q || !k || !vt || !o) { set_error("bench: out of memory"); return LEMAS_E_STATE; }
+    hipLaunchKernelGGL(fill_pattern_kernel, dim3(1024), dim3(256), 0, s, q, (size_t)bh * n * 64, 3u);
+    hipLaunchKernelGGL(fill_pattern_kernel, dim3(1024), dim3(256), 0, s, k, (size_t)bh * n * 64, 4u);
+    hipLaunchKernelGGL(fill_pattern_kernel, dim3(1024), dim3(256), 0, s, vt, (size_t)bh * 64 * npad, 5u);
+    AttnParams p{};
+    p.q = q; p.k = k; p.vt = vt; p.out = o; p.kv_len = nullptr; p.b2 = bh / 16; p.batch = bh / 16; p.heads = 16; p.n = n; p.npad = npad; p.pitch = n;
+    p.scale = 0.125f;
+    rc = time_it([&]() { return launch_attention(p, s); });
+  } else {
+    set_error("bench: unknown kernel '%s'", what);
+    rc = LEMAS_E_ARG;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipStreamDestroy(own);
+  if (rc == 0 && avg_us) *avg_us = 1e3 * ms / iters;
+  return rc;
+}

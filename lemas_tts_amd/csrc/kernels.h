@@ -6,7 +6,7 @@ hipError_t launch_step_set(int* step_idx, int value, hipStream_t s);
 hipError_t launch_rope_table(float* cs, float* sn, int n, int half, const float* inv_freq, hipStream_t s);
 hipError_t launch_f32_to_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t s);
 hipError_t launch_convpos_weight(const float* src, bf16_t* dst, int C, int cg, int taps, hipStream_t s);
-hipError_t launch_select_rows(float* out, const float* a, const float* b, const uint8_t* mask, int rows, int cols, hipStream_t s);
+hipError_t launch_select_rows(float* out, const float* a, const float* b_padded, const uint8_t* mask, int B, int N, int pitch, int cols, hipStream_t s);
 
 hipError_t launch_text_gather(const int64_t* text, int B, int Nt, int N, int td, int branches, const float* table,
                               const float* freqs_cis, int max_pos, float* out, uint8_t* rowmask, hipStream_t s);
@@ -16,8 +16,8 @@ hipError_t launch_grn(float* x, float* gx_scratch, const float* gamma, const flo
 hipError_t launch_add_rowvec(float* x, const float* vec, int BB, int B, int N, int C, int nlim, hipStream_t s);
 hipError_t launch_cond_prepare(const float* cond, const uint8_t* mask, const float* pm, const float* pbias, int B, int N,
                                int F, int md, float* cond_eff, float* step_cond, hipStream_t s);
-hipError_t launch_concat_ct(const float* step_cond, const float* te, int B, int N, int md, int td, int branches, float* ct,
-                            hipStream_t s);
+hipError_t launch_concat_ct(const float* step_cond, const float* te, int B, int N, int md, int td, int branches, int pitch,
+                            float* ct, hipStream_t s);
 hipError_t launch_time_sinus(const float* t, const float* freqs, int S, int half, float* out, hipStream_t s);
 hipError_t launch_silu(const float* x, float* out, size_t n, hipStream_t s);
 hipError_t launch_im2col7(const float* mel, int B, int C, int L, float* col, hipStream_t s);

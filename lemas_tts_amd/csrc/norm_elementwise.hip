@@ -101,11 +101,16 @@ __global__ void convpos_weight_kernel(const float* __restrict__ src, bf16_t* __r
 }
 
 // step_cond = where(cond_mask, cond, 0) etc. are host-side one-offs; the final out = where(mask, cond, y):
+// `b` lives in the padded row space [B][pitch][cols]; out / a / mask are the caller's dense [B][N][...]
 __global__ void select_rows_kernel(float* __restrict__ out, const float* __restrict__ a, const float* __restrict__ b,
-                                   const uint8_t* __restrict__ mask, int rows, int cols) {
-  const size_t total = (size_t)rows * cols;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
-    out[i] = mask[i / cols] ? a[i] : b[i];
+                                   const uint8_t* __restrict__ mask, int B, int N, int pitch, int cols) {
+  const size_t total = (size_t)B * N * cols;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t row = i / cols;
+    const int c = (int)(i - row * cols);
+    const int bb = (int)(row / N), n = (int)(row - (size_t)bb * N);
+    out[i] = mask[row] ? a[i] : b[((size_t)bb * pitch + n) * cols + c];
+  }
 }
 
 inline int grid_for(size_t n, int block = 256) {
@@ -151,8 +156,9 @@ hipError_t launch_convpos_weight(const float* src, bf16_t* dst, int C, int cg, i
   return hipGetLastError();
 }
 
-hipError_t launch_select_rows(float* out, const float* a, const float* b, const uint8_t* mask, int rows, int cols,
-                              hipStream_t s) {
-  hipLaunchKernelGGL(select_rows_kernel, dim3(grid_for((size_t)rows * cols)), dim3(256), 0, s, out, a, b, mask, rows, cols);
+hipError_t launch_select_rows(float* out, const float* a, const float* b_padded, const uint8_t* mask, int B, int N, int pitch,
+                              int cols, hipStream_t s) {
+  hipLaunchKernelGGL(select_rows_kernel, dim3(grid_for((size_t)B * N * cols)), dim3(256), 0, s, out, a, b_padded, mask, B, N,
+                     pitch, cols);
   return hipGetLastError();
 }
