@@ -21,7 +21,7 @@ The JSON line also carries
                   FLOPs per launch / average launch duration measured with HIP events on the launch stream in a
                   separate short eager pass (events cannot sit inside the replayed hipGraph), vs 2.5 PFLOP/s dense bf16;
   cpu_baseline -- the fp32 oracle (oracle/lemas_oracle.py, a port of the reference's path) timed on this box's host
-                  cores on a bounded sample (2 of the 32 Euler steps at full N, scaled x16, + the full vocoder).
+                  cores on a bounded sample (1 of the 32 Euler steps at full N, scaled x32, + the full vocoder).
 """
 from __future__ import annotations
 
@@ -65,16 +65,29 @@ def build_inputs(rank_seed: int, device):
     return cond.to(device), text.to(device), y0.to(device)
 
 
+def usable_cores() -> int:
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota (the GPU box exposes 256
+    logical CPUs but the container is throttled to a quota; asking torch for 256 threads there is 50x slower)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(sd, vsd, arch):
     """Oracle on host cores, bounded sample of the same workload."""
     from oracle import lemas_oracle as O  # checker / baseline only
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     cond = torch.from_numpy(synth.synth_cond_mel(1234, F_REF))[None]
     text = torch.from_numpy(synth.synth_tokens(1234, round(N_TOT * 0.17), VOCAB))[None]
     y0 = torch.from_numpy(synth.synth_noise(1234, N_TOT))[None]
     cfm = O.OracleCFM(sd, arch)
-    sub = 2
+    sub = 1
     tg = O.time_grid(NFE, SWAY)[: sub + 1]
     t0 = time.perf_counter()
     out, _ = cfm.sample(cond, text, N_TOT, y0=y0, steps=sub, cfg_strength=CFG, sway_sampling_coef=SWAY, t_grid=tg)

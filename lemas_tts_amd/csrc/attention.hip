@@ -3,164 +3,240 @@
 // Reference semantics: lemas_tts/model/modules.py:483-491 -- F.scaled_dot_product_attention(q, k, v,
 // attn_mask = key-padding mask [B,1,1,N], is_causal=False), scale 1/sqrt(64); q,k already rotated.
 //
-// Layout contract (produced by the QKV GEMM epilogue): q, k [B2, H, pitch, 64] bf16; v^T [B2, H, 64, npad] bf16
-// (npad % 64 == 0, the tail is finite); out [B2*pitch, H*64] bf16 (token-major, feeds the out-proj GEMM); pitch >= N
-// is the per-sample row pitch of the activation row space (a multiple of 128).
+// Layout contract (produced by the QK / V GEMM epilogues): q, k [B2, H, pitch, 64] bf16; v^T [B2, H, 64, npad] bf16
+// (npad % 64 == 0); out [B2*pitch, H*64] bf16 (token-major, feeds the out-proj GEMM); pitch >= N is the per-sample
+// row pitch of the activation row space (a multiple of 128).  Rows / columns past N inside the pitch hold finite
+// stale values and are masked, so tiles are loaded without clamping.
 //
-// Work split: one workgroup = 128 queries of one (batch, head) = 4 waves x 32 queries; K and V^T tiles of 64 keys
-// go global -> registers -> LDS one tile ahead (double-buffered, one barrier per tile).
+// Work split: one workgroup = 128 queries of one (batch, head) = 4 waves x 32 queries.  K and V^T tiles of 64 keys
+// stream L2 -> LDS by LDS-DMA (global_load_lds_dwordx4, wave-uniform base + per-lane 32-bit offset) into a 4-stage
+// ring: one s_barrier per tile, counted s_waitcnt vmcnt keeps the tile after next in flight across the barrier.
 //
 // Both matmuls are computed TRANSPOSED so that everything the softmax needs is lane-local:
 //   S^T[key, q] = K . Q^T   (A = K rows from LDS, B = Q fragment held in registers)
 //   O^T[d,  q] = V^T . P^T  (A = V^T rows from LDS, B = P^T built in registers from S^T)
 // With v_mfma_f32_32x32x16_bf16 the C fragment has col = lane&31 (= query) and 16 rows per lane, so each lane
 // owns ONE query: row max / row sum / rescale are per-lane scalars plus a single exchange with lane^32.
-// The S^T row index i is mapped to key kappa(i) = i with bits 2 and 3 swapped (the A operand simply reads LDS
-// row kappa(lane&31)); then the 8 accumulator registers 8s..8s+7 of a lane hold 8 CONSECUTIVE keys
+// The S^T row index i is mapped to key kappa(i) = i with bits 2 and 3 swapped (the A operand simply reads LDS row
+// kappa(lane&31)); then the 8 accumulator registers 8s..8s+7 of a lane hold 8 CONSECUTIVE keys
 // 16s + 8*(lane>>5) + 0..7, which is exactly the k-slot order of the B operand of the second MFMA -- P never
 // leaves registers and V^T is read with one ds_read_b128 per MFMA.
+//
+// This kernel is VALU-bound, not MFMA-bound (PMC: at head_dim 64 the softmax costs 2x the matrix-pipe time), so the
+// structure minimises VALU instructions per key: the tile loop is unrolled by the ring depth (every LDS address is
+// base register + immediate, no per-tile address arithmetic), S^T ping-pongs between two register sets (no copies),
+// the exponent argument and the row sum use packed fp32 math (v_pk_fma_f32 / v_pk_add_f32), v_exp_f32 is issued
+// directly, and the O rescale is skipped whenever no query of the wave raised its running max (alpha == 1 exactly).
+// S^T of tile j+1 is issued to the matrix pipe BEFORE the softmax of tile j so the two pipes overlap inside a wave.
 #include "common.h"
 
 namespace {
 
-constexpr int QB = 128;  // queries per workgroup
-constexpr int KB = 64;   // keys per tile
-constexpr int TILE = KB * 64 * 2;  // 8 KiB per operand tile
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+constexpr int QB = 128;            // queries per workgroup
+constexpr int KB = 64;             // keys per tile
+constexpr int TILE = KB * 64 * 2;  // 8 KiB per operand tile
+constexpr int STAGE = 2 * TILE;    // K | V^T
+constexpr int NST = 4;             // ring depth
+constexpr int PW = 4;              // DMA pieces per wave per tile (2 K + 2 V^T)
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+struct Ctx {
+  char* smem;
+  const char* kg;   // K of this (b, h), bytes
+  const char* vg;   // V^T of this (b, h), bytes
+  unsigned koff[2], voff[2];   // per-lane DMA source offsets (bytes) of this wave's two K / two V^T pieces
+  int kbase, vbase;            // per-lane LDS byte offsets of the A-operand rows (swizzle folded in), stage 0
+  int kx[4], vx[4];            // per-lane swizzled chunk offsets for the 4 k-steps of S^T / the 4 (t, ss) steps of PV
+  int wave, hi;
+  int kvlen, ntiles;
+  float c;
+};
+
+__device__ __forceinline__ void issue_tile(const Ctx& x, int stage, int j) {
+  char* base = x.smem + stage * STAGE + x.wave * 1024;
+  const char* kt = x.kg + (size_t)j * (KB * 64 * 2);
+  const char* vt = x.vg + (size_t)j * (KB * 2);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kt + x.koff[i]),
+                                     (__attribute__((address_space(3))) void*)(base + i * 4096), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vt + x.voff[i]),
+                                     (__attribute__((address_space(3))) void*)(base + TILE + i * 4096), 16, 0, 0);
+  }
+}
+
+template <int ST>
+__device__ __forceinline__ void qk_tile(const Ctx& x, const bf16x8 (&qf)[4], f32x16 (&s)[2]) {
+  const char* sK = x.smem + ST * STAGE + x.kbase;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(sK + t * 4096 + x.kx[kk]);
+      s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[kk], s[t], 0, 0, 0);
+    }
+  }
+}
+
+// softmax of tile j held in `s`, then O^T += V^T . P^T from ring stage ST
+template <int ST>
+__device__ __forceinline__ void softmax_pv(const Ctx& x, int j, f32x16 (&s)[2], f32x16 (&o)[2], float& m_run, float& l_run) {
+  // lane's register r of sub-tile t is key  j*64 + 32 t + 16 (r>>3) + 8 hi + (r&7)
+  if ((j + 1) * KB > x.kvlen) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = j * KB + 32 * t + 16 * (r >> 3) + 8 * x.hi + (r & 7);
+        if (key >= x.kvlen) s[t][r] = -INFINITY;
+      }
+  }
+  float mx = s[0][0];
+#pragma unroll
+  for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));   // partner lane holds the other 32 keys of the tile
+  const float m_new = fmaxf(m_run, mx * x.c);
+  // v_exp_f32 directly: exp2f() wraps it in a 6-instruction denormal-range fix-up softmax does not need
+  const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // first tile: exp2(-inf) = 0
+  const bool grew = m_new > m_run;
+  m_run = m_new;
+  const f32x2 c2 = {x.c, x.c}, m2 = {m_new, m_new};
+  f32x2 ps = {0.f, 0.f};
+  bf16x8 pb[2][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      f32x2 e = {s[t][r], s[t][r + 1]};
+      e = e * c2 - m2;                                  // v_pk_fma_f32
+      f32x2 pv = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+      ps += pv;                                         // v_pk_add_f32
+      pb[t][r >> 3][r & 7] = (bf16_t)pv[0];
+      pb[t][r >> 3][(r & 7) + 1] = (bf16_t)pv[1];
+    }
+  l_run = l_run * alpha + (ps[0] + ps[1]);
+  if (__any(grew)) {   // wave-uniform: when no query of this wave raised its running max, alpha == 1 exactly
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+  }
+  const char* sV = x.smem + ST * STAGE + TILE + x.vbase;
+  __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(sV + dt * 4096 + x.vx[t * 2 + ss]);
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb[t][ss], o[dt], 0, 0, 0);
+      }
+  __builtin_amdgcn_s_setprio(0);
+}
+
+// one ring position of the 4x-unrolled tile loop: tile j lives in stage ST, its S^T in `s_cur`; S^T of tile j+1 goes
+// to `s_nxt` (stage ST+1) before the softmax of tile j
+template <int ST>
+__device__ __forceinline__ void step(const Ctx& x, int j, const bf16x8 (&qf)[4], f32x16 (&s_cur)[2], f32x16 (&s_nxt)[2],
+                                     f32x16 (&o)[2], float& m_run, float& l_run) {
+  // tile j+1 must have landed; tile j+2 may stay in flight across the barrier
+  if (j + 2 < x.ntiles) wait_vmcnt<PW>();
+  else wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  // all waves are past tile j-1: its stage (ST+3 mod 4) is free for tile j+3
+  if (j + NST - 1 < x.ntiles) issue_tile(x, (ST + NST - 1) % NST, j + NST - 1);
+  if (j + 1 < x.ntiles) qk_tile<(ST + 1) % NST>(x, qf, s_nxt);
+  softmax_pv<ST>(x, j, s_cur, o, m_run, l_run);
+}
 
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * TILE];  // [2][K 8K | V^T 8K]
+  __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int l31 = lane & 31, hi = lane >> 5;
   const int bh = blockIdx.y;
   const int b2 = bh / p.heads, h = bh - b2 * p.heads;
   const int N = p.n;
-  const int kvlen = p.kv_len ? p.kv_len[b2 % p.batch] : N;
-  const int q_base = blockIdx.x * QB + wave * 32;
 
-  const bf16_t* Qg = p.q + (size_t)bh * p.pitch * 64;
-  const bf16_t* Kg = p.k + (size_t)bh * p.pitch * 64;
-  const bf16_t* Vg = p.vt + (size_t)bh * 64 * p.npad;
+  Ctx x;
+  x.smem = smem;
+  x.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  x.hi = hi;
+  x.kvlen = p.kv_len ? p.kv_len[b2 % p.batch] : N;
+  x.ntiles = (x.kvlen + KB - 1) / KB;
+  x.c = p.scale * 1.4426950408889634f;  // softmax in base 2
+  x.kg = reinterpret_cast<const char*>(p.k + (size_t)bh * p.pitch * 64);
+  x.vg = reinterpret_cast<const char*>(p.vt + (size_t)bh * 64 * p.npad);
+  const int q_base = blockIdx.x * QB + x.wave * 32;
+
+  // DMA: a tile is 8 + 8 one-KiB pieces (8 rows of 128 B each); wave w owns pieces {w, w+4} of K and of V^T.
+  // lane -> (row, physical chunk); the swizzle sits in the SOURCE address (the LDS image is lane-linear).
+  {
+    const int lr = lane >> 3, lp = lane & 7;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = 8 * (x.wave + 4 * i) + lr;
+      const int c = (lp ^ ((r >> 1) & 7)) << 3;   // elements
+      x.koff[i] = (unsigned)((r * 64 + c) * 2);
+      x.voff[i] = (unsigned)((r * p.npad + c) * 2);
+    }
+  }
+  // A-operand rows: S^T reads K row kappa(l31) (bits 2,3 of the MFMA row index swapped), PV reads V^T row l31 (= d).
+  // lds_off(row, chunk) = row*128 + ((chunk ^ ((row>>1)&7)) << 4); +32 rows leaves the swizzle unchanged (+4096 B).
+  {
+    const int krow = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+    x.kbase = krow * 128;
+    x.vbase = l31 * 128;
+    const int ksw = (krow >> 1) & 7, vsw = (l31 >> 1) & 7;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) x.kx[kk] = ((kk * 2 + hi) ^ ksw) << 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x.vx[e] = ((2 * e + hi) ^ vsw) << 4;   // chunk = 4 t + 2 ss + hi, e = 2 t + ss
+  }
 
   // Q fragment (B operand of S^T = K.Q^T): lane (q = l31, hi) holds Q[q][kk*16 + hi*8 .. +7]
   bf16x8 qf[4];
   {
+    const bf16_t* Qg = p.q + (size_t)bh * p.pitch * 64;
     int qrow = q_base + l31;
     qrow = qrow < N ? qrow : N - 1;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
       qf[kk] = *reinterpret_cast<const bf16x8*>(Qg + (size_t)qrow * 64 + kk * 16 + hi * 8);
   }
-  // kappa: swap bits 2 and 3 of the MFMA row index
-  const int krow = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
-
-  // staging coordinates: 512 16-B chunks per tile, 2 per thread per operand
-  const int srow0 = tid >> 3, schunk = tid & 7;  // rows srow0 and srow0 + 32
-  u32x4 rk[2], rv[2];
-  const int ntiles = (kvlen + KB - 1) / KB;
-
-  auto gload = [&](int j) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = srow0 + 32 * i;
-      int key = j * KB + r;
-      key = key < N ? key : N - 1;
-      rk[i] = *reinterpret_cast<const u32x4*>(Kg + (size_t)key * 64 + schunk * 8);
-      rv[i] = *reinterpret_cast<const u32x4*>(Vg + (size_t)r * p.npad + j * KB + schunk * 8);
-    }
-  };
-  auto lwrite = [&](int buf) {
-    char* d = smem + buf * 2 * TILE;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = srow0 + 32 * i;
-      *reinterpret_cast<u32x4*>(d + lds_off(r, schunk)) = rk[i];
-      *reinterpret_cast<u32x4*>(d + TILE + lds_off(r, schunk)) = rv[i];
-    }
-  };
 
   f32x16 o[2];
 #pragma unroll
   for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
   float m_run = -INFINITY, l_run = 0.f;
-  const float c = p.scale * 1.4426950408889634f;  // softmax in base 2
 
-  gload(0);
-  lwrite(0);
-  __syncthreads();
+  // prologue: tiles 0..2 in flight, S^T of tile 0 computed
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s)
+    if (s < x.ntiles) issue_tile(x, s, s);
+  if (x.ntiles > 2) wait_vmcnt<2 * PW>();
+  else if (x.ntiles > 1) wait_vmcnt<PW>();
+  else wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  f32x16 sa[2], sb[2];
+  qk_tile<0>(x, qf, sa);
 
-  for (int j = 0; j < ntiles; ++j) {
-    const int buf = j & 1;
-    if (j + 1 < ntiles) gload(j + 1);
-    const char* sK = smem + buf * 2 * TILE;
-    const char* sV = sK + TILE;
-
-    // ---- S^T = K . Q^T for two 32-key sub-tiles
-    f32x16 s[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(sK + lds_off(t * 32 + krow, kk * 2 + hi));
-        s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[kk], s[t], 0, 0, 0);
-      }
-    }
-    // lane's register r of sub-tile t is key  j*64 + 32 t + 16 (r>>3) + 8 hi + (r&7)
-    if ((j + 1) * KB > kvlen) {
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = j * KB + 32 * t + 16 * (r >> 3) + 8 * hi + (r & 7);
-          if (key >= kvlen) s[t][r] = -INFINITY;
-        }
-    }
-    // ---- online softmax (per-lane query; partner lane^32 holds the other half of the keys)
-    float mx = s[0][0];
-#pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx * c);
-    const float alpha = exp2f(m_run - m_new);  // first tile: exp2(-inf) = 0
-    m_run = m_new;
-    float psum = 0.f;
-    bf16x8 pb[2][2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pv = exp2f(fmaf(s[t][r], c, -m_new));
-        psum += pv;
-        pb[t][r >> 3][r & 7] = (bf16_t)pv;
-      }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
-
-    // ---- O^T += V^T . P^T
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int ss = 0; ss < 2; ++ss) {
-          const bf16x8 a = *reinterpret_cast<const bf16x8*>(sV + lds_off(dt * 32 + l31, 4 * t + 2 * ss + hi));
-          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb[t][ss], o[dt], 0, 0, 0);
-        }
-
-    if (j + 1 < ntiles) lwrite(buf ^ 1);
-    __syncthreads();
+  for (int j = 0; j < x.ntiles; j += NST) {
+    step<0>(x, j, qf, sa, sb, o, m_run, l_run);
+    if (j + 1 < x.ntiles) step<1>(x, j + 1, qf, sb, sa, o, m_run, l_run);
+    if (j + 2 < x.ntiles) step<2>(x, j + 2, qf, sa, sb, o, m_run, l_run);
+    if (j + 3 < x.ntiles) step<3>(x, j + 3, qf, sb, sa, o, m_run, l_run);
   }
 
   // ---- normalise and store: lane owns query q_base + l31; rows of O^T are d = 32 dt + (r&3) + 8 (r>>2) + 4 hi
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = 1.0f / l_tot;
+  const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32, 64));
   const int q = q_base + l31;
   if (q < N) {
     bf16_t* dst = p.out + ((size_t)b2 * p.pitch + q) * (p.heads * 64) + h * 64;
@@ -179,7 +255,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
 }  // namespace
 
 hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
-  if (p.npad % 64 != 0 || p.n <= 0 || p.pitch < p.n) return hipErrorInvalidValue;
+  // K rows are loaded up to the next multiple of 64 without clamping: the row pitch must cover them
+  if (p.npad % 64 != 0 || p.n <= 0 || p.pitch < ((p.n + 63) & ~63) || p.npad < ((p.n + 63) & ~63)) return hipErrorInvalidValue;
   dim3 grid((p.n + QB - 1) / QB, p.b2 * p.heads);
   hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, s, p);
   return hipGetLastError();

@@ -35,6 +35,26 @@ __global__ void transpose_v_kernel(const float* v, bf16_t* vt, int BH, int N, in
     vt[((size_t)bh * 64 + d) * npad + n] = (bf16_t)v[i];
   }
 }
+// [BH][N][64] fp32 -> [BH][pitch][64] bf16 (rows >= N stay zero)
+__global__ void pad_rows_kernel(const float* src, bf16_t* dst, int BH, int N, int pitch) {
+  const size_t total = (size_t)BH * N * 64;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int d = (int)(i % 64);
+    const int n = (int)((i / 64) % N);
+    const int bh = (int)(i / ((size_t)64 * N));
+    dst[((size_t)bh * pitch + n) * 64 + d] = (bf16_t)src[i];
+  }
+}
+// [B][pitch][C] bf16 -> [B][N][C] fp32
+__global__ void unpad_widen_kernel(const bf16_t* src, float* dst, int B, int N, int pitch, int C) {
+  const size_t total = (size_t)B * N * C;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int n = (int)((i / C) % N);
+    const int b = (int)(i / ((size_t)C * N));
+    dst[i] = (float)src[((size_t)b * pitch + n) * C + c];
+  }
+}
 __global__ void widen_kernel(const bf16_t* src, float* dst, size_t n) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = (float)src[i];
 }
@@ -94,21 +114,21 @@ int lemas_k_attention(const float* q, const float* k, const float* v, const int3
                       int32_t H, int32_t N, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   Scratch sc;
-  const int npad = (N + 63) & ~63;
-  const size_t n = (size_t)B * H * N * 64;
-  bf16_t* qb = sc.get<bf16_t>(n);
-  bf16_t* kb = sc.get<bf16_t>(n);
+  const int pitch = (N + 127) & ~127, npad = pitch;
+  const size_t np = (size_t)B * H * pitch * 64;
+  bf16_t* qb = sc.get<bf16_t>(np);
+  bf16_t* kb = sc.get<bf16_t>(np);
   bf16_t* vt = sc.get<bf16_t>((size_t)B * H * 64 * npad);
-  bf16_t* ob = sc.get<bf16_t>(n);
+  bf16_t* ob = sc.get<bf16_t>(np);
   if (!qb || !kb || !vt || !ob) { set_error("lemas_k_attention: out of memory"); return LEMAS_E_STATE; }
-  HIP_TRY(launch_f32_to_bf16(q, qb, n, s));
-  HIP_TRY(launch_f32_to_bf16(k, kb, n, s));
+  hipLaunchKernelGGL(pad_rows_kernel, dim3(2048), dim3(256), 0, s, q, qb, B * H, N, pitch);
+  hipLaunchKernelGGL(pad_rows_kernel, dim3(2048), dim3(256), 0, s, k, kb, B * H, N, pitch);
   hipLaunchKernelGGL(transpose_v_kernel, dim3(2048), dim3(256), 0, s, v, vt, B * H, N, npad);
   AttnParams p{};
-  p.q = qb; p.k = kb; p.vt = vt; p.out = ob; p.kv_len = seq_len; p.b2 = B; p.batch = B; p.heads = H; p.n = N; p.npad = npad; p.pitch = N;
+  p.q = qb; p.k = kb; p.vt = vt; p.out = ob; p.kv_len = seq_len; p.b2 = B; p.batch = B; p.heads = H; p.n = N; p.npad = npad; p.pitch = pitch;
   p.scale = 0.125f;
   HIP_TRY(launch_attention(p, s));
-  hipLaunchKernelGGL(widen_kernel, dim3(1024), dim3(256), 0, s, ob, out, n);
+  hipLaunchKernelGGL(unpad_widen_kernel, dim3(2048), dim3(256), 0, s, ob, out, B, N, pitch, H * 64);
   HIP_TRY(hipStreamSynchronize(s));
   return 0;
 }
@@ -200,17 +220,17 @@ extern "C" int lemas_k_bench(const char* what, int32_t M, int32_t N, int32_t K, 
     rc = time_it([&]() { return launch_gemm_bf16_variant(epi, p, variant, s); });
   } else if (w == "attention") {
     // M = sequence length, N = batch*heads
-    const int n = M, bh = N, npad = (n + 63) & ~63;
-    bf16_t* q = sc.get<bf16_t>((size_t)bh * n * 64);
-    bf16_t* k = sc.get<bf16_t>((size_t)bh * n * 64);
+    const int n = M, bh = N, npad = (n + 127) & ~127, pitch = npad;
+    bf16_t* q = sc.get<bf16_t>((size_t)bh * pitch * 64);
+    bf16_t* k = sc.get<bf16_t>((size_t)bh * pitch * 64);
     bf16_t* vt = sc.get<bf16_t>((size_t)bh * 64 * npad);
-    bf16_t* o = sc.get<bf16_t>((size_t)bh * n * 64);
+    bf16_t* o = sc.get<bf16_t>((size_t)bh * pitch * 64);
     if (!q || !k || !vt || !o) { set_error("bench: out of memory"); return LEMAS_E_STATE; }
-    hipLaunchKernelGGL(fill_pattern_kernel, dim3(1024), dim3(256), 0, s, q, (size_t)bh * n * 64, 3u);
-    hipLaunchKernelGGL(fill_pattern_kernel, dim3(1024), dim3(256), 0, s, k, (size_t)bh * n * 64, 4u);
+    hipLaunchKernelGGL(fill_pattern_kernel, dim3(1024), dim3(256), 0, s, q, (size_t)bh * pitch * 64, 3u);
+    hipLaunchKernelGGL(fill_pattern_kernel, dim3(1024), dim3(256), 0, s, k, (size_t)bh * pitch * 64, 4u);
     hipLaunchKernelGGL(fill_pattern_kernel, dim3(1024), dim3(256), 0, s, vt, (size_t)bh * 64 * npad, 5u);
     AttnParams p{};
-    p.q = q; p.k = k; p.vt = vt; p.out = o; p.kv_len = nullptr; p.b2 = bh / 16; p.batch = bh / 16; p.heads = 16; p.n = n; p.npad = npad; p.pitch = n;
+    p.q = q; p.k = k; p.vt = vt; p.out = o; p.kv_len = nullptr; p.b2 = bh / 16; p.batch = bh / 16; p.heads = 16; p.n = n; p.npad = npad; p.pitch = pitch;
     p.scale = 0.125f;
     rc = time_it([&]() { return launch_attention(p, s); });
   } else {
