@@ -1,0 +1,109 @@
+"""Host-side mirror of ``lemas_tts/api.py``: the ``TTS`` facade over the MI355X engines.
+
+Same constructor arguments and the same ``infer(...)`` keyword surface and return value as ``api.py:83-97`` /
+``:171-249``.  What differs is stated, not hidden:
+
+* ``frontend`` is an OBJECT with ``text2phn(str) -> 'p1|p2|...'`` and ``dtype == "phone"`` (the reference builds
+  ``TextNorm`` from espeak/jieba/langid, none of which exist here and all of which are out of scope); with
+  ``frontend=None`` the caller passes phone-token lists directly;
+* ``ref_file`` is the reference mel ``[F, 100]`` (or an ``(audio, sr)`` pair once the wav->mel front edge lands);
+* ``state_dict`` / ``vocoder_state_dict`` / ``vocab_char_map`` allow in-memory (synthetic) weights.
+"""
+from __future__ import annotations
+
+import random
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from .infer.utils_infer import infer_process, load_arch_config, load_model, load_vocoder
+
+
+def seed_everything(seed=0):
+    """``model/utils.py:18-25``."""
+    random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+
+
+class TTS:
+    def __init__(self, model="multilingual_grl", ckpt_file="", vocab_file="", ode_method="euler", use_ema=False,
+                 vocoder_local_path=None, use_prosody_encoder=False, prosody_cfg_path="", prosody_ckpt_path="",
+                 device=None, hf_cache_dir=None, frontend=None, *, state_dict=None, vocoder_state_dict=None,
+                 vocab_char_map=None):
+        cfg = load_arch_config(model)                                   # api.py:99-105
+        self.mel_spec_type = cfg["mel_spec"]["mel_spec_type"]
+        self.target_sample_rate = cfg["mel_spec"]["target_sample_rate"]
+        self.ode_method, self.use_ema = ode_method, use_ema
+        self.langs = {"cmn": "zh", "zh": "zh", "en": "en-us", "it": "it", "es": "es", "pt": "pt-br", "fr": "fr-fr",
+                      "de": "de", "ru": "ru", "id": "id", "vi": "vi", "th": "th"}
+        if device is None:
+            if not torch.cuda.is_available():
+                raise RuntimeError("lemas_tts_amd has no CPU path: an MI355X ('cuda') device is required")
+            device = "cuda:0"
+        self.device = device
+        is_local = vocoder_local_path is not None and Path(str(vocoder_local_path)).is_dir()
+        self.vocoder = load_vocoder(self.mel_spec_type, is_local, vocoder_local_path, self.device, hf_cache_dir,
+                                    state_dict=vocoder_state_dict)          # api.py:136
+        self.frontend = frontend                                            # api.py:140-151
+        self.ema_model = load_model(None, cfg["arch"], ckpt_file, self.mel_spec_type, vocab_file, self.ode_method,
+                                    self.use_ema, self.device, use_prosody_encoder=use_prosody_encoder,
+                                    prosody_cfg_path=prosody_cfg_path, prosody_ckpt_path=prosody_ckpt_path,
+                                    state_dict=state_dict, vocab_char_map=vocab_char_map)   # api.py:154
+        self.seed = None
+
+    def export_wav(self, wav, file_wave, remove_silence=False):
+        """api.py:162-166 writes with soundfile; here a minimal 16-bit PCM writer (no soundfile in this image)."""
+        import wave
+        pcm = (np.clip(wav, -1.0, 1.0) * 32767.0).astype("<i2")
+        with wave.open(str(file_wave), "wb") as f:
+            f.setnchannels(1)
+            f.setsampwidth(2)
+            f.setframerate(self.target_sample_rate)
+            f.writeframes(pcm.tobytes())
+
+    def infer(self, ref_file, ref_text, gen_text, show_info=print, progress=None, target_rms=0.1,
+              cross_fade_duration=0.15, use_acc_grl=False, ref_ratio=None, no_ref_audio=False, cfg_strength=2,
+              nfe_step=32, speed=1.0, sway_sampling_coef=5, separate_langs=False, fix_duration=None,
+              use_prosody_encoder=True, file_wave=None, file_spec=None, seed=None, **extra):
+        if seed is None:
+            seed = random.randint(0, sys.maxsize)                           # api.py:194-197
+        seed_everything(seed)
+        self.seed = seed
+        if self.frontend is not None and isinstance(ref_text, str):
+            if getattr(self.frontend, "dtype", "phone") != "phone":
+                raise NotImplementedError("only the phone frontend of the shipped models is mirrored")
+            ref_text = self.frontend.text2phn(ref_text + ". ").replace("(cmn)", "(zh)").split("|")      # api.py:202
+            gen_text = [self.frontend.text2phn(x + ". ").replace("(cmn)", "(zh)").split("|") for x in gen_text.split("\n")]
+        if separate_langs:
+            ref_text = self.process_phone_list(ref_text)                    # api.py:214-216
+            gen_text = [self.process_phone_list(x) for x in gen_text]
+        wav, sr, spec = infer_process(
+            ref_file, ref_text, gen_text, self.ema_model, self.vocoder, self.mel_spec_type, show_info=show_info,
+            progress=progress, target_rms=target_rms, cross_fade_duration=cross_fade_duration, nfe_step=nfe_step,
+            cfg_strength=cfg_strength, sway_sampling_coef=sway_sampling_coef, use_prosody_encoder=use_prosody_encoder,
+            use_acc_grl=use_acc_grl, ref_ratio=ref_ratio, no_ref_audio=no_ref_audio, speed=speed,
+            fix_duration=fix_duration, device=self.device, seed=seed, **extra)
+        if file_wave is not None:
+            self.export_wav(wav, file_wave)
+        return wav, sr, spec
+
+    def process_phone_list(self, parts):
+        """api.py:252-276: prefix every non-punctuation phone with the current language id."""
+        puncs = {"#1", "#2", "#3", "#4", "_", "!", ",", ".", "?", '"', "'", "^", "。", "，", "？", "！"}
+        processed, current_lang = [], ""
+        for part in parts:
+            if part.startswith("(") and part.endswith(")") and part[1:-1] in self.langs:
+                current_lang = part
+            elif part in puncs:
+                if processed and processed[-1] == "_":
+                    processed.pop()
+                elif processed and processed[-1] in puncs and part == "_":
+                    continue
+                processed.append(part)
+            elif current_lang is not None:
+                processed.append(f"{current_lang}{part}")
+        return processed
