@@ -1,0 +1,60 @@
+"""GPU tier: the mirrored call surface end to end -- TTS.infer (two text lines -> two generations, vocoder, rms
+rescale, cross-fade) on synthetic weights against the same pipeline assembled from the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from lemas_tts_amd import synth
+from lemas_tts_amd.model.layout import DiTArch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_tts_infer_end_to_end_vs_oracle():
+    from lemas_tts_amd.api import TTS
+    from lemas_tts_amd.infer.utils_infer import cross_fade_concat
+    from oracle import lemas_oracle as O
+    import lemas_tts_amd.infer.utils_infer as UI
+
+    arch = DiTArch(depth=2)
+    vocab = {f"p{i}": i for i in range(898)}
+    sd = synth.synth_cfm_state_dict(arch, 898, 31)
+    vsd = synth.synth_vocos_state_dict(32)
+    # depth-2 stand-in for the yaml's depth 22 (weights are synthetic anyway)
+    UI_load = UI.load_arch_config
+    UI.load_arch_config = lambda m: {**UI_load(m), "arch": {**UI_load(m)["arch"], "depth": 2}}
+    import lemas_tts_amd.api as A
+    A.load_arch_config = UI.load_arch_config
+    try:
+        tts = TTS(model="multilingual_grl", device="cuda:0", state_dict=sd, vocoder_state_dict=vsd, vocab_char_map=vocab)
+    finally:
+        UI.load_arch_config = UI_load
+        A.load_arch_config = UI_load
+    F_ = 60
+    ref_mel = torch.from_numpy(synth.synth_cond_mel(33, F_))
+    ref_text = [f"p{i}" for i in synth.synth_tokens(34, 12, 898)]
+    lines = [[f"p{i}" for i in synth.synth_tokens(35 + k, 9 + 3 * k, 898)] for k in range(2)]
+    ref_len = F_ - 1
+    durs = [ref_len + int(ref_len / len(ref_text) * len(g) / 1.0) for g in lines]
+    durs = [max(d, F_ + 1, len(ref_text) + len(g) + 1) for d, g in zip(durs, lines)]
+    noise = [torch.from_numpy(synth.synth_noise(40 + k, d))[None] for k, d in enumerate(durs)]
+    wav, sr, spec = tts.infer(ref_mel, ref_text, lines, nfe_step=4, cfg_strength=2, sway_sampling_coef=5, noise=noise, seed=1)
+    assert sr == 24000
+
+    cfm, voc = O.OracleCFM(sd, arch), O.OracleVocos(vsd)
+    waves, mels = [], []
+    for k, g in enumerate(lines):
+        text = O.tokens_to_idx([ref_text + g], vocab)
+        dur = ref_len + int(ref_len / len(ref_text) * len(g) / 1.0)
+        out, _ = cfm.sample(ref_mel[None], text, dur, y0=noise[k], steps=4, cfg_strength=2, sway_sampling_coef=5)
+        mel = out[:, ref_len:, :].permute(0, 2, 1)
+        mels.append(mel[0].numpy())
+        waves.append(voc.decode(mel)[0].numpy())
+    ref_wav = np.clip(cross_fade_concat(waves, 0.15), -0.999, 0.999)
+    ref_spec = np.concatenate(mels, axis=1)
+    assert wav.shape == ref_wav.shape and spec.shape == ref_spec.shape
+    mse = float(((spec - ref_spec) ** 2).mean())
+    rel = float(np.sqrt(((wav - ref_wav) ** 2).mean()) / np.sqrt((ref_wav ** 2).mean()))
+    print(f"\n[tts.infer] mel-MSE {mse:.3e}  waveform relative rms error {rel:.3e}")
+    assert mse <= 1e-4
+    assert rel < 5e-2      # bf16-level mel differences pushed through a random-weight vocoder

@@ -1,0 +1,44 @@
+"""CPU tier: host-side logic of the mirrored call surface that needs no GPU."""
+import numpy as np
+import torch
+
+from lemas_tts_amd.infer.utils_infer import cross_fade_concat
+from lemas_tts_amd.model.cfm import compute_sway_max, lens_to_mask, list_str_to_idx, time_grid
+from oracle import lemas_oracle as O
+
+
+def test_time_grid_matches_oracle_bitwise():
+    for steps in (3, 4, 16, 32, 48):
+        for coef in (None, 1, 3.0, 5, -1):
+            assert torch.equal(time_grid(steps, coef), O.time_grid(steps, coef))
+    assert abs(compute_sway_max(32) - 3.486) < 1e-3
+
+
+def test_token_and_mask_helpers():
+    vocab = {"a": 1, "b": 2, " ": 0}
+    t = list_str_to_idx([["a", "b", "zz"], ["b"]], vocab)
+    assert t.tolist() == [[1, 2, 0], [2, -1, -1]]          # unknown -> 0, pad -1 (model/utils.py:87-94)
+    m = lens_to_mask(torch.tensor([2, 4]))
+    assert m.tolist() == [[True, True, False, False], [True] * 4]
+
+
+def test_cross_fade_matches_reference_formula():
+    # utils_infer.py:581-617: linear fade over min(0.15 s, len(prev), len(next)) samples
+    rng = np.random.default_rng(0)
+    a, b, c = rng.standard_normal(6000), rng.standard_normal(5000), rng.standard_normal(100)
+    out = cross_fade_concat([a, b, c], 0.15)
+    n1 = int(0.15 * 24000)
+    exp = np.concatenate([a[:-n1], a[-n1:] * np.linspace(1, 0, n1) + b[:n1] * np.linspace(0, 1, n1), b[n1:]])
+    n2 = 100
+    exp = np.concatenate([exp[:-n2], exp[-n2:] * np.linspace(1, 0, n2) + c[:n2] * np.linspace(0, 1, n2), c[n2:]])
+    np.testing.assert_allclose(out, exp)
+    np.testing.assert_array_equal(cross_fade_concat([a, b], 0.0), np.concatenate([a, b]))
+
+
+def test_process_phone_list_rules():
+    # api.py:252-276 -- language tags are consumed, phones get the current tag as prefix, '_' before punctuation drops
+    from lemas_tts_amd.api import TTS
+    t = TTS.__new__(TTS)
+    t.langs = {"en": "en-us", "zh": "zh"}
+    out = t.process_phone_list(["(en)", "h", "@", "_", ",", "_", "(zh)", "n", "i3", "."])
+    assert out == ["(en)h", "(en)@", ",", "(zh)n", "(zh)i3", "."]
