@@ -73,14 +73,17 @@ template <int ST>
 __device__ __forceinline__ void qk_tile(const Ctx& x, const bf16x8 (&qf)[4], f32x16 (&s)[2]) {
   const char* sK = x.smem + ST * STAGE + x.kbase;
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
+  for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+  // the two 32-key sub-tiles are independent accumulators: alternate them so no MFMA waits on its predecessor
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const bf16x8 a = *reinterpret_cast<const bf16x8*>(sK + t * 4096 + x.kx[kk]);
-      s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[kk], s[t], 0, 0, 0);
-    }
+  for (int kk = 0; kk < 4; ++kk) {
+    bf16x8 a[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) a[t] = *reinterpret_cast<const bf16x8*>(sK + t * 4096 + x.kx[kk]);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t], qf[kk], s[t], 0, 0, 0);
   }
 }
 
@@ -129,15 +132,17 @@ __device__ __forceinline__ void softmax_pv(const Ctx& x, int j, f32x16 (&s)[2], 
   }
   const char* sV = x.smem + ST * STAGE + TILE + x.vbase;
   __builtin_amdgcn_s_setprio(1);
+  // the two 32-row halves of O^T are independent accumulators: alternate them (no back-to-back dependent MFMAs)
 #pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
+  for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int ss = 0; ss < 2; ++ss) {
+      bf16x8 a[2];
 #pragma unroll
-      for (int ss = 0; ss < 2; ++ss) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(sV + dt * 4096 + x.vx[t * 2 + ss]);
-        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb[t][ss], o[dt], 0, 0, 0);
-      }
+      for (int dt = 0; dt < 2; ++dt) a[dt] = *reinterpret_cast<const bf16x8*>(sV + dt * 4096 + x.vx[t * 2 + ss]);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[dt], pb[t][ss], o[dt], 0, 0, 0);
+    }
   __builtin_amdgcn_s_setprio(0);
 }
 

@@ -12,6 +12,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define LEMAS_WAVE 64
 
+// 16-byte global store with the sc1 (write-through) cache policy: the line goes to memory now instead of sitting dirty
+// in this XCD's L2 until the end-of-kernel write-back, which otherwise serialises ~B/6 TB/s behind every producer
+// kernel (MI355X_MICROARCH.md price list, rows 'boundary' and 'publish-large').  Consumers run on other XCDs anyway
+// (private, non-coherent L2s), so nothing is lost by not keeping the line.  The asm store is invisible to the
+// compiler's waitcnt bookkeeping; s_nop 1 keeps the data registers intact until the store has read them.
+__device__ __forceinline__ void store_wt_b128(void* p, unsigned int __attribute__((ext_vector_type(4))) v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -23,21 +32,23 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Activations: v_exp_f32 / v_rcp_f32 directly (1 ulp class) -- a precise fp32 division costs ~10 VALU instructions and
+// these sit in GEMM / conv epilogues that run 64 values per lane.
+__device__ __forceinline__ float fast_sigmoid(float z) {   // 1 / (1 + e^-z); z -> -inf gives rcp(inf) = 0
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z));
+}
 __device__ __forceinline__ float gelu_tanh_f(float x) {
-  // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)));  tanh(u) = 1 - 2/(1+exp(2u))
-  const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-  const float e = __expf(2.0f * u);
-  const float th = 1.0f - 2.0f / (1.0f + e);
-  return 0.5f * x * (1.0f + th);
+  // 0.5 x (1 + tanh(u)) = x * sigmoid(2u),  u = sqrt(2/pi) (x + 0.044715 x^3)
+  const float u2 = x * (1.5957691216057308f + 0.07135481627260025f * x * x);
+  return x * fast_sigmoid(u2);
 }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * fast_sigmoid(x); }
 __device__ __forceinline__ float mish_f(float x) {
   // x * tanh(softplus(x)); with n = e^x (e^x + 2): tanh(log(1+e^x)) = n / (n + 2).  softplus threshold 20 as torch.
-  const float xe = fminf(x, 20.0f);
-  const float e = __expf(xe);
+  const float e = __builtin_amdgcn_exp2f(1.4426950408889634f * fminf(x, 20.0f));
   const float n = e * (e + 2.0f);
-  return x * (n / (n + 2.0f));
+  return x * n * __builtin_amdgcn_rcpf(n + 2.0f);
 }
 
 // ---- epilogue selectors of the bf16 MFMA GEMM -------------------------------------------------
@@ -48,6 +59,7 @@ enum GemmEpi : int {
   EPI_GATE_RES = 3,        // res_f32[m][n] += gate[n] * (acc + bias)   (rows past kv_len contribute 0)
   EPI_QK_ROPE = 4,         // N = 2*inner: +bias, RoPE, scatter to q / k [B2,H,pitch,64]
   EPI_V_T = 5,             // N = inner:   +bias, scatter to v^T [B2,H,64,npad]
+  EPI_NONE = 6,            // benchmarking only: K loop without an epilogue (one guarded store keeps the MFMAs live)
 };
 
 struct GemmParams {

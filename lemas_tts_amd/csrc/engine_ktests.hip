@@ -192,7 +192,7 @@ extern "C" int lemas_k_bench(const char* what, int32_t M, int32_t N, int32_t K, 
     HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
     return 0;
   };
-  if (w == "gemm_gelu" || w == "gemm_gate" || w == "gemm_qk" || w == "gemm_v" || w == "gemm_f32out") {
+  if (w == "gemm_gelu" || w == "gemm_gate" || w == "gemm_qk" || w == "gemm_v" || w == "gemm_f32out" || w == "gemm_none") {
     const int Np = (N + 127) & ~127;
     bf16_t* a = sc.get<bf16_t>((size_t)M * K);
     bf16_t* wt = sc.get<bf16_t>((size_t)Np * K);
@@ -215,7 +215,7 @@ extern "C" int lemas_k_bench(const char* what, int32_t M, int32_t N, int32_t K, 
     p.A = a; p.W = wt; p.bias = b; p.M = M; p.N = Np; p.K = K; p.n_valid = N; p.ldc = N; p.out_bf16 = ob; p.out_f32 = of;
     p.tab = tab; p.tab_stride = 0; p.gate_off = 0; p.step_idx = step; p.seq_pitch = M; p.seq_valid = M; p.batch = 1; p.heads = 16; p.npad = npad;
     p.q = q; p.k = k; p.vt = vt; p.rope_cos = rc_; p.rope_sin = rs_;
-    const int epi = w == "gemm_gelu" ? EPI_BIAS_GELU_BF16 : w == "gemm_gate" ? EPI_GATE_RES : w == "gemm_qk" ? EPI_QK_ROPE : w == "gemm_v" ? EPI_V_T : EPI_BIAS_F32;
+    const int epi = w == "gemm_gelu" ? EPI_BIAS_GELU_BF16 : w == "gemm_gate" ? EPI_GATE_RES : w == "gemm_qk" ? EPI_QK_ROPE : w == "gemm_v" ? EPI_V_T : w == "gemm_none" ? EPI_NONE : EPI_BIAS_F32;
     if ((epi == EPI_QK_ROPE && N != 2048) || (epi == EPI_V_T && N != 1024)) { set_error("bench: gemm_qk needs N = 2048, gemm_v N = 1024"); return LEMAS_E_ARG; }
     rc = time_it([&]() { return launch_gemm_bf16_variant(epi, p, variant, s); });
   } else if (w == "attention") {
