@@ -52,9 +52,11 @@ def fwd_flops(B: int, N: int) -> float:
     return B * (378_888_192.0 * N + 90_112.0 * N * N)
 
 
-def gemm_class_flops(cls: str, rows: int, d: int = 1024, ff: int = 2048) -> float:
-    return {"gemm_qkv_rope": 2.0 * rows * 3 * d * d, "gemm_attn_out": 2.0 * rows * d * d,
-            "gemm_ff1_gelu": 2.0 * rows * ff * d, "gemm_ff2": 2.0 * rows * d * ff}[cls]
+def class_flops(cls: str, rows: int, n: int, bb: int, d: int = 1024, ff: int = 2048, heads: int = 16) -> float:
+    """Algorithmic FLOPs of one launch of a step-loop kernel class (rows = BB*N real frames, not the padded row space)."""
+    return {"gemm_qk_rope": 2.0 * rows * 2 * d * d, "gemm_v_t": 2.0 * rows * d * d, "gemm_attn_out": 2.0 * rows * d * d,
+            "gemm_ff1_gelu": 2.0 * rows * ff * d, "gemm_ff2": 2.0 * rows * d * ff,
+            "attention": 4.0 * n * n * 64 * bb * heads}[cls]
 
 
 def build_inputs(rank_seed: int, device):
@@ -202,17 +204,20 @@ def main():
         eng.solve(y0, want_out=False)
         prof = eng.profile_read()
         eng.set_option("profile", 0)
-        gemms = {k: v for k, v in prof.items() if k in ("gemm_qkv_rope", "gemm_attn_out", "gemm_ff1_gelu", "gemm_ff2")}
-        dom = max(gemms, key=lambda k: gemms[k][0])
-        ms, cnt = gemms[dom]
+        mm = {k: v for k, v in prof.items() if k in ("gemm_qk_rope", "gemm_v_t", "gemm_attn_out", "gemm_ff1_gelu", "gemm_ff2", "attention")}
+        dom = max(mm, key=lambda k: mm[k][0])      # dominant kernel = largest total time in the step loop
+        ms, cnt = mm[dom]
         avg_us = 1e3 * ms / max(cnt, 1)
         rows = 2 * N_TOT
-        ach = gemm_class_flops(dom, rows) / (avg_us * 1e-6) / 1e12
+        fl = class_flops(dom, rows, N_TOT, 2)
+        ach = fl / (avg_us * 1e-6) / 1e12
         total_ms = sum(v[0] for v in prof.values())
-        result["roofline"] = {"bound": "mfma", "kernel": f"gemm_bf16_kernel<{dom}>", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS,
+        kname = "attn_fwd_kernel" if dom == "attention" else f"gemm_bf16_kernel<{dom}>"
+        result["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS,
                               "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
-                              "avg_launch_us": avg_us, "launches": int(cnt),
-                              "flops_per_launch": gemm_class_flops(dom, rows)}
+                              "avg_launch_us": avg_us, "launches": int(cnt), "flops_per_launch": fl}
+        result["kernel_tflops"] = {k: round(class_flops(k, rows, N_TOT, 2) / (1e3 * v[0] / max(v[1], 1) * 1e-6) / 1e12, 1)
+                                   for k, v in mm.items()}
         result["kernel_time_share"] = {k: round(v[0] / total_ms, 4) for k, v in prof.items()}
         result["kernel_avg_us"] = {k: round(1e3 * v[0] / max(v[1], 1), 2) for k, v in prof.items()}
         if not a.no_cpu_baseline:

@@ -19,9 +19,9 @@
 
 namespace lemas {
 
-enum ProfClass { PC_INPROJ, PC_CONVPOS, PC_LN, PC_GEMM_QKV, PC_ATTN, PC_GEMM_OUT, PC_GEMM_FF1, PC_GEMM_FF2, PC_GEMM_FINAL,
+enum ProfClass { PC_INPROJ, PC_CONVPOS, PC_LN, PC_GEMM_QK, PC_GEMM_V, PC_ATTN, PC_GEMM_OUT, PC_GEMM_FF1, PC_GEMM_FF2, PC_GEMM_FINAL,
                  PC_CFG_EULER, PC_COUNT };
-static const char* kProfNames[PC_COUNT] = {"inproj_f32", "convpos", "ln_mod", "gemm_qkv_rope", "attention", "gemm_attn_out",
+static const char* kProfNames[PC_COUNT] = {"inproj_f32", "convpos", "ln_mod", "gemm_qk_rope", "gemm_v_t", "attention", "gemm_attn_out",
                                            "gemm_ff1_gelu", "gemm_ff2", "gemm_proj_out", "cfg_euler"};
 
 struct BlockW {
@@ -420,10 +420,12 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     RC_TRY(pbegin(PC_LN, s));
     HIP_TRY(launch_ln_mod(d_xres.as<float>(), d_hbf.as<bf16_t>(), rows, d, tab, tab_stride, base + d, base, step, s));
     RC_TRY(pend(s));
-    RC_TRY(pbegin(PC_GEMM_QKV, s));
+    RC_TRY(pbegin(PC_GEMM_QK, s));
     g.A = d_hbf.as<bf16_t>(); g.W = w.wqkv.as<bf16_t>(); g.bias = w.bqkv.as<float>(); g.N = 2 * in; g.K = d; g.n_valid = 2 * in;
     g.kv_len = nullptr;
     HIP_TRY(launch_gemm_bf16(EPI_QK_ROPE, g, s));
+    RC_TRY(pend(s));
+    RC_TRY(pbegin(PC_GEMM_V, s));
     g.W = w.wqkv.as<bf16_t>() + (size_t)2 * in * d; g.bias = w.bqkv.as<float>() + 2 * in; g.N = in; g.n_valid = in;
     HIP_TRY(launch_gemm_bf16(EPI_V_T, g, s));
     RC_TRY(pend(s));
