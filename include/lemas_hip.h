@@ -114,6 +114,8 @@ int lemas_k_linear_f32(const float* A, const float* W, const float* bias, float*
 /* q,k,v [B,H,N,64] (already rotated) -> out [B,N,H*64]; seq_len device int32 [B] or NULL */
 int lemas_k_attention(const float* q, const float* k, const float* v, const int32_t* seq_len, float* out, int32_t B,
                       int32_t H, int32_t N, void* stream);
+/* selects the attention kernel used by lemas_k_attention: 0 auto (by grid size), 1 four-wave, 2 split-KV eight-wave */
+int lemas_k_set_attention_variant(int32_t variant);
 /* out = LayerNorm(x; eps 1e-6) * (1 + scale) + shift, rows of 1024; result rounded to bf16 then widened */
 int lemas_k_ln_mod(const float* x, const float* scale, const float* shift, float* out, int32_t M, int32_t D, void* stream);
 /* out = conv_pos_embed(x) + x for x [B,N,C]; w1,w2 [C, C/groups, taps], b1,b2 [C] */

@@ -257,12 +257,200 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
   }
 }
 
+
+// ================================================================================================================
+// Split-KV variant for small problems (B = 1: only ~7 waves of work per CU).  A workgroup still owns 128 queries but
+// runs 8 waves: waves 0-3 take the even key tiles, waves 4-7 the odd ones (same queries), and the two partial results
+// (m, l, O^T) are merged through LDS at the end.  Twice the waves per SIMD (4 instead of 2, <= 128 VGPRs each) hide the
+// long per-tile dependency chain (LDS read -> MFMA -> row max -> exchange -> exp -> MFMA) that bounds the 4-wave kernel.
+// Ring: 2 stages of [K0 | V0^T | K1 | V1^T] (32 KiB each), one barrier per tile pair.
+constexpr int STAGE2 = 4 * TILE;
+
+__global__ __launch_bounds__(512, 2) void attn_fwd_splitkv_kernel(const AttnParams p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE2];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, wq = wave & 3;     // key-tile parity, query sub-block
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int bh = blockIdx.y;
+  const int b2 = bh / p.heads, h = bh - b2 * p.heads;
+  const int N = p.n;
+  const int kvlen = p.kv_len ? p.kv_len[b2 % p.batch] : N;
+  const int ntiles = (kvlen + KB - 1) / KB, nsup = (ntiles + 1) >> 1;
+  const float c = p.scale * 1.4426950408889634f;
+  const char* kg = reinterpret_cast<const char*>(p.k + (size_t)bh * p.pitch * 64);
+  const char* vg = reinterpret_cast<const char*>(p.vt + (size_t)bh * 64 * p.npad);
+  const int q_base = blockIdx.x * QB + wq * 32;
+
+  // DMA: wave w moves piece w (rows 8w..8w+7) of K0, V0^T, K1, V1^T of every tile pair
+  unsigned koff, voff;
+  {
+    const int r = 8 * wave + (lane >> 3), lp = lane & 7;
+    const int cc = (lp ^ ((r >> 1) & 7)) << 3;
+    koff = (unsigned)((r * 64 + cc) * 2);
+    voff = (unsigned)((r * p.npad + cc) * 2);
+  }
+  auto issue = [&](int stage, int i) {
+    char* base = smem + stage * STAGE2 + wave * 1024;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      int j = 2 * i + g;
+      j = j < ntiles ? j : ntiles - 1;   // odd tile count: the missing tile aliases the last one (never consumed)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kg + (size_t)j * (KB * 64 * 2) + koff),
+                                       (__attribute__((address_space(3))) void*)(base + g * 2 * TILE), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vg + (size_t)j * (KB * 2) + voff),
+                                       (__attribute__((address_space(3))) void*)(base + g * 2 * TILE + TILE), 16, 0, 0);
+    }
+  };
+
+  const int krow = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+  const int ksw = (krow >> 1) & 7, vsw = (l31 >> 1) & 7;
+  int kx[4], vx[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    kx[e] = krow * 128 + (((e * 2 + hi) ^ ksw) << 4);
+    vx[e] = l31 * 128 + (((2 * e + hi) ^ vsw) << 4);
+  }
+
+  bf16x8 qf[4];
+  {
+    const bf16_t* Qg = p.q + (size_t)bh * p.pitch * 64;
+    int qrow = q_base + l31;
+    qrow = qrow < N ? qrow : N - 1;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(Qg + (size_t)qrow * 64 + kk * 16 + hi * 8);
+  }
+  f32x16 o[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+  float m_run = -INFINITY, l_run = 0.f;
+
+  issue(0, 0);
+  for (int i = 0; i < nsup; ++i) {
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (i + 1 < nsup) issue((i + 1) & 1, i + 1);
+    const int j = 2 * i + grp;
+    if (j < ntiles) {
+      const char* sK = smem + (i & 1) * STAGE2 + grp * 2 * TILE;
+      const char* sV = sK + TILE;
+      f32x16 s[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        bf16x8 a[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) a[t] = *reinterpret_cast<const bf16x8*>(sK + t * 4096 + kx[kk]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t], qf[kk], s[t], 0, 0, 0);
+      }
+      if ((j + 1) * KB > kvlen) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = j * KB + 32 * t + 16 * (r >> 3) + 8 * hi + (r & 7);
+            if (key >= kvlen) s[t][r] = -INFINITY;
+          }
+      }
+      float mx = s[0][0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx * c);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      const bool grew = m_new > m_run;
+      m_run = m_new;
+      const f32x2 c2 = {c, c}, m2 = {m_new, m_new};
+      f32x2 ps = {0.f, 0.f};
+      bf16x8 pb[2][2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          f32x2 e = {s[t][r], s[t][r + 1]};
+          e = e * c2 - m2;
+          f32x2 pv = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+          ps += pv;
+          pb[t][r >> 3][r & 7] = (bf16_t)pv[0];
+          pb[t][r >> 3][(r & 7) + 1] = (bf16_t)pv[1];
+        }
+      l_run = l_run * alpha + (ps[0] + ps[1]);
+      if (__any(grew)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        bf16x8 a[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) a[dt] = *reinterpret_cast<const bf16x8*>(sV + dt * 4096 + vx[e]);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[dt], pb[e >> 1][e & 1], o[dt], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- merge the two key-parity partials: group 1 parks (m, l, O^T) in LDS, group 0 folds it in
+  __syncthreads();
+  float* xch = reinterpret_cast<float*>(smem) + (size_t)wq * 64 * 36 + lane * 36;   // 34 floats used per lane, 36 pitch
+  if (grp == 1) {
+    xch[0] = m_run;
+    xch[1] = l_run;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { xch[2 + r] = o[0][r]; xch[18 + r] = o[1][r]; }
+  }
+  __syncthreads();
+  if (grp == 0) {
+    const float m2 = xch[0], l2 = xch[1];
+    const float m = fmaxf(m_run, m2);
+    const float a1 = __builtin_amdgcn_exp2f(m_run - m), a2 = __builtin_amdgcn_exp2f(m2 - m);   // m2 = -inf (no odd tile) -> a2 = 0
+    l_run = l_run * a1 + l2 * a2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      o[0][r] = o[0][r] * a1 + xch[2 + r] * a2;
+      o[1][r] = o[1][r] * a1 + xch[18 + r] * a2;
+    }
+  }
+  __syncthreads();   // xch fully consumed before the slabs below reuse the LDS
+  if (grp == 0) {
+    // normalise, park O as [32 q][64 d] bf16 (144-B pitch) and write whole 128-B rows
+    const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32, 64));
+    char* slab = smem + wq * (32 * 144);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bf16x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(o[dt][g * 4 + e] * inv);
+        *reinterpret_cast<bf16x4*>(slab + l31 * 144 + (dt * 32 + 8 * g + 4 * hi) * 2) = v;
+      }
+    const int rr = lane >> 3, ch = lane & 7;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int q = q_base + it * 8 + rr;
+      const u32x4 d = *reinterpret_cast<const u32x4*>(slab + (it * 8 + rr) * 144 + ch * 16);
+      if (q < N) store_wt_b128(p.out + ((size_t)b2 * p.pitch + q) * (p.heads * 64) + h * 64 + ch * 8, d);
+    }
+  }
+}
+
 }  // namespace
 
 hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
   // K rows are loaded up to the next multiple of 64 without clamping: the row pitch must cover them
   if (p.npad % 64 != 0 || p.n <= 0 || p.pitch < ((p.n + 63) & ~63) || p.npad < ((p.n + 63) & ~63)) return hipErrorInvalidValue;
   dim3 grid((p.n + QB - 1) / QB, p.b2 * p.heads);
-  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, s, p);
+  // measured (tools/kbench_attn.py): the split-KV kernel wins at every size tried (B=1: 47 vs 53 us; BH=256: 136 vs 154 us)
+  const bool split = p.variant != 1;
+  if (split) hipLaunchKernelGGL(attn_fwd_splitkv_kernel, grid, dim3(512), 0, s, p);
+  else hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, s, p);
   return hipGetLastError();
 }

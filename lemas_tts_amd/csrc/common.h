@@ -102,6 +102,7 @@ struct AttnParams {
   const int* kv_len; // [B] or nullptr
   int b2, batch, heads, n, npad;
   int pitch;         // rows per sample of q / k / out (>= n)
+  int variant;       // 0 = auto, 1 = 4-wave kernel, 2 = split-KV 8-wave kernel
   float scale;
 };
 hipError_t launch_attention(const AttnParams& p, hipStream_t s);

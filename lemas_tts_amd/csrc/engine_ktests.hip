@@ -70,7 +70,11 @@ __global__ void fill_pattern_kernel(bf16_t* p, size_t n, unsigned seed) {
 
 }  // namespace
 
+static int g_attn_variant = 0;
+
 extern "C" {
+
+int lemas_k_set_attention_variant(int32_t v) { g_attn_variant = v; return 0; }
 
 int lemas_k_linear_bf16(const float* A, const float* W, const float* bias, float* out, int32_t M, int32_t N, int32_t K,
                         int32_t act, void* stream) {
@@ -125,7 +129,7 @@ int lemas_k_attention(const float* q, const float* k, const float* v, const int3
   hipLaunchKernelGGL(pad_rows_kernel, dim3(2048), dim3(256), 0, s, k, kb, B * H, N, pitch);
   hipLaunchKernelGGL(transpose_v_kernel, dim3(2048), dim3(256), 0, s, v, vt, B * H, N, npad);
   AttnParams p{};
-  p.q = qb; p.k = kb; p.vt = vt; p.out = ob; p.kv_len = seq_len; p.b2 = B; p.batch = B; p.heads = H; p.n = N; p.npad = npad; p.pitch = pitch;
+  p.q = qb; p.k = kb; p.vt = vt; p.out = ob; p.kv_len = seq_len; p.b2 = B; p.batch = B; p.heads = H; p.n = N; p.npad = npad; p.pitch = pitch; p.variant = g_attn_variant;
   p.scale = 0.125f;
   HIP_TRY(launch_attention(p, s));
   hipLaunchKernelGGL(unpad_widen_kernel, dim3(2048), dim3(256), 0, s, ob, out, B, N, pitch, H * 64);
@@ -230,7 +234,7 @@ extern "C" int lemas_k_bench(const char* what, int32_t M, int32_t N, int32_t K, 
     hipLaunchKernelGGL(fill_pattern_kernel, dim3(1024), dim3(256), 0, s, k, (size_t)bh * pitch * 64, 4u);
     hipLaunchKernelGGL(fill_pattern_kernel, dim3(1024), dim3(256), 0, s, vt, (size_t)bh * 64 * npad, 5u);
     AttnParams p{};
-    p.q = q; p.k = k; p.vt = vt; p.out = o; p.kv_len = nullptr; p.b2 = bh / 16; p.batch = bh / 16; p.heads = 16; p.n = n; p.npad = npad; p.pitch = pitch;
+    p.q = q; p.k = k; p.vt = vt; p.out = o; p.kv_len = nullptr; p.b2 = bh / 16; p.batch = bh / 16; p.heads = 16; p.n = n; p.npad = npad; p.pitch = pitch; p.variant = variant;
     p.scale = 0.125f;
     rc = time_it([&]() { return launch_attention(p, s); });
   } else {

@@ -60,10 +60,12 @@ def test_linear_f32(M, N, K, act):
     assert err < 2e-5 * math.sqrt(K / 16), err          # exact-fp32 MFMA == fmaf chain
 
 
+@pytest.mark.parametrize("variant", [1, 2])
 @pytest.mark.parametrize("B,H,N,lens", [(1, 2, 64, None), (2, 16, 200, None), (2, 4, 333, [333, 210]), (1, 16, 1875, None),
-                                         (3, 2, 130, [1, 64, 130])])
-def test_attention(B, H, N, lens):
+                                         (3, 2, 130, [1, 64, 130]), (1, 1, 65, None), (2, 2, 192, [129, 192])])
+def test_attention(B, H, N, lens, variant):
     L, lib = _lib()
+    lib.lemas_k_set_attention_variant(variant)      # 1 = four-wave kernel, 2 = split-KV eight-wave kernel
     g = torch.Generator().manual_seed(N + H)
     q, k, v = (torch.randn(B, H, N, 64, generator=g) for _ in range(3))
     k[0, 0, N // 2] *= 4.0        # a spiky key: exercises the online-softmax rescale
@@ -79,6 +81,7 @@ def test_attention(B, H, N, lens):
     qd, kd, vd = _dev(q), _dev(k), _dev(v)
     L.check(lib.lemas_k_attention(qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), lens_d.data_ptr() if lens_d is not None else None,
                                   out.data_ptr(), B, H, N, None))
+    lib.lemas_k_set_attention_variant(0)
     err = (out.cpu() - ref).abs().max().item()
     assert err < 2e-2, err          # P and O rounded to bf16 (8 mantissa bits) on |v| ~ 1..4
 
