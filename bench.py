@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--depth", type=int, default=22, help="DiT depth (22 = the shipped model; smaller only for debugging)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dual", type=int, default=1, help="1 = CFG branches as two concurrent lanes (default), 0 = one stream")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -140,6 +141,7 @@ def main():
         sd = broadcast_state_dict(sd, arch, VOCAB, device, dist)
         vsd = broadcast_state_dict(vsd, None, None, device, dist, vocos=True)
     model = CFM(arch, VOCAB, sd, device=device)
+    model.engine.set_option("dual", a.dual)
     model.engine.set_option("table_cache", 0)      # hoists are redone for every utterance: nothing cached across steps
     vocoder = VocosEngine(vsd, device=device)
     cond, text, y0 = build_inputs(rank, device)

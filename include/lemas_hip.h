@@ -80,7 +80,8 @@ void lemas_dit_destroy(lemas_dit* m);
 int lemas_dit_load_weight(lemas_dit* m, const char* name, const float* host_data, const int64_t* shape, int32_t ndim);
 int lemas_dit_finalize(lemas_dit* m);
 /* options: "graph" (1 = replay one captured hipGraph per ODE step, default 1), "profile" (1 = per-kernel events),
- * "table_cache" (1 = keep the time/AdaLN tables while the t-grid is unchanged, default 1) */
+ * "table_cache" (1 = keep the time/AdaLN tables while the t-grid is unchanged, default 1),
+ * "dual" (1 = run the two CFG branches as concurrent lanes on two streams / graph branches, default 1) */
 int lemas_dit_set_option(lemas_dit* m, const char* key, int64_t value);
 /* full sampler: hoists + NFE Euler steps (+ final where) */
 int lemas_dit_sample(lemas_dit* m, const lemas_sample_args* a, void* stream);

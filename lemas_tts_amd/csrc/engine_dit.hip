@@ -41,6 +41,9 @@ struct lemas_dit {
   bool use_graph = true;
   bool profile = false;
   bool table_cache = true;  // reuse the AdaLN/time tables while the t-grid is unchanged
+  bool dual = true;         // run the two CFG branches as concurrent lanes (second stream / parallel graph branch)
+  hipStream_t s2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 
   std::vector<BlockW> blocks;
   DevBuf wproj_out, bproj_out;  // padded to 128 rows
@@ -69,6 +72,9 @@ struct lemas_dit {
 
   ~lemas_dit() {
     for (auto& g : graphs) (void)hipGraphExecDestroy(g.second);
+    if (s2) (void)hipStreamDestroy(s2);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
     for (auto& r : prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (DevBuf* b : {&wproj_out, &bproj_out, &wconv[0], &wconv[1], &d_step, &d_dt, &d_cfg, &d_t, &d_tab, &d_rope_cos,
                       &d_rope_sin, &d_len, &d_sin, &d_h1, &d_temb, &d_st, &d_cond_eff, &d_step_cond, &d_pm, &d_pt, &d_te,
@@ -205,6 +211,11 @@ int lemas_dit::finalize() {
                                   wconv[j].as<bf16_t>(), d, cg, cfg.conv_pos_kernel, s));
   }
   RC_TRY(d_step.ensure(64));
+  if (!s2) {
+    HIP_TRY(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+  }
   HIP_TRY(hipStreamSynchronize(s));
   tab_stride = cfg.depth * 6 * d + 2 * d;
   finalized = true;
@@ -374,7 +385,7 @@ int lemas_dit::prepare(const lemas_sample_args* a, hipStream_t s) {
 }
 
 int lemas_dit::enqueue_forward(hipStream_t s) {
-  const int d = cfg.dim, md = cfg.mel_dim, rows = BB * pitch, in = inner(), ffd = cfg.ff_mult * d;
+  const int d = cfg.dim, md = cfg.mel_dim, in = inner(), ffd = cfg.ff_mult * d;
   const int* step = d_step.as<int>();
   const float* tab = d_tab.as<float>();
   // input projection, x part (K = mel_dim) in fp32, broadcast onto both CFG branches  (dit.py:97)
@@ -392,75 +403,113 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     }
     RC_TRY(pend(s));
   }
-  // conv position embedding + residual (dit.py:98)
-  {
-    RC_TRY(pbegin(PC_CONVPOS, s));
-    ConvPosParams c{};
-    c.b2 = BB; c.n = N; c.pitch = pitch; c.channels = d; c.groups = cfg.conv_pos_groups; c.taps = cfg.conv_pos_kernel;
-    c.in_f32 = d_xres.as<float>(); c.w = wconv[0].as<bf16_t>(); c.bias = ws.ptr(T("input_embed.conv_pos_embed.conv1d.0.bias"));
-    c.out_bf16 = d_cmid.as<bf16_t>();
-    HIP_TRY(launch_convpos(c, s));
-    c.in_f32 = nullptr; c.in_bf16 = d_cmid.as<bf16_t>(); c.w = wconv[1].as<bf16_t>();
-    c.bias = ws.ptr(T("input_embed.conv_pos_embed.conv1d.2.bias")); c.out_bf16 = nullptr;
-    c.out_f32 = d_xres.as<float>(); c.residual = d_xres.as<float>();
-    HIP_TRY(launch_convpos(c, s));
-    RC_TRY(pend(s));
+  // From here on the two CFG branches (conditional rows, unconditional rows) are independent chains.  With "dual" on
+  // they run as two concurrent lanes (second HIP stream / parallel hipGraph branch): each GEMM then has one round of
+  // ~120 tiles, and one lane's epilogue / prologue / launch gap overlaps the other lane's K loop.
+  const int lanes = (dual && use_cfg && !profile && s != nullptr) ? 2 : 1;
+  hipStream_t st[2] = {s, lanes == 2 ? s2 : s};
+  if (lanes == 2) {
+    HIP_TRY(hipEventRecord(ev_fork, s));
+    HIP_TRY(hipStreamWaitEvent(s2, ev_fork, 0));
   }
-  GemmParams g{};
-  g.M = rows; g.tab = tab; g.tab_stride = tab_stride; g.step_idx = step; g.seq_pitch = pitch; g.seq_valid = N; g.batch = B;
-  g.heads = cfg.heads; g.npad = npad; g.rope_cos = d_rope_cos.as<float>(); g.rope_sin = d_rope_sin.as<float>();
-  g.q = d_q.as<bf16_t>(); g.k = d_k.as<bf16_t>(); g.vt = d_vt.as<bf16_t>();
-  AttnParams at{};
-  at.q = d_q.as<bf16_t>(); at.k = d_k.as<bf16_t>(); at.vt = d_vt.as<bf16_t>(); at.out = d_abf.as<bf16_t>();
-  at.kv_len = has_len ? d_len.as<int>() : nullptr; at.b2 = BB; at.batch = B; at.heads = cfg.heads; at.n = N; at.npad = npad; at.pitch = pitch;
-  at.scale = 1.0f / sqrtf((float)cfg.dim_head);
-  for (int l = 0; l < cfg.depth; ++l) {
+  const int bh = BB / lanes;                 // samples (branch-rows) per lane
+  const int rows = bh * pitch;
+
+  auto convpos = [&](int ln) -> int {        // conv position embedding + residual (dit.py:98)
+    hipStream_t q = st[ln];
+    const size_t r0 = (size_t)ln * rows;
+    RC_TRY(pbegin(PC_CONVPOS, q));
+    ConvPosParams c{};
+    c.b2 = bh; c.n = N; c.pitch = pitch; c.channels = d; c.groups = cfg.conv_pos_groups; c.taps = cfg.conv_pos_kernel;
+    c.in_f32 = d_xres.as<float>() + r0 * d; c.w = wconv[0].as<bf16_t>(); c.bias = ws.ptr(T("input_embed.conv_pos_embed.conv1d.0.bias"));
+    c.out_bf16 = d_cmid.as<bf16_t>() + r0 * d;
+    HIP_TRY(launch_convpos(c, q));
+    c.in_f32 = nullptr; c.in_bf16 = d_cmid.as<bf16_t>() + r0 * d; c.w = wconv[1].as<bf16_t>();
+    c.bias = ws.ptr(T("input_embed.conv_pos_embed.conv1d.2.bias")); c.out_bf16 = nullptr;
+    c.out_f32 = d_xres.as<float>() + r0 * d; c.residual = d_xres.as<float>() + r0 * d;
+    HIP_TRY(launch_convpos(c, q));
+    RC_TRY(pend(q));
+    return 0;
+  };
+
+  auto block = [&](int l, int ln) -> int {   // one DiTBlock (modules.py:627-641) on one lane's rows
+    hipStream_t q = st[ln];
+    const size_t r0 = (size_t)ln * rows;
+    float* xres = d_xres.as<float>() + r0 * d;
+    bf16_t* hbf = d_hbf.as<bf16_t>() + r0 * d;
+    bf16_t* abf = d_abf.as<bf16_t>() + r0 * in;
+    bf16_t* ffb = d_ff.as<bf16_t>() + r0 * ffd;
+    GemmParams g{};
+    g.M = rows; g.tab = tab; g.tab_stride = tab_stride; g.step_idx = step; g.seq_pitch = pitch; g.seq_valid = N; g.batch = B;
+    g.heads = cfg.heads; g.npad = npad; g.rope_cos = d_rope_cos.as<float>(); g.rope_sin = d_rope_sin.as<float>();
+    g.q = d_q.as<bf16_t>() + r0 * in; g.k = d_k.as<bf16_t>() + r0 * in; g.vt = d_vt.as<bf16_t>() + r0 * in;
+    AttnParams at{};
+    at.q = g.q; at.k = g.k; at.vt = g.vt; at.out = abf;
+    at.kv_len = has_len ? d_len.as<int>() : nullptr; at.b2 = bh; at.batch = B; at.heads = cfg.heads; at.n = N; at.npad = npad; at.pitch = pitch;
+    at.scale = 1.0f / sqrtf((float)cfg.dim_head);
     const BlockW& w = blocks[l];
     const int base = l * 6 * d;  // [shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp] (modules.py:312)
-    RC_TRY(pbegin(PC_LN, s));
-    HIP_TRY(launch_ln_mod(d_xres.as<float>(), d_hbf.as<bf16_t>(), rows, d, tab, tab_stride, base + d, base, step, s));
-    RC_TRY(pend(s));
-    RC_TRY(pbegin(PC_GEMM_QK, s));
-    g.A = d_hbf.as<bf16_t>(); g.W = w.wqkv.as<bf16_t>(); g.bias = w.bqkv.as<float>(); g.N = 2 * in; g.K = d; g.n_valid = 2 * in;
+    RC_TRY(pbegin(PC_LN, q));
+    HIP_TRY(launch_ln_mod(xres, hbf, rows, d, tab, tab_stride, base + d, base, step, q));
+    RC_TRY(pend(q));
+    RC_TRY(pbegin(PC_GEMM_QK, q));
+    g.A = hbf; g.W = w.wqkv.as<bf16_t>(); g.bias = w.bqkv.as<float>(); g.N = 2 * in; g.K = d; g.n_valid = 2 * in;
     g.kv_len = nullptr;
-    HIP_TRY(launch_gemm_bf16(EPI_QK_ROPE, g, s));
-    RC_TRY(pend(s));
-    RC_TRY(pbegin(PC_GEMM_V, s));
+    HIP_TRY(launch_gemm_bf16(EPI_QK_ROPE, g, q));
+    RC_TRY(pend(q));
+    RC_TRY(pbegin(PC_GEMM_V, q));
     g.W = w.wqkv.as<bf16_t>() + (size_t)2 * in * d; g.bias = w.bqkv.as<float>() + 2 * in; g.N = in; g.n_valid = in;
-    HIP_TRY(launch_gemm_bf16(EPI_V_T, g, s));
-    RC_TRY(pend(s));
-    RC_TRY(pbegin(PC_ATTN, s));
-    HIP_TRY(launch_attention(at, s));
-    RC_TRY(pend(s));
-    RC_TRY(pbegin(PC_GEMM_OUT, s));
-    g.A = d_abf.as<bf16_t>(); g.W = w.wo.as<bf16_t>(); g.bias = w.bo; g.N = d; g.K = in; g.n_valid = d;
-    g.out_f32 = d_xres.as<float>(); g.ldc = d; g.gate_off = base + 2 * d; g.kv_len = has_len ? d_len.as<int>() : nullptr;
-    HIP_TRY(launch_gemm_bf16(EPI_GATE_RES, g, s));
-    RC_TRY(pend(s));
-    RC_TRY(pbegin(PC_LN, s));
-    HIP_TRY(launch_ln_mod(d_xres.as<float>(), d_hbf.as<bf16_t>(), rows, d, tab, tab_stride, base + 4 * d, base + 3 * d, step, s));
-    RC_TRY(pend(s));
-    RC_TRY(pbegin(PC_GEMM_FF1, s));
-    g.A = d_hbf.as<bf16_t>(); g.W = w.w1.as<bf16_t>(); g.bias = w.b1; g.N = ffd; g.K = d; g.n_valid = ffd;
-    g.out_bf16 = d_ff.as<bf16_t>(); g.ldc = ffd; g.kv_len = nullptr;
-    HIP_TRY(launch_gemm_bf16(EPI_BIAS_GELU_BF16, g, s));
-    RC_TRY(pend(s));
-    RC_TRY(pbegin(PC_GEMM_FF2, s));
-    g.A = d_ff.as<bf16_t>(); g.W = w.w2.as<bf16_t>(); g.bias = w.b2; g.N = d; g.K = ffd; g.n_valid = d;
-    g.out_f32 = d_xres.as<float>(); g.ldc = d; g.gate_off = base + 5 * d;
-    HIP_TRY(launch_gemm_bf16(EPI_GATE_RES, g, s));
-    RC_TRY(pend(s));
+    HIP_TRY(launch_gemm_bf16(EPI_V_T, g, q));
+    RC_TRY(pend(q));
+    RC_TRY(pbegin(PC_ATTN, q));
+    HIP_TRY(launch_attention(at, q));
+    RC_TRY(pend(q));
+    RC_TRY(pbegin(PC_GEMM_OUT, q));
+    g.A = abf; g.W = w.wo.as<bf16_t>(); g.bias = w.bo; g.N = d; g.K = in; g.n_valid = d;
+    g.out_f32 = xres; g.ldc = d; g.gate_off = base + 2 * d; g.kv_len = has_len ? d_len.as<int>() : nullptr;
+    HIP_TRY(launch_gemm_bf16(EPI_GATE_RES, g, q));
+    RC_TRY(pend(q));
+    RC_TRY(pbegin(PC_LN, q));
+    HIP_TRY(launch_ln_mod(xres, hbf, rows, d, tab, tab_stride, base + 4 * d, base + 3 * d, step, q));
+    RC_TRY(pend(q));
+    RC_TRY(pbegin(PC_GEMM_FF1, q));
+    g.A = hbf; g.W = w.w1.as<bf16_t>(); g.bias = w.b1; g.N = ffd; g.K = d; g.n_valid = ffd;
+    g.out_bf16 = ffb; g.ldc = ffd; g.kv_len = nullptr;
+    HIP_TRY(launch_gemm_bf16(EPI_BIAS_GELU_BF16, g, q));
+    RC_TRY(pend(q));
+    RC_TRY(pbegin(PC_GEMM_FF2, q));
+    g.A = ffb; g.W = w.w2.as<bf16_t>(); g.bias = w.b2; g.N = d; g.K = ffd; g.n_valid = d;
+    g.out_f32 = xres; g.ldc = d; g.gate_off = base + 5 * d;
+    HIP_TRY(launch_gemm_bf16(EPI_GATE_RES, g, q));
+    RC_TRY(pend(q));
+    return 0;
+  };
+
+  auto head = [&](int ln) -> int {           // final AdaLN (order scale, shift: modules.py:333) + proj_out
+    hipStream_t q = st[ln];
+    const size_t r0 = (size_t)ln * rows;
+    const int fb = cfg.depth * 6 * d;
+    RC_TRY(pbegin(PC_LN, q));
+    HIP_TRY(launch_ln_mod(d_xres.as<float>() + r0 * d, d_hbf.as<bf16_t>() + r0 * d, rows, d, tab, tab_stride, fb, fb + d, step, q));
+    RC_TRY(pend(q));
+    RC_TRY(pbegin(PC_GEMM_FINAL, q));
+    GemmParams g{};
+    g.M = rows; g.seq_pitch = pitch; g.seq_valid = N; g.batch = B; g.heads = cfg.heads; g.npad = npad;
+    g.A = d_hbf.as<bf16_t>() + r0 * d; g.W = wproj_out.as<bf16_t>(); g.bias = bproj_out.as<float>(); g.N = 128; g.K = d; g.n_valid = md;
+    g.out_f32 = d_pred.as<float>() + r0 * md; g.ldc = md;
+    HIP_TRY(launch_gemm_bf16(EPI_BIAS_F32, g, q));
+    RC_TRY(pend(q));
+    return 0;
+  };
+
+  for (int ln = 0; ln < lanes; ++ln) RC_TRY(convpos(ln));
+  for (int l = 0; l < cfg.depth; ++l)
+    for (int ln = 0; ln < lanes; ++ln) RC_TRY(block(l, ln));
+  for (int ln = 0; ln < lanes; ++ln) RC_TRY(head(ln));
+  if (lanes == 2) {
+    HIP_TRY(hipEventRecord(ev_join, s2));
+    HIP_TRY(hipStreamWaitEvent(s, ev_join, 0));
   }
-  // final AdaLN (order scale, shift: modules.py:333) + proj_out
-  const int fb = cfg.depth * 6 * d;
-  RC_TRY(pbegin(PC_LN, s));
-  HIP_TRY(launch_ln_mod(d_xres.as<float>(), d_hbf.as<bf16_t>(), rows, d, tab, tab_stride, fb, fb + d, step, s));
-  RC_TRY(pend(s));
-  RC_TRY(pbegin(PC_GEMM_FINAL, s));
-  g.A = d_hbf.as<bf16_t>(); g.W = wproj_out.as<bf16_t>(); g.bias = bproj_out.as<float>(); g.N = 128; g.K = d; g.n_valid = md;
-  g.out_f32 = d_pred.as<float>(); g.ldc = md; g.kv_len = nullptr;
-  HIP_TRY(launch_gemm_bf16(EPI_BIAS_F32, g, s));
-  RC_TRY(pend(s));
   return 0;
 }
 
@@ -495,7 +544,7 @@ int lemas_dit::solve(const lemas_sample_args* a, hipStream_t s) {
       graph_generation = DevBuf::generation;
     }
     char key[96];
-    snprintf(key, sizeof key, "B%d_N%d_cfg%d_len%d", B, N, (int)use_cfg, (int)has_len);
+    snprintf(key, sizeof key, "B%d_N%d_cfg%d_len%d_dual%d", B, N, (int)use_cfg, (int)has_len, (int)dual);
     auto it = graphs.find(key);
     if (it == graphs.end()) {
       hipGraph_t graph = nullptr;
@@ -555,6 +604,12 @@ int lemas_dit_set_option(lemas_dit* m, const char* key, int64_t value) {
   if (!m || !key) return LEMAS_E_ARG;
   if (!strcmp(key, "graph")) { m->use_graph = value != 0; return 0; }
   if (!strcmp(key, "table_cache")) { m->table_cache = value != 0; return 0; }
+  if (!strcmp(key, "dual")) {
+    m->dual = value != 0;
+    for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.second);
+    m->graphs.clear();
+    return 0;
+  }
   if (!strcmp(key, "profile")) {
     m->profile = value != 0;
     for (auto& r : m->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }

@@ -101,6 +101,22 @@ def test_graph_replay_is_bit_identical_to_eager(golden_dir, name):
     np.testing.assert_array_equal(graph, graph2)
 
 
+@pytest.mark.parametrize("name", ["mini_plain", "mini_batch"])
+def test_dual_lane_is_bit_identical_to_single_lane(golden_dir, name):
+    """The two CFG branches as concurrent lanes (two streams / graph branches) must not change a single bit."""
+    fx, arch, sd = _load(golden_dir, name)
+    m = _model(arch, int(fx["vocab"]), int(fx["wseed"]), bool(fx["prosody"]), sd)
+    outs = {}
+    for dual in (0, 1):
+        m.engine.set_option("dual", dual)
+        for graph in (False, True):
+            outs[(dual, graph)] = _run_case(fx, arch, sd, graph=graph, traj=False)[0]
+    m.engine.set_option("dual", 1)
+    ref = outs[(0, False)]
+    for k, v in outs.items():
+        np.testing.assert_array_equal(v, ref, err_msg=str(k))
+
+
 def test_dit_forward_vs_oracle(golden_dir):
     """One DiT forward (both CFG branches) against the fp32 oracle: localises step-loop errors."""
     from oracle import lemas_oracle as O
