@@ -27,9 +27,14 @@
 // (computed, never stored where it matters).
 #include "common.h"
 
+#ifndef LEMAS_GEMM_PRIO
+#define LEMAS_GEMM_PRIO 0
+#endif
+
 namespace {
 
 constexpr int BK = 64;
+constexpr bool PRIO = LEMAS_GEMM_PRIO;
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
@@ -335,12 +340,14 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, int m
         for (int x = (PW * kk) / 4; x < (PW * (kk + 1)) / 4; ++x) issue_piece(ns, nt, x);
       }
       __builtin_amdgcn_sched_barrier(0);
+      if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < TJ; ++j)
           acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[kk & 1][j], af[kk & 1][i], acc[i][j], 0, 0, 0)
                            : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
+      if (PRIO) __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
     }
     stage = stage + 1 == NSTAGE ? 0 : stage + 1;
