@@ -13,6 +13,7 @@
  *   lemas_vocos_create/load_weight/finalize <- lemas_tts/infer/utils_infer.py:120-143 load_vocoder
  *   lemas_vocos_decode                      <- vocoder.decode call, lemas_tts/infer/utils_infer.py:549 and
  *                                              lemas_tts/scripts/speech_edit_multilingual.py:198
+ *   lemas_mel_create/forward                <- lemas_tts/model/modules.py:104-143 MelSpec.forward (cfm.py:232-236)
  *   lemas_k_*                               <- single-kernel entry points used by the parity tests
  *
  * Conventions: plain pointers and sizes only.  "device" pointers are HIP device addresses on the current device
@@ -38,6 +39,7 @@ extern "C" {
 
 typedef struct lemas_dit lemas_dit;
 typedef struct lemas_vocos lemas_vocos;
+typedef struct lemas_mel lemas_mel;
 
 /* model.arch of lemas_tts/configs/multilingual_grl.yaml:48-58 (+ derived sizes) */
 typedef struct {
@@ -104,6 +106,13 @@ int lemas_vocos_finalize(lemas_vocos* v);
 /* mel device [B, C, L] fp32 -> wav device [B, hop*(L-1)] fp32; `gain` multiplies the waveform (rms rescale,
  * utils_infer.py:552-553; pass 1.0 for none) */
 int lemas_vocos_decode(lemas_vocos* v, const float* mel, int32_t batch, int32_t frames, float gain, float* wav, void* stream);
+
+/* ---- reference wav -> log-mel front edge (lemas_tts/model/modules.py:75-143 MelSpec, call site cfm.py:232-236) ----
+ * wav device [B, samples] fp32 at `sample_rate` -> mel device [B, samples/hop + 1, n_mels] fp32 (already in the
+ * [b, frames, channels] layout CFM.sample uses after its permute, cfm.py:235) */
+int lemas_mel_create(int32_t n_fft, int32_t hop_length, int32_t n_mels, int32_t sample_rate, lemas_mel** out);
+void lemas_mel_destroy(lemas_mel* m);
+int lemas_mel_forward(lemas_mel* m, const float* wav, int32_t batch, int32_t samples, float* mel, void* stream);
 
 /* ---- single-kernel entry points (parity tests) ---- all pointers device fp32 unless noted */
 /* out[M,N] = act(A[M,K] . W[N,K]^T + bias) through the bf16 MFMA GEMM (inputs rounded to bf16); act: 0 none, 1 gelu-tanh */

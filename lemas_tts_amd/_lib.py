@@ -63,6 +63,9 @@ def lib():
         "lemas_vocos_load_weight": (C.c_int, [vp, C.c_char_p, vp, C.POINTER(i64), i32]),
         "lemas_vocos_finalize": (C.c_int, [vp]),
         "lemas_vocos_decode": (C.c_int, [vp, vp, i32, i32, f32, vp, vp]),
+        "lemas_mel_create": (C.c_int, [i32, i32, i32, i32, C.POINTER(vp)]),
+        "lemas_mel_destroy": (None, [vp]),
+        "lemas_mel_forward": (C.c_int, [vp, vp, i32, i32, vp, vp]),
         "lemas_k_linear_bf16": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
         "lemas_k_linear_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
         "lemas_k_attention": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
@@ -83,7 +86,8 @@ EXPORTED = [
     "lemas_last_error", "lemas_version", "lemas_dit_create", "lemas_dit_destroy", "lemas_dit_load_weight",
     "lemas_dit_finalize", "lemas_dit_set_option", "lemas_dit_sample", "lemas_dit_prepare", "lemas_dit_solve",
     "lemas_dit_forward", "lemas_dit_profile_read", "lemas_vocos_create", "lemas_vocos_destroy",
-    "lemas_vocos_load_weight", "lemas_vocos_finalize", "lemas_vocos_decode", "lemas_k_linear_bf16",
+    "lemas_vocos_load_weight", "lemas_vocos_finalize", "lemas_vocos_decode", "lemas_mel_create", "lemas_mel_destroy",
+    "lemas_mel_forward", "lemas_k_linear_bf16",
     "lemas_k_linear_f32", "lemas_k_attention", "lemas_k_ln_mod", "lemas_k_convpos", "lemas_k_bench", "lemas_k_set_attention_variant",
 ]
 

@@ -318,3 +318,71 @@ hipError_t launch_overlap_add(const float* frames, const float* window, int B, i
   LAUNCH(overlap_add_kernel, (size_t)B * hop * (L - 1), frames, window, B, L, nfft, hop, wav)
 }
 hipError_t launch_scale(float* x, float sc, size_t n, hipStream_t s) { LAUNCH(scale_kernel, n, x, sc, n) }
+
+// ================================================================================================================
+// wav -> log-mel front edge ("next" row f-1): lemas_tts/model/modules.py:75-101 get_vocos_mel_spectrogram
+// (torchaudio MelSpectrogram: reflect pad n_fft/2, periodic Hann, |STFT| (power 1), HTK mel filterbank, then
+// clamp(1e-5).log()).  The DFT is a GEMM against a precomputed basis, like the vocoder's inverse.
+namespace {
+
+// frames[b*F + f][n] = window[n] * reflect(wav[b])[f*hop + n - nfft/2]
+__global__ void stft_frames_kernel(const float* __restrict__ wav, const float* __restrict__ window, int B, int nw, int F,
+                                   int nfft, int hop, float* __restrict__ frames) {
+  const size_t total = (size_t)B * F * nfft;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i % nfft);
+    const size_t row = i / nfft;
+    const int f = (int)(row % F), b = (int)(row / F);
+    int t = f * hop + n - nfft / 2;
+    if (t < 0) t = -t;                         // reflect (no edge repeat), as torch.stft(center=True, pad_mode="reflect")
+    if (t >= nw) t = 2 * (nw - 1) - t;
+    frames[i] = window[n] * wav[(size_t)b * nw + t];
+  }
+}
+// forward real-DFT basis rows: k < nb -> cos(2 pi k n / N), nb <= k < 2 nb -> -sin(2 pi (k-nb) n / N), rest 0
+__global__ void rdft_basis_kernel(int nfft, int rows, float* __restrict__ basis) {
+  const int nb = nfft / 2 + 1;
+  const size_t total = (size_t)rows * nfft;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i % nfft), r = (int)(i / nfft);
+    float v = 0.f;
+    if (r < 2 * nb) {
+      const int k = r < nb ? r : r - nb;
+      const float x = 2.0f * (float)(int)(((long long)k * n) % nfft) / (float)nfft;
+      v = r < nb ? cospif(x) : -sinpif(x);
+    }
+    basis[i] = v;
+  }
+}
+// mag[row][k] = sqrt(re^2 + im^2), padded to ldm columns with zeros
+__global__ void magnitude_kernel(const float* __restrict__ spec, int rows, int nb, int lds_, int ldm, float* __restrict__ mag) {
+  const size_t total = (size_t)rows * ldm;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int k = (int)(i % ldm);
+    const size_t r = i / ldm;
+    float v = 0.f;
+    if (k < nb) {
+      const float re = spec[r * lds_ + k], im = spec[r * lds_ + nb + k];
+      v = sqrtf(re * re + im * im);
+    }
+    mag[i] = v;
+  }
+}
+__global__ void log_clamp_kernel(float* __restrict__ x, size_t n, float lo) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    x[i] = logf(fmaxf(x[i], lo));
+}
+
+}  // namespace
+
+hipError_t launch_stft_frames(const float* wav, const float* window, int B, int nw, int F, int nfft, int hop, float* frames,
+                              hipStream_t s) {
+  LAUNCH(stft_frames_kernel, (size_t)B * F * nfft, wav, window, B, nw, F, nfft, hop, frames)
+}
+hipError_t launch_rdft_basis(int nfft, int rows, float* basis, hipStream_t s) {
+  LAUNCH(rdft_basis_kernel, (size_t)rows * nfft, nfft, rows, basis)
+}
+hipError_t launch_magnitude(const float* spec, int rows, int nb, int lds_, int ldm, float* mag, hipStream_t s) {
+  LAUNCH(magnitude_kernel, (size_t)rows * ldm, spec, rows, nb, lds_, ldm, mag)
+}
+hipError_t launch_log_clamp(float* x, size_t n, float lo, hipStream_t s) { LAUNCH(log_clamp_kernel, n, x, n, lo) }

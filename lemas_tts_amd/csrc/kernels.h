@@ -25,3 +25,9 @@ hipError_t launch_spec(const float* head, int rows, int nb, int ldh, int lds_, f
 hipError_t launch_dft_basis(const float* window, int nfft, int ld, float* basis, hipStream_t s);
 hipError_t launch_overlap_add(const float* frames, const float* window, int B, int L, int nfft, int hop, float* wav, hipStream_t s);
 hipError_t launch_scale(float* x, float sc, size_t n, hipStream_t s);
+
+// wav -> log-mel front edge
+hipError_t launch_stft_frames(const float* wav, const float* window, int B, int nw, int F, int nfft, int hop, float* frames, hipStream_t s);
+hipError_t launch_rdft_basis(int nfft, int rows, float* basis, hipStream_t s);
+hipError_t launch_magnitude(const float* spec, int rows, int nb, int lds_, int ldm, float* mag, hipStream_t s);
+hipError_t launch_log_clamp(float* x, size_t n, float lo, hipStream_t s);

@@ -228,3 +228,37 @@ class VocosEngine(_Streamed):
                        "lemas_vocos_decode")
             self._exit()
         return wav
+
+
+class MelEngine(_Streamed):
+    """``MelSpec.forward`` replacement (lemas_tts/model/modules.py:130-143): wav [B, nw] -> log-mel."""
+
+    def __init__(self, device="cuda:0", n_fft=1024, hop_length=256, n_mel_channels=100, target_sample_rate=24000):
+        super().__init__(device)
+        self.n_fft, self.hop_length, self.n_mel_channels, self.target_sample_rate = n_fft, hop_length, n_mel_channels, target_sample_rate
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().lemas_mel_create(n_fft, hop_length, n_mel_channels, target_sample_rate, C.byref(self._h)),
+                       "lemas_mel_create")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().lemas_mel_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def frames_first(self, wav: torch.Tensor) -> torch.Tensor:
+        """wav [B, nw] -> [B, nw // hop + 1, n_mels] (the layout CFM.sample works in)."""
+        with torch.cuda.device(self.device):
+            wav = wav.to(self.device, torch.float32).contiguous()
+            B, nw = wav.shape
+            mel = torch.empty((B, nw // self.hop_length + 1, self.n_mel_channels), device=self.device, dtype=torch.float32)
+            s = self._enter(wav, mel)
+            _lib.check(_lib.lib().lemas_mel_forward(self._h, wav.data_ptr(), B, nw, mel.data_ptr(), s), "lemas_mel_forward")
+            self._exit()
+        return mel

@@ -8,7 +8,7 @@ Differences that are stated rather than hidden:
 * compute dtype: the reference picks fp16 on "cuda" (:205-213); this build uses bf16 MFMA operands with fp32
   accumulation / residual stream / ODE state (BASELINE.json), whatever ``dtype`` says;
 * reference audio arrives as a ``(tensor[channels, samples], sample_rate)`` pair (what ``torchaudio.load`` returns
-  at :422) or, until the wav->mel front edge ("next" row, SURVEY.md 8f-1) lands, as a ready mel ``[F, 100]``;
+  at :422; 24 kHz only, resampling is not built) or as a ready mel ``[F, 100]``;
 * ``ref_text`` / ``gen_text`` are phone-token lists (the text frontend stays host Python and is out of scope);
   the ``str`` branch (:509-515) needs ``convert_char_to_pinyin`` and raises ``NotImplementedError``.
 """
@@ -199,10 +199,7 @@ def infer_batch_process(ref_audio, ref_text, gen_text_batches, model_obj, vocode
         if rms < target_rms:
             audio = audio * target_rms / rms                                    # :492-493
         if sr != target_sample_rate:
-            raise NotImplementedError("resampling the prompt belongs to the wav->mel front edge ('next' row)")
-        if model_obj.mel_spec is None:
-            raise NotImplementedError("raw reference audio needs the wav->mel front edge ('next' row, SURVEY.md 8f-1); "
-                                      "pass the reference mel [F,100] instead")
+            raise NotImplementedError("resampling the prompt (torchaudio Resample, :494-496) is not built; pass 24 kHz audio")
         cond = audio
         ref_audio_len = audio.shape[-1] // hop_length                           # :520
     else:

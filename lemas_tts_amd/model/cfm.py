@@ -67,7 +67,10 @@ class CFM:
         self.num_channels = num_channels
         self.vocab_char_map = vocab_char_map
         self.use_prosody_encoder = use_prosody_encoder
-        self.mel_spec = mel_spec_module          # wav -> mel front edge: a "next" row
+        if mel_spec_module is None:              # wav -> mel front edge, cfm.py:113
+            from .modules import MelSpec
+            mel_spec_module = MelSpec(n_mel_channels=num_channels, device=device)
+        self.mel_spec = mel_spec_module
         self.prosody_encoder = None              # Pretssel ECAPA encoder: a "next" row
         self.odeint_kwargs = odeint_kwargs
         self.engine = DiTEngine(arch, vocab_size, state_dict, device=device, prosody=use_prosody_encoder)
@@ -96,9 +99,7 @@ class CFM:
             raise NotImplementedError("ref_ratio < 1 (random clip-and-shuffle of the prompt) is outside the hot path")
         dev = self.device
         if cond.ndim == 2:
-            if self.mel_spec is None:
-                raise NotImplementedError("raw-audio cond needs the wav->mel front edge ('next' row); pass a mel [B,F,100]")
-            cond = self.mel_spec(cond).permute(0, 2, 1)
+            cond = self.mel_spec(cond).permute(0, 2, 1)              # cfm.py:232-236
         assert cond.shape[-1] == self.num_channels
         cond = cond.to(dev, torch.float32)
         batch, cond_seq_len = cond.shape[:2]

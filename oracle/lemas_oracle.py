@@ -306,6 +306,30 @@ class OracleCFM:
 
 
 # ----------------------------------------------------------------------------------------------
+# wav -> log-mel front edge (model/modules.py:75-101; torchaudio MelSpectrogram is third-party: PARITY UNPINNED)
+# ----------------------------------------------------------------------------------------------
+def htk_filterbank(n_freqs: int = 513, n_mels: int = 100, sample_rate: int = 24000) -> Tensor:
+    """torchaudio.functional.melscale_fbanks(n_freqs, 0, sr/2, n_mels, sr, norm=None, mel_scale='htk') -> [n_freqs, n_mels]."""
+    all_freqs = torch.linspace(0, sample_rate // 2, n_freqs, dtype=torch.float64)
+    m_max = 2595.0 * math.log10(1.0 + (sample_rate / 2) / 700.0)
+    m_pts = torch.linspace(0.0, m_max, n_mels + 2, dtype=torch.float64)
+    f_pts = 700.0 * (10.0 ** (m_pts / 2595.0) - 1.0)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts[None, :] - all_freqs[:, None]
+    down = -slopes[:, :-2] / f_diff[:-1]
+    up = slopes[:, 2:] / f_diff[1:]
+    return torch.clamp(torch.minimum(down, up), min=0.0).float()
+
+
+def vocos_mel_spectrogram(wav: Tensor, n_fft: int = 1024, hop: int = 256, n_mels: int = 100, sample_rate: int = 24000) -> Tensor:
+    """get_vocos_mel_spectrogram (modules.py:75-101): wav [B, nw] -> log-mel [B, n_mels, nw // hop + 1]."""
+    spec = torch.stft(wav.float(), n_fft, hop_length=hop, win_length=n_fft, window=torch.hann_window(n_fft), center=True,
+                      pad_mode="reflect", normalized=False, onesided=True, return_complex=True).abs()      # power = 1
+    mel = torch.matmul(spec.transpose(1, 2), htk_filterbank(n_fft // 2 + 1, n_mels, sample_rate)).transpose(1, 2)
+    return mel.clamp(min=1e-5).log()
+
+
+# ----------------------------------------------------------------------------------------------
 # Vocos decode (third-party; call site infer/utils_infer.py:549)
 # ----------------------------------------------------------------------------------------------
 class OracleVocos:

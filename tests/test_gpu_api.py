@@ -58,3 +58,42 @@ def test_tts_infer_end_to_end_vs_oracle():
     print(f"\n[tts.infer] mel-MSE {mse:.3e}  waveform relative rms error {rel:.3e}")
     assert mse <= 1e-4
     assert rel < 5e-2      # bf16-level mel differences pushed through a random-weight vocoder
+
+
+def test_infer_batch_process_from_raw_audio_with_rms_rescale():
+    """utils_infer.py:487-497,552-553: quiet 24 kHz mono/stereo prompt -> boosted to rms 0.1 for the model, output scaled back."""
+    import math
+    from lemas_tts_amd.infer.utils_infer import infer_batch_process, load_model, load_vocoder
+    from oracle import lemas_oracle as O
+    arch = DiTArch(depth=1)
+    vocab = {f"p{i}": i for i in range(898)}
+    sd = synth.synth_cfm_state_dict(arch, 898, 91)
+    vsd = synth.synth_vocos_state_dict(92)
+    model = load_model(None, dict(dim=1024, depth=1, heads=16, ff_mult=2, text_dim=512, conv_layers=4), "", device="cuda:0",
+                       state_dict=sd, vocab_char_map=vocab)
+    vocoder = load_vocoder("vocos", device="cuda:0", state_dict=vsd)
+    nw = 256 * 50 + 100
+    t = torch.arange(nw) / 24000.0
+    mono = 0.02 * torch.sin(2 * math.pi * 330.0 * t) + 0.004 * torch.randn(nw, generator=torch.Generator().manual_seed(1))
+    stereo = torch.stack([mono * 1.1, mono * 0.9])          # averaged back to `mono` (:488-489)
+    ref_text = [f"p{i}" for i in synth.synth_tokens(93, 10, 898)]
+    gen = [[f"p{i}" for i in synth.synth_tokens(94, 8, 898)]]
+    ref_len = nw // 256
+    dur = ref_len + int(ref_len / len(ref_text) * len(gen[0]) / 1.0)
+    N = max(dur, ref_len + 2)
+    noise = [torch.from_numpy(synth.synth_noise(95, N))[None]]
+    wav, sr, spec = next(infer_batch_process((stereo, 24000), ref_text, gen, model, vocoder, nfe_step=3, cfg_strength=2.0,
+                                             sway_sampling_coef=5, use_acc_grl=False, noise=noise))
+    rms = float(torch.sqrt(torch.mean(mono ** 2)))
+    assert rms < 0.1
+    boosted = mono * 0.1 / rms
+    mel = O.vocos_mel_spectrogram(boosted[None]).permute(0, 2, 1)
+    out, _ = O.OracleCFM(sd, arch).sample(mel, O.tokens_to_idx([ref_text + gen[0]], vocab), dur, y0=noise[0], steps=3,
+                                          cfg_strength=2.0, sway_sampling_coef=5)
+    gmel = out[:, ref_len:, :].permute(0, 2, 1)
+    ref_wav = np.clip((O.OracleVocos(vsd).decode(gmel)[0] * rms / 0.1).numpy(), -0.999, 0.999)
+    assert wav.shape == ref_wav.shape and sr == 24000
+    mse = float(((spec - gmel[0].numpy()) ** 2).mean())
+    rel = float(np.sqrt(((wav - ref_wav) ** 2).mean()) / np.sqrt((ref_wav ** 2).mean()))
+    print(f"\n[infer_batch_process raw audio] mel-MSE {mse:.3e}  waveform relative rms error {rel:.3e}")
+    assert mse <= 1e-4 and rel < 5e-2
