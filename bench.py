@@ -215,8 +215,13 @@ def main():
         ach = fl / (avg_us * 1e-6) / 1e12
         total_ms = sum(v[0] for v in prof.values())
         kname = "attn_fwd_kernel" if dom == "attention" else f"gemm_bf16_kernel<{dom}>"
+        traffic = None   # HBM-side bytes per launch from the committed PMC passes (rocprofv3 cannot run inside bench.py)
+        try:
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))[dom]["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         result["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS,
-                              "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                              "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
                               "avg_launch_us": avg_us, "launches": int(cnt), "flops_per_launch": fl}
         result["kernel_tflops"] = {k: round(class_flops(k, rows, N_TOT, 2) / (1e3 * v[0] / max(v[1], 1) * 1e-6) / 1e12, 1)
                                    for k, v in mm.items()}
