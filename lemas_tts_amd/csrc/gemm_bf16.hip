@@ -25,6 +25,8 @@
 // Row space: activations are laid out as [sample][seq_pitch rows][...] with seq_pitch a multiple of 128, so a
 // 128-row tile never straddles two samples and v^T stores are 8-B aligned; rows >= seq_valid are padding
 // (computed, never stored where it matters).
+#include <cstdlib>
+
 #include "common.h"
 
 #ifndef LEMAS_GEMM_PRIO
@@ -245,7 +247,7 @@ constexpr int slab_bytes() {
                                                       : SlabBf16<WTM, WTN>::BYTES;
 }
 
-template <int EPI, int TBM, int TBN, int NSTAGE, int NWM, int NWN, bool SPREAD, bool SWAP>
+template <int EPI, int TBM, int TBN, int NSTAGE, int NWM, int NWN, int SPREAD, bool SWAP>
 __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, int m0, int n0) {
   constexpr int NW = NWM * NWN;                       // waves per workgroup
   constexpr int WTM = TBM / NWM, WTN = TBN / NWN;     // wave tile
@@ -304,53 +306,143 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, int m
   for (int s = 0; s < NSTAGE - 1; ++s)
     if (s < nk) issue(s, s);
 
-  int stage = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    // tile kt must have landed; in steady state the NSTAGE-2 younger tiles stay in flight across the barrier
-    if (kt + NSTAGE - 2 < nk) wait_vmcnt<PW * (NSTAGE - 2)>();
+  auto frag_a = [&](const char* sA, int kk, int t) {
+    return *reinterpret_cast<const bf16x8*>(sA + lds_off(wm * WTM + t * 32 + l31, kk * 2 + hi));
+  };
+  auto frag_b = [&](const char* sB, int kk, int t) {
+    return *reinterpret_cast<const bf16x8*>(sB + lds_off(wn * WTN + t * 32 + l31, kk * 2 + hi));
+  };
+  if (SPREAD == 2) {
+    // Mid-iteration barrier: the wait + barrier that publishes tile kt+1 sits between k-steps 1 and 2 of tile kt, so the
+    // first fragments of tile kt+1 are read under the last MFMAs of tile kt and no iteration opens with every wave
+    // waiting on LDS at once (with the barrier at the top, all 8 waves issue their reads together and the matrix pipe
+    // idles ~300 cycles per K-tile).  Tile kt+NSTAGE-1 is issued in the second half, after the barrier.
+    bf16x8 f0a[TI], f0b[TJ], f1a[TI], f1b[TJ];
+    if (nk >= NSTAGE - 1) wait_vmcnt<PW * (NSTAGE - 2)>();   // prologue issued NSTAGE-1 tiles: tile 0 is the oldest
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
-    // every wave is past its reads of the stage consumed in iteration kt-1: refill it with tile kt+NSTAGE-1
-    const int nt = kt + NSTAGE - 1;
-    int ns = stage + NSTAGE - 1;
-    ns = ns >= NSTAGE ? ns - NSTAGE : ns;
-    const bool refill = nt < nk;
-    if (!SPREAD && refill) issue(ns, nt);
-    const char* sA = smem + stage * STAGE;
-    const char* sB = sA + A_BYTES;
-    // fragments are double-buffered in registers: the ds_read_b128 of k-step kk+1 are in flight under the MFMAs of kk;
-    // sched_barrier pins that order (the scheduler otherwise sinks the reads next to their consumers)
-    bf16x8 af[2][TI], bf[2][TJ];
 #pragma unroll
-    for (int t = 0; t < TI; ++t) af[0][t] = *reinterpret_cast<const bf16x8*>(sA + lds_off(wm * WTM + t * 32 + l31, hi));
+    for (int t = 0; t < TI; ++t) f0a[t] = frag_a(smem, 0, t);
 #pragma unroll
-    for (int t = 0; t < TJ; ++t) bf[0][t] = *reinterpret_cast<const bf16x8*>(sB + lds_off(wn * WTN + t * 32 + l31, hi));
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      if (kk < 3) {
-#pragma unroll
-        for (int t = 0; t < TI; ++t)
-          af[(kk + 1) & 1][t] = *reinterpret_cast<const bf16x8*>(sA + lds_off(wm * WTM + t * 32 + l31, (kk + 1) * 2 + hi));
-#pragma unroll
-        for (int t = 0; t < TJ; ++t)
-          bf[(kk + 1) & 1][t] = *reinterpret_cast<const bf16x8*>(sB + lds_off(wn * WTN + t * 32 + l31, (kk + 1) * 2 + hi));
-      }
-      if (SPREAD && refill) {   // DMA issue slots hidden behind the MFMAs instead of a burst after the barrier
-#pragma unroll
-        for (int x = (PW * kk) / 4; x < (PW * (kk + 1)) / 4; ++x) issue_piece(ns, nt, x);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (PRIO) __builtin_amdgcn_s_setprio(1);
+    for (int t = 0; t < TJ; ++t) f0b[t] = frag_b(smem + A_BYTES, 0, t);
+    auto mma = [&](const bf16x8 (&fa)[TI], const bf16x8 (&fb)[TJ]) {
 #pragma unroll
       for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < TJ; ++j)
-          acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[kk & 1][j], af[kk & 1][i], acc[i][j], 0, 0, 0)
-                           : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
-      if (PRIO) __builtin_amdgcn_s_setprio(0);
+          acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0)
+                           : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    };
+    int stage = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      const char* sA = smem + stage * STAGE;
+      const char* sB = sA + A_BYTES;
+      int s1 = stage + 1;
+      s1 = s1 == NSTAGE ? 0 : s1;
+      const int nt = kt + NSTAGE - 1;
+      int ns = stage + NSTAGE - 1;
+      ns = ns >= NSTAGE ? ns - NSTAGE : ns;
+      // k-step 0
+#pragma unroll
+      for (int t = 0; t < TI; ++t) f1a[t] = frag_a(sA, 1, t);
+#pragma unroll
+      for (int t = 0; t < TJ; ++t) f1b[t] = frag_b(sB, 1, t);
       __builtin_amdgcn_sched_barrier(0);
+      mma(f0a, f0b);
+      __builtin_amdgcn_sched_barrier(0);
+      // k-step 1
+#pragma unroll
+      for (int t = 0; t < TI; ++t) f0a[t] = frag_a(sA, 2, t);
+#pragma unroll
+      for (int t = 0; t < TJ; ++t) f0b[t] = frag_b(sB, 2, t);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(f1a, f1b);
+      __builtin_amdgcn_sched_barrier(0);
+      // publish tile kt+1 (its DMA was issued one iteration ago); younger tiles stay in flight
+      if (kt + 1 < nk) {
+        if (kt + NSTAGE - 2 < nk) wait_vmcnt<PW * (NSTAGE - 3 > 0 ? NSTAGE - 3 : 0)>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+      }
+      const bool refill = nt < nk;
+      // k-step 2 (+ first half of the refill DMA: the stage of tile kt-1 is free now)
+#pragma unroll
+      for (int t = 0; t < TI; ++t) f1a[t] = frag_a(sA, 3, t);
+#pragma unroll
+      for (int t = 0; t < TJ; ++t) f1b[t] = frag_b(sB, 3, t);
+      if (refill) {
+#pragma unroll
+        for (int x = 0; x < PW / 2; ++x) issue_piece(ns, nt, x);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mma(f0a, f0b);
+      __builtin_amdgcn_sched_barrier(0);
+      // k-step 3 (+ second half of the DMA, + first fragments of tile kt+1)
+      if (kt + 1 < nk) {
+        const char* nA = smem + s1 * STAGE;
+#pragma unroll
+        for (int t = 0; t < TI; ++t) f0a[t] = frag_a(nA, 0, t);
+#pragma unroll
+        for (int t = 0; t < TJ; ++t) f0b[t] = frag_b(nA + A_BYTES, 0, t);
+      }
+      if (refill) {
+#pragma unroll
+        for (int x = PW / 2; x < PW; ++x) issue_piece(ns, nt, x);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mma(f1a, f1b);
+      __builtin_amdgcn_sched_barrier(0);
+      stage = s1;
     }
-    stage = stage + 1 == NSTAGE ? 0 : stage + 1;
+  } else {
+    int stage = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      // tile kt must have landed; in steady state the NSTAGE-2 younger tiles stay in flight across the barrier
+      if (kt + NSTAGE - 2 < nk) wait_vmcnt<PW * (NSTAGE - 2)>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      // every wave is past its reads of the stage consumed in iteration kt-1: refill it with tile kt+NSTAGE-1
+      const int nt = kt + NSTAGE - 1;
+      int ns = stage + NSTAGE - 1;
+      ns = ns >= NSTAGE ? ns - NSTAGE : ns;
+      const bool refill = nt < nk;
+      if (!SPREAD && refill) issue(ns, nt);
+      const char* sA = smem + stage * STAGE;
+      const char* sB = sA + A_BYTES;
+      // fragments are double-buffered in registers: the ds_read_b128 of k-step kk+1 are in flight under the MFMAs of kk;
+      // sched_barrier pins that order (the scheduler otherwise sinks the reads next to their consumers)
+      bf16x8 af[2][TI], bf[2][TJ];
+  #pragma unroll
+      for (int t = 0; t < TI; ++t) af[0][t] = *reinterpret_cast<const bf16x8*>(sA + lds_off(wm * WTM + t * 32 + l31, hi));
+  #pragma unroll
+      for (int t = 0; t < TJ; ++t) bf[0][t] = *reinterpret_cast<const bf16x8*>(sB + lds_off(wn * WTN + t * 32 + l31, hi));
+  #pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        if (kk < 3) {
+  #pragma unroll
+          for (int t = 0; t < TI; ++t)
+            af[(kk + 1) & 1][t] = *reinterpret_cast<const bf16x8*>(sA + lds_off(wm * WTM + t * 32 + l31, (kk + 1) * 2 + hi));
+  #pragma unroll
+          for (int t = 0; t < TJ; ++t)
+            bf[(kk + 1) & 1][t] = *reinterpret_cast<const bf16x8*>(sB + lds_off(wn * WTN + t * 32 + l31, (kk + 1) * 2 + hi));
+        }
+        if (SPREAD && refill) {   // DMA issue slots hidden behind the MFMAs instead of a burst after the barrier
+  #pragma unroll
+          for (int x = (PW * kk) / 4; x < (PW * (kk + 1)) / 4; ++x) issue_piece(ns, nt, x);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+  #pragma unroll
+        for (int i = 0; i < TI; ++i)
+  #pragma unroll
+          for (int j = 0; j < TJ; ++j)
+            acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[kk & 1][j], af[kk & 1][i], acc[i][j], 0, 0, 0)
+                             : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      stage = stage + 1 == NSTAGE ? 0 : stage + 1;
+    }
   }
   if (EPI == EPI_NONE) {
     float t = 0.f;
@@ -369,7 +461,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, int m
   else epilogue_vt<TI, TJ>(p, acc, slab, m0 + wm * WTM, n0 + wn * WTN, lane);
 }
 
-template <int EPI, int TBM, int TBN, int NSTAGE, int NWM, int NWN, bool SPREAD>
+template <int EPI, int TBM, int TBN, int NSTAGE, int NWM, int NWN, int SPREAD>
 __global__ __launch_bounds__(64 * NWM * NWN) void gemm_bf16_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tiles_n = p.N / TBN;
@@ -378,7 +470,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_bf16_kernel(const GemmPar
   gemm_body<EPI, TBM, TBN, NSTAGE, NWM, NWN, SPREAD, EPI != EPI_V_T>(p, smem, m0, n0);
 }
 
-template <int EPI, int TBM, int TBN, int NSTAGE, int NWM, int NWN, bool SPREAD>
+template <int EPI, int TBM, int TBN, int NSTAGE, int NWM, int NWN, int SPREAD>
 hipError_t launch_cfg(const GemmParams& p, hipStream_t s) {
   if (p.N % TBN != 0) return hipErrorInvalidValue;
   constexpr int ring = NSTAGE * (TBM + TBN) * 128;
@@ -402,8 +494,11 @@ template <int EPI>
 hipError_t dispatch(const GemmParams& p, int variant, hipStream_t s) {
   if (variant == 0) {
     // measured on MI355X at M = 3840 (tools/kbench.py): wide GEMMs (QK, FF1; N >= 2048) are fastest with 256x128 tiles,
-    // 8 waves, 3-stage ring (one round of 240 tiles); the N = 1024 GEMMs (V, out-proj, FF2) with 128x128 tiles, 8 waves
-    variant = p.N >= 2048 ? 6 : 10;
+    // 8 waves, 3-stage ring (one round of 240 tiles); the N = 1024 GEMMs (V, out-proj, FF2) with 128x128 tiles, 8 waves,
+    // 4-stage ring with the mid-iteration barrier
+    static const int wide = getenv("LEMAS_GEMM_WIDE") ? atoi(getenv("LEMAS_GEMM_WIDE")) : 6;       // development A/B switches
+    static const int narrow = getenv("LEMAS_GEMM_NARROW") ? atoi(getenv("LEMAS_GEMM_NARROW")) : 10;
+    variant = p.N >= 2048 ? wide : narrow;
   }
   switch (variant) {
     //                              BM   BN  ST WM WN spread
@@ -416,6 +511,9 @@ hipError_t dispatch(const GemmParams& p, int variant, hipStream_t s) {
     case 10: return launch_cfg<EPI, 128, 128, 3, 2, 4, true>(p, s);
     case 11: return launch_cfg<EPI, 128, 128, 3, 2, 2, false>(p, s);
     case 12: return launch_cfg<EPI, 256, 128, 3, 4, 2, false>(p, s);
+    case 13: return launch_cfg<EPI, 256, 128, 3, 4, 2, 2>(p, s);
+    case 14: return launch_cfg<EPI, 128, 128, 3, 2, 4, 2>(p, s);
+    case 15: return launch_cfg<EPI, 128, 128, 4, 2, 4, 2>(p, s);
     default: return hipErrorInvalidValue;
   }
 }
