@@ -123,10 +123,18 @@ def main():
         import torch.distributed as dist  # noqa: F811
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # LEMAS_DIST_BACKEND=gloo + LEMAS_SHARE_GPU=1 exist only to rehearse the N>1 code path on a 1-GPU box
+        backend = os.environ.get("LEMAS_DIST_BACKEND", "nccl")
+        if os.environ.get("LEMAS_SHARE_GPU") == "1":
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert torch.cuda.is_available(), "bench.py needs the MI355X (there is no CPU path)"
     device = torch.device(f"cuda:{local_rank}")
+    comm_device = device if (world == 1 or os.environ.get("LEMAS_DIST_BACKEND", "nccl") == "nccl") else torch.device("cpu")
     torch.cuda.set_device(device)
 
     from lemas_tts_amd.engine import VocosEngine  # noqa: E402
@@ -138,8 +146,8 @@ def main():
     sd = synth.synth_cfm_state_dict(arch, VOCAB, 1234) if rank == 0 else None
     vsd = synth.synth_vocos_state_dict(1234) if rank == 0 else None
     if world > 1:
-        sd = broadcast_state_dict(sd, arch, VOCAB, device, dist)
-        vsd = broadcast_state_dict(vsd, None, None, device, dist, vocos=True)
+        sd = broadcast_state_dict(sd, arch, VOCAB, comm_device, dist)
+        vsd = broadcast_state_dict(vsd, None, None, comm_device, dist, vocos=True)
     model = CFM(arch, VOCAB, sd, device=device)
     model.engine.set_option("dual", a.dual)
     model.engine.set_option("table_cache", 0)      # hoists are redone for every utterance: nothing cached across steps
@@ -170,7 +178,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist:
-        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        tmax = torch.tensor([elapsed], device=comm_device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     assert np.isfinite(host_wav.numpy()).all()

@@ -138,6 +138,10 @@ int lemas_k_convpos(const float* x, const float* w1, const float* b1, const floa
  * (0 = production choice). */
 int lemas_k_bench(const char* what, int32_t M, int32_t N, int32_t K, int32_t iters, int32_t variant, double* avg_us);
 
+/* development experiment: one lane's attention beside the other lane's five GEMMs, serial (mode 0) or on two streams
+ * (mode 1); returns microseconds per group */
+int lemas_k_bench_overlap(int32_t mode, int32_t iters, int32_t gemm_variant_wide, int32_t gemm_variant_narrow, double* avg_us);
+
 #ifdef __cplusplus
 }
 #endif

@@ -72,6 +72,7 @@ def lib():
         "lemas_k_ln_mod": (C.c_int, [vp, vp, vp, vp, i32, i32, vp]),
         "lemas_k_convpos": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
         "lemas_k_set_attention_variant": (C.c_int, [i32]),
+        "lemas_k_bench_overlap": (C.c_int, [i32, i32, i32, i32, C.POINTER(C.c_double)]),
         "lemas_k_bench": (C.c_int, [C.c_char_p, i32, i32, i32, i32, i32, C.POINTER(C.c_double)]),
     }
     for name, (res, args) in sig.items():
@@ -88,7 +89,7 @@ EXPORTED = [
     "lemas_dit_forward", "lemas_dit_profile_read", "lemas_vocos_create", "lemas_vocos_destroy",
     "lemas_vocos_load_weight", "lemas_vocos_finalize", "lemas_vocos_decode", "lemas_mel_create", "lemas_mel_destroy",
     "lemas_mel_forward", "lemas_k_linear_bf16",
-    "lemas_k_linear_f32", "lemas_k_attention", "lemas_k_ln_mod", "lemas_k_convpos", "lemas_k_bench", "lemas_k_set_attention_variant",
+    "lemas_k_linear_f32", "lemas_k_attention", "lemas_k_ln_mod", "lemas_k_convpos", "lemas_k_bench", "lemas_k_set_attention_variant", "lemas_k_bench_overlap",
 ]
 
 

@@ -196,7 +196,7 @@ extern "C" int lemas_k_bench(const char* what, int32_t M, int32_t N, int32_t K, 
     HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
     return 0;
   };
-  if (w == "gemm_gelu" || w == "gemm_gate" || w == "gemm_qk" || w == "gemm_v" || w == "gemm_f32out" || w == "gemm_none") {
+  if (w == "gemm_gelu" || w == "gemm_gate" || w == "gemm_qk" || w == "gemm_v" || w == "gemm_f32out" || w == "gemm_none" || w == "gemm_nodma") {
     const int Np = (N + 127) & ~127;
     bf16_t* a = sc.get<bf16_t>((size_t)M * K);
     bf16_t* wt = sc.get<bf16_t>((size_t)Np * K);
@@ -219,7 +219,8 @@ extern "C" int lemas_k_bench(const char* what, int32_t M, int32_t N, int32_t K, 
     p.A = a; p.W = wt; p.bias = b; p.M = M; p.N = Np; p.K = K; p.n_valid = N; p.ldc = N; p.out_bf16 = ob; p.out_f32 = of;
     p.tab = tab; p.tab_stride = 0; p.gate_off = 0; p.step_idx = step; p.seq_pitch = M; p.seq_valid = M; p.batch = 1; p.heads = 16; p.npad = npad;
     p.q = q; p.k = k; p.vt = vt; p.rope_cos = rc_; p.rope_sin = rs_;
-    const int epi = w == "gemm_gelu" ? EPI_BIAS_GELU_BF16 : w == "gemm_gate" ? EPI_GATE_RES : w == "gemm_qk" ? EPI_QK_ROPE : w == "gemm_v" ? EPI_V_T : w == "gemm_none" ? EPI_NONE : EPI_BIAS_F32;
+    const int epi = w == "gemm_gelu" ? EPI_BIAS_GELU_BF16 : w == "gemm_gate" ? EPI_GATE_RES : w == "gemm_qk" ? EPI_QK_ROPE : w == "gemm_v" ? EPI_V_T : (w == "gemm_none" || w == "gemm_nodma") ? EPI_NONE : EPI_BIAS_F32;
+    if (w == "gemm_nodma") p.n_valid = -1;
     if ((epi == EPI_QK_ROPE && N != 2048) || (epi == EPI_V_T && N != 1024)) { set_error("bench: gemm_qk needs N = 2048, gemm_v N = 1024"); return LEMAS_E_ARG; }
     rc = time_it([&]() { return launch_gemm_bf16_variant(epi, p, variant, s); });
   } else if (w == "attention") {
@@ -246,4 +247,74 @@ extern "C" int lemas_k_bench(const char* what, int32_t M, int32_t N, int32_t K, 
   (void)hipStreamDestroy(own);
   if (rc == 0 && avg_us) *avg_us = 1e3 * ms / iters;
   return rc;
+}
+
+// ---- experiment: how well does the VALU-bound attention kernel overlap with the MFMA-bound GEMMs of the OTHER CFG lane
+// when they run concurrently on two streams?  mode 0 = serial on one stream, 1 = concurrent.  Returns us per (attention +
+// 5 GEMMs) group.
+extern "C" int lemas_k_bench_overlap(int32_t mode, int32_t iters, int32_t gemm_variant_wide, int32_t gemm_variant_narrow, double* avg_us) {
+  hipStream_t sa = nullptr, sb = nullptr;
+  HIP_TRY(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
+  Scratch sc;
+  const int M = 1920, n = 1875, bh = 16, pitch = 1920;
+  bf16_t* a = sc.get<bf16_t>((size_t)M * 2048);
+  bf16_t* wt = sc.get<bf16_t>((size_t)2048 * 2048);
+  float* b = sc.get<float>(2048);
+  bf16_t* ob = sc.get<bf16_t>((size_t)M * 2048);
+  float* of = sc.get<float>((size_t)M * 2048);
+  float* tab = sc.get<float>(2048);
+  int* step = sc.get<int>(16);
+  bf16_t* q = sc.get<bf16_t>((size_t)bh * pitch * 64);
+  bf16_t* k = sc.get<bf16_t>((size_t)bh * pitch * 64);
+  bf16_t* vt = sc.get<bf16_t>((size_t)bh * 64 * pitch);
+  bf16_t* o = sc.get<bf16_t>((size_t)bh * pitch * 64);
+  bf16_t* q2 = sc.get<bf16_t>((size_t)bh * pitch * 64);
+  bf16_t* k2 = sc.get<bf16_t>((size_t)bh * pitch * 64);
+  bf16_t* vt2 = sc.get<bf16_t>((size_t)bh * 64 * pitch);
+  float* rc_ = sc.get<float>((size_t)M * 32);
+  float* rs_ = sc.get<float>((size_t)M * 32);
+  if (!a || !wt || !b || !ob || !of || !tab || !step || !q || !k || !vt || !o || !q2 || !k2 || !vt2 || !rc_ || !rs_) { set_error("bench: out of memory"); return LEMAS_E_STATE; }
+  hipLaunchKernelGGL(fill_pattern_kernel, dim3(1024), dim3(256), 0, sa, a, (size_t)M * 2048, 1u);
+  hipLaunchKernelGGL(fill_pattern_kernel, dim3(1024), dim3(256), 0, sa, wt, (size_t)2048 * 2048, 2u);
+  hipLaunchKernelGGL(fill_pattern_kernel, dim3(1024), dim3(256), 0, sa, q, (size_t)bh * pitch * 64, 3u);
+  hipLaunchKernelGGL(fill_pattern_kernel, dim3(1024), dim3(256), 0, sa, k, (size_t)bh * pitch * 64, 4u);
+  hipLaunchKernelGGL(fill_pattern_kernel, dim3(1024), dim3(256), 0, sa, vt, (size_t)bh * 64 * pitch, 5u);
+  HIP_TRY(hipStreamSynchronize(sa));
+  AttnParams at{};
+  at.q = q; at.k = k; at.vt = vt; at.out = o; at.b2 = 1; at.batch = 1; at.heads = 16; at.n = n; at.npad = pitch; at.pitch = pitch; at.scale = 0.125f;
+  GemmParams g{};
+  g.A = a; g.W = wt; g.bias = b; g.M = M; g.tab = tab; g.step_idx = step; g.seq_pitch = pitch; g.seq_valid = n; g.batch = 1; g.heads = 16; g.npad = pitch;
+  g.q = q2; g.k = k2; g.vt = vt2; g.rope_cos = rc_; g.rope_sin = rs_; g.out_bf16 = ob; g.out_f32 = of;
+  auto gemms = [&](hipStream_t s) {
+    g.N = 2048; g.K = 1024; g.n_valid = 2048; g.ldc = 2048; (void)launch_gemm_bf16_variant(EPI_QK_ROPE, g, gemm_variant_wide, s);
+    g.N = 1024; g.n_valid = 1024; (void)launch_gemm_bf16_variant(EPI_V_T, g, gemm_variant_narrow, s);
+    g.ldc = 1024; (void)launch_gemm_bf16_variant(EPI_GATE_RES, g, gemm_variant_narrow, s);
+    g.N = 2048; g.n_valid = 2048; g.ldc = 2048; (void)launch_gemm_bf16_variant(EPI_BIAS_GELU_BF16, g, gemm_variant_wide, s);
+    g.N = 1024; g.K = 2048; g.n_valid = 1024; g.ldc = 1024; (void)launch_gemm_bf16_variant(EPI_GATE_RES, g, gemm_variant_narrow, s);
+  };
+  hipEvent_t e0, e1, ej;
+  HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventCreateWithFlags(&ej, hipEventDisableTiming));
+  for (int w = 0; w < 2; ++w) { (void)launch_attention(at, sa); gemms(mode ? sb : sa); }
+  HIP_TRY(hipStreamSynchronize(sa)); HIP_TRY(hipStreamSynchronize(sb));
+  HIP_TRY(hipEventRecord(e0, sa));
+  if (mode == 1 || mode == 2) { HIP_TRY(hipStreamWaitEvent(sb, e0, 0)); }
+  for (int i = 0; i < iters; ++i) {
+    if (mode >= 2) {   // control experiment: the SAME half-size attention on both streams (mode 2) or twice on one (mode 3)
+      (void)launch_attention(at, sa);
+      (void)launch_attention(at, mode == 2 ? sb : sa);
+      continue;
+    }
+    (void)launch_attention(at, sa);
+    gemms(mode ? sb : sa);
+  }
+  if (mode == 1 || mode == 2) { HIP_TRY(hipEventRecord(ej, sb)); HIP_TRY(hipStreamWaitEvent(sa, ej, 0)); }
+  HIP_TRY(hipEventRecord(e1, sa));
+  HIP_TRY(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  if (avg_us) *avg_us = 1e3 * ms / iters;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(ej);
+  (void)hipStreamDestroy(sa); (void)hipStreamDestroy(sb);
+  return 0;
 }

@@ -405,7 +405,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, int m
       const int nt = kt + NSTAGE - 1;
       int ns = stage + NSTAGE - 1;
       ns = ns >= NSTAGE ? ns - NSTAGE : ns;
-      const bool refill = nt < nk;
+      const bool refill = nt < nk && !(EPI == EPI_NONE && p.n_valid == -1);   // n_valid == -1: timing experiment without DMA
       if (!SPREAD && refill) issue(ns, nt);
       const char* sA = smem + stage * STAGE;
       const char* sB = sA + A_BYTES;
@@ -456,9 +456,15 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, int m
     return;
   }
   __syncthreads();   // every wave is done with the ring: its LDS becomes the epilogue slabs
-  char* slab = smem + wave * slab_bytes<EPI, WTM, WTN>();
-  if (SWAP) epilogue_rows<EPI, TI, TJ>(p, acc, slab, m0 + wm * WTM, n0 + wn * WTN, lane);
-  else epilogue_vt<TI, TJ>(p, acc, slab, m0 + wm * WTM, n0 + wn * WTN, lane);
+  // one 32-row block of the wave tile at a time through a small wave-private slab (LDS ops of a wave execute in order, so
+  // the slab can be rewritten right after it was read): keeps the kernel's LDS footprint = the ring, not ring + big slabs
+  char* slab = smem + wave * slab_bytes<EPI, 32, WTN>();
+#pragma unroll
+  for (int i = 0; i < TI; ++i) {
+    f32x16 (&blk)[1][TJ] = *reinterpret_cast<f32x16 (*)[1][TJ]>(&acc[i]);
+    if (SWAP) epilogue_rows<EPI, 1, TJ>(p, blk, slab, m0 + wm * WTM + 32 * i, n0 + wn * WTN, lane);
+    else epilogue_vt<1, TJ>(p, blk, slab, m0 + wm * WTM + 32 * i, n0 + wn * WTN, lane);
+  }
 }
 
 template <int EPI, int TBM, int TBN, int NSTAGE, int NWM, int NWN, int SPREAD>
@@ -474,7 +480,7 @@ template <int EPI, int TBM, int TBN, int NSTAGE, int NWM, int NWN, int SPREAD>
 hipError_t launch_cfg(const GemmParams& p, hipStream_t s) {
   if (p.N % TBN != 0) return hipErrorInvalidValue;
   constexpr int ring = NSTAGE * (TBM + TBN) * 128;
-  constexpr int slabs = NWM * NWN * slab_bytes<EPI, TBM / NWM, TBN / NWN>();
+  constexpr int slabs = NWM * NWN * slab_bytes<EPI, 32, TBN / NWN>();
   constexpr int lds = ring > slabs ? ring : slabs;
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
@@ -493,12 +499,14 @@ hipError_t launch_cfg(const GemmParams& p, hipStream_t s) {
 template <int EPI>
 hipError_t dispatch(const GemmParams& p, int variant, hipStream_t s) {
   if (variant == 0) {
-    // measured on MI355X at M = 3840 (tools/kbench.py): wide GEMMs (QK, FF1; N >= 2048) are fastest with 256x128 tiles,
-    // 8 waves, 3-stage ring (one round of 240 tiles); the N = 1024 GEMMs (V, out-proj, FF2) with 128x128 tiles, 8 waves,
-    // 4-stage ring with the mid-iteration barrier
-    static const int wide = getenv("LEMAS_GEMM_WIDE") ? atoi(getenv("LEMAS_GEMM_WIDE")) : 6;       // development A/B switches
-    static const int narrow = getenv("LEMAS_GEMM_NARROW") ? atoi(getenv("LEMAS_GEMM_NARROW")) : 10;
-    variant = p.N >= 2048 ? wide : narrow;
+    // Largest tile that still yields about one workgroup per CU (measured with tools/kbench.py at M = 1920 / 3840 /
+    // 18432): 256x128 (8 waves, 3-stage ring) -> 128x128 (8 waves, 3-stage) -> 128x64 (4 waves, 3-stage).
+    static const int force_wide = getenv("LEMAS_GEMM_WIDE") ? atoi(getenv("LEMAS_GEMM_WIDE")) : 0;       // development A/B switches
+    static const int force_narrow = getenv("LEMAS_GEMM_NARROW") ? atoi(getenv("LEMAS_GEMM_NARROW")) : 0;
+    const long t256 = (long)((p.M + 255) / 256) * (p.N / 128), t128 = (long)((p.M + 127) / 128) * (p.N / 128);
+    variant = t256 >= 200 ? 6 : t128 >= 200 ? 10 : 4;
+    if (p.N >= 2048 && force_wide) variant = force_wide;
+    if (p.N < 2048 && force_narrow) variant = force_narrow;
   }
   switch (variant) {
     //                              BM   BN  ST WM WN spread

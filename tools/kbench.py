@@ -9,7 +9,8 @@ import torch  # noqa
 from lemas_tts_amd import _lib
 
 L = _lib.lib()
-M = 3840
+import os
+M = int(os.environ.get("KB_M", "3840"))
 variants = [int(v) for v in sys.argv[1:]] or [2, 3, 4, 5, 6, 7, 10, 11, 12]
 shapes = [("gemm_qk", 2048, 1024), ("gemm_v", 1024, 1024), ("gemm_gate", 1024, 1024), ("gemm_gelu", 2048, 1024), ("gemm_gate", 1024, 2048),
           ("gemm_gelu", 2048, 2048)]
