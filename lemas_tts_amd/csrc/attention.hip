@@ -28,6 +28,8 @@
 // the exponent argument and the row sum use packed fp32 math (v_pk_fma_f32 / v_pk_add_f32), v_exp_f32 is issued
 // directly, and the O rescale is skipped whenever no query of the wave raised its running max (alpha == 1 exactly).
 // S^T of tile j+1 is issued to the matrix pipe BEFORE the softmax of tile j so the two pipes overlap inside a wave.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -339,14 +341,16 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_splitkv_kernel(const AttnPara
   for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
   float m_run = -INFINITY, l_run = 0.f;
 
-  issue(0, 0);
-  for (int i = 0; i < nsup; ++i) {
+  // the ring stage is a compile-time constant inside `pair` (the loop below is unrolled by the ring depth), so every
+  // LDS address is base register + immediate
+  auto pair = [&](int i, auto stage_c) {
+    constexpr int SG = decltype(stage_c)::value;
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
-    if (i + 1 < nsup) issue((i + 1) & 1, i + 1);
+    if (i + 1 < nsup && !(p.variant == 3 && i > 0)) issue(SG ^ 1, i + 1);   // variant 3: timing experiment without DMA
     const int j = 2 * i + grp;
     if (j < ntiles) {
-      const char* sK = smem + (i & 1) * STAGE2 + grp * 2 * TILE;
+      const char* sK = smem + SG * STAGE2 + grp * 2 * TILE;
       const char* sV = sK + TILE;
       f32x16 s[2];
 #pragma unroll
@@ -408,6 +412,11 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_splitkv_kernel(const AttnPara
         for (int dt = 0; dt < 2; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[dt], pb[e >> 1][e & 1], o[dt], 0, 0, 0);
       }
     }
+  };
+  issue(0, 0);
+  for (int i = 0; i < nsup; i += 2) {
+    pair(i, std::integral_constant<int, 0>{});
+    if (i + 1 < nsup) pair(i + 1, std::integral_constant<int, 1>{});
   }
 
   // ---- merge the two key-parity partials: group 1 parks (m, l, O^T) in LDS, group 0 folds it in
