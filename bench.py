@@ -45,6 +45,7 @@ VOCAB = 898
 F_REF, N_TOT, NFE, CFG, SWAY = 938, 1875, 32, 2.0, 5
 HOP, SR = 256, 24000
 MFMA_BF16_PEAK_TFLOPS = 2500.0
+MFMA_FP8_PEAK_TFLOPS = 5000.0
 
 
 def fwd_flops(B: int, N: int) -> float:
@@ -112,6 +113,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--depth", type=int, default=22, help="DiT depth (22 = the shipped model; smaller only for debugging)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fp8", type=int, default=0, help="1 = block GEMMs on the fp8-e4m3 (MXFP8) path of BASELINE config 5; "
+                    "NOT the headline configuration (configs[1] is bf16): the line is then labelled dtype fp8")
     ap.add_argument("--dual", type=int, default=1, help="1 = CFG branches as two concurrent lanes (default), 0 = one stream")
     a = ap.parse_args()
 
@@ -150,6 +153,7 @@ def main():
         vsd = broadcast_state_dict(vsd, None, None, comm_device, dist, vocos=True)
     model = CFM(arch, VOCAB, sd, device=device)
     model.engine.set_option("dual", a.dual)
+    model.engine.set_option("fp8", a.fp8)
     model.engine.set_option("table_cache", 0)      # hoists are redone for every utterance: nothing cached across steps
     vocoder = VocosEngine(vsd, device=device)
     cond, text, y0 = build_inputs(rank, device)
@@ -191,11 +195,12 @@ def main():
         result = {
             "metric": "audio-seconds/sec @24kHz (NFE=32, CFG on)", "value": value, "unit": "audio-seconds/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp8" if a.fp8 else "bf16", "data": "synthetic",
             "rtf": elapsed / (a.steps * audio_per_step),
             "config": {"workload": "BASELINE configs[1]: multilingual_grl, batch 1, 10 s ref + 10 s target "
                                    f"(F={F_REF}, N={N_TOT}), NFE={NFE}, CFG={CFG}, sway coef {SWAY} (capped), "
-                                   "bf16 MFMA operands / fp32 state, Vocos decode + D2H included",
+                                   + ("fp8-e4m3 (MXFP8) GEMM operands, bf16 attention" if a.fp8 else "bf16 MFMA operands")
+                                   + " / fp32 state, Vocos decode + D2H included",
                        "utterances_per_gpu_per_step": 1, "audio_seconds_per_step": audio_per_step,
                        "parallelism": f"dp{world} (utterance sharding, RCCL weight broadcast, no step-loop collectives)",
                        "depth": a.depth, "weights": "synthetic N(0,0.02^2), seed 1234"},
@@ -218,20 +223,23 @@ def main():
         dom = max(mm, key=lambda k: mm[k][0])      # dominant kernel = largest total time in the step loop
         ms, cnt = mm[dom]
         avg_us = 1e3 * ms / max(cnt, 1)
-        rows = 2 * N_TOT
-        fl = class_flops(dom, rows, N_TOT, 2)
+        lanes = 2 if a.dual else 1                 # dual: each launch covers one CFG branch (B rows of the 2B)
+        rows, bb = 2 * N_TOT // lanes, 2 // lanes
+        fl = class_flops(dom, rows, N_TOT, bb)
         ach = fl / (avg_us * 1e-6) / 1e12
         total_ms = sum(v[0] for v in prof.values())
-        kname = "attn_fwd_kernel" if dom == "attention" else f"gemm_bf16_kernel<{dom}>"
+        kname = "attn_fwd_splitkv_kernel" if dom == "attention" else f"gemm_bf16_kernel<{dom}>"
         traffic = None   # HBM-side bytes per launch from the committed PMC passes (rocprofv3 cannot run inside bench.py)
         try:
             traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))[dom]["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
-        result["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS,
-                              "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
-                              "avg_launch_us": avg_us, "launches": int(cnt), "flops_per_launch": fl}
-        result["kernel_tflops"] = {k: round(class_flops(k, rows, N_TOT, 2) / (1e3 * v[0] / max(v[1], 1) * 1e-6) / 1e12, 1)
+        peak = MFMA_FP8_PEAK_TFLOPS if (a.fp8 and dom != "attention") else MFMA_BF16_PEAK_TFLOPS   # attention stays bf16
+        result["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": ach, "peak": peak,
+                              "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
+                              "avg_launch_us": avg_us, "launches": int(cnt), "flops_per_launch": fl,
+                              "launch_shape": f"{bb} x {N_TOT} frames x 16 heads per launch ({lanes} concurrent lane(s))"}
+        result["kernel_tflops"] = {k: round(class_flops(k, rows, N_TOT, bb) / (1e3 * v[0] / max(v[1], 1) * 1e-6) / 1e12, 1)
                                    for k, v in mm.items()}
         result["kernel_time_share"] = {k: round(v[0] / total_ms, 4) for k, v in prof.items()}
         result["kernel_avg_us"] = {k: round(1e3 * v[0] / max(v[1], 1), 2) for k, v in prof.items()}

@@ -83,7 +83,10 @@ int lemas_dit_load_weight(lemas_dit* m, const char* name, const float* host_data
 int lemas_dit_finalize(lemas_dit* m);
 /* options: "graph" (1 = replay one captured hipGraph per ODE step, default 1), "profile" (1 = per-kernel events),
  * "table_cache" (1 = keep the time/AdaLN tables while the t-grid is unchanged, default 1),
- * "dual" (1 = run the two CFG branches as concurrent lanes on two streams / graph branches, default 1) */
+ * "dual" (1 = run the two CFG branches as concurrent lanes on two streams / graph branches, default 1),
+ * "fp8" (1 = the DiT block GEMMs run on fp8-e4m3 MFMA: e4m3 weights with one fp32 scale per output channel, MXFP8
+ *        activations (one E8M0 scale per 32 K); attention, norms, residual stream and ODE state unchanged; default 0;
+ *        takes effect at the next prepare()/sample()) */
 int lemas_dit_set_option(lemas_dit* m, const char* key, int64_t value);
 /* full sampler: hoists + NFE Euler steps (+ final where) */
 int lemas_dit_sample(lemas_dit* m, const lemas_sample_args* a, void* stream);
@@ -122,6 +125,16 @@ int lemas_k_linear_bf16(const float* A, const float* W, const float* bias, float
 int lemas_k_linear_f32(const float* A, const float* W, const float* bias, float* out, int32_t M, int32_t N, int32_t K,
                        int32_t act, void* stream);
 /* q,k,v [B,H,N,64] (already rotated) -> out [B,N,H*64]; seq_len device int32 [B] or NULL */
+/* fp8 (MXFP8) path of the GEMMs -- BASELINE config 5 "fp8 MFMA weights".  Activations: e4m3 bytes + one E8M0 scale per
+ * 32 consecutive K (OCP MX); weights: e4m3 + one fp32 scale per output channel.  All pointers device. */
+int lemas_k_mx_quant(const float* x, int32_t M, int32_t K, uint8_t* out8, uint8_t* mx, void* stream);
+int lemas_k_w_quant_f8(const float* w, int32_t N, int32_t K, uint8_t* out8, float* scale, void* stream);
+int lemas_k_ln_mod_f8(const float* x, const float* scale, const float* shift, uint8_t* out8, uint8_t* mx, int32_t M, int32_t D,
+                      void* stream);
+/* out = act(MXFP8(A) . FP8(W)^T + bias); act 0 none (fp32 out), 1 GELU-tanh (bf16-rounded out), 2 GELU-tanh written as
+ * MXFP8 into out8 [M,N] / outmx [M,N/32] (out unused) */
+int lemas_k_linear_f8(const float* A, const float* W, const float* bias, float* out, int32_t M, int32_t N, int32_t K, int32_t act,
+                      uint8_t* out8, uint8_t* outmx, void* stream);
 int lemas_k_attention(const float* q, const float* k, const float* v, const int32_t* seq_len, float* out, int32_t B,
                       int32_t H, int32_t N, void* stream);
 /* selects the attention kernel used by lemas_k_attention: 0 auto (by grid size), 1 four-wave, 2 split-KV eight-wave */

@@ -69,6 +69,10 @@ def lib():
         "lemas_k_linear_bf16": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
         "lemas_k_linear_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
         "lemas_k_attention": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+        "lemas_k_mx_quant": (C.c_int, [vp, i32, i32, vp, vp, vp]),
+        "lemas_k_w_quant_f8": (C.c_int, [vp, i32, i32, vp, vp, vp]),
+        "lemas_k_ln_mod_f8": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, vp]),
+        "lemas_k_linear_f8": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]),
         "lemas_k_ln_mod": (C.c_int, [vp, vp, vp, vp, i32, i32, vp]),
         "lemas_k_convpos": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
         "lemas_k_set_attention_variant": (C.c_int, [i32]),
@@ -90,6 +94,7 @@ EXPORTED = [
     "lemas_vocos_load_weight", "lemas_vocos_finalize", "lemas_vocos_decode", "lemas_mel_create", "lemas_mel_destroy",
     "lemas_mel_forward", "lemas_k_linear_bf16",
     "lemas_k_linear_f32", "lemas_k_attention", "lemas_k_ln_mod", "lemas_k_convpos", "lemas_k_bench", "lemas_k_set_attention_variant", "lemas_k_bench_overlap",
+    "lemas_k_mx_quant", "lemas_k_w_quant_f8", "lemas_k_ln_mod_f8", "lemas_k_linear_f8",
 ]
 
 

@@ -61,5 +61,22 @@ def build_library(force: bool = False) -> str:
     return LIB
 
 
+def build_c_client() -> str:
+    """gcc-compile the plain-C client of the ABI (examples/c_abi_smoke.c): a compile-time proof that
+    include/lemas_hip.h is C, and the binary a GPU test runs."""
+    root = os.path.dirname(HERE)
+    src = os.path.join(root, "examples", "c_abi_smoke.c")
+    out = os.path.join(root, "examples", "c_abi_smoke")
+    if os.path.exists(out) and os.path.getmtime(out) > max(os.path.getmtime(src), os.path.getmtime(LIB), _headers_mtime()):
+        return out
+    cmd = ["gcc", "-O2", "-std=c11", "-Wall", "-D_GNU_SOURCE", "-I", INCLUDE, src, "-o", out, "-L", LIBDIR, "-llemas_hip",
+           "-Wl,-rpath,$ORIGIN/../lemas_tts_amd/lib", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib", "-lm"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"gcc failed for c_abi_smoke.c:\n{r.stdout}\n{r.stderr}")
+    return out
+
+
 if __name__ == "__main__":
     print(build_library(force="--force" in sys.argv))
+    print(build_c_client())

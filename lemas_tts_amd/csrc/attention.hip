@@ -445,6 +445,33 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_splitkv_kernel(const AttnPara
     // normalise, park O as [32 q][64 d] bf16 (144-B pitch) and write whole 128-B rows
     const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32, 64));
     char* slab = smem + wq * (32 * 144);
+    if (p.out8) {
+      // fp8 path: the out-projection consumes MXFP8 -- each 32-wide half of the head (dt) is one scale block, held by
+      // lanes l and l ^ 32; [32 q][64 B] slab (80-B pitch), whole 64-B head rows leave as 4 x 16 B
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        float amax = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o[dt][r] *= inv; amax = fmaxf(amax, fabsf(o[dt][r])); }
+        amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+        const int e = mx_exponent(amax);
+        const float sc = mx_inv_scale(e);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<unsigned int*>(slab + l31 * 80 + dt * 32 + 8 * g + 4 * hi) =
+              pack_fp8x4(o[dt][g * 4 + 0] * sc, o[dt][g * 4 + 1] * sc, o[dt][g * 4 + 2] * sc, o[dt][g * 4 + 3] * sc);
+        const int q = q_base + l31;
+        if (hi == 0 && q < N) p.out_mx[((size_t)b2 * p.pitch + q) * (p.heads * 2) + h * 2 + dt] = (uint8_t)(e + 127);
+      }
+      const int rr = lane >> 2, ch = lane & 3;
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int q = q_base + it * 16 + rr;
+        const u32x4 d = *reinterpret_cast<const u32x4*>(slab + (it * 16 + rr) * 80 + ch * 16);
+        if (q < N) store_wt_b128(p.out8 + ((size_t)b2 * p.pitch + q) * (p.heads * 64) + h * 64 + ch * 16, d);
+      }
+      return;
+    }
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -472,6 +499,7 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
   dim3 grid(((p.n + QB - 1) / QB) * p.b2 * p.heads);
   // measured (tools/kbench_attn.py): the split-KV kernel wins at every size tried (B=1: 47 vs 53 us; BH=256: 136 vs 154 us)
   const bool split = p.variant != 1;
+  if (p.out8 && (!split || !p.out_mx)) return hipErrorInvalidValue;   // the MXFP8 epilogue lives in the split-KV kernel
   if (split) hipLaunchKernelGGL(attn_fwd_splitkv_kernel, grid, dim3(512), 0, s, p);
   else hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, s, p);
   return hipGetLastError();

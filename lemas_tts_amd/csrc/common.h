@@ -9,6 +9,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 #define LEMAS_WAVE 64
 
@@ -51,6 +52,25 @@ __device__ __forceinline__ float mish_f(float x) {
   return x * n * __builtin_amdgcn_rcpf(n + 2.0f);
 }
 
+// ---- MXFP8 activations (OCP microscaling: fp8 e4m3 elements, one E8M0 power-of-two scale per 32 consecutive K) ----
+// smallest e with amax * 2^-e <= 448 (e4m3 max), clamped so 2^e and 2^-e stay normal fp32; byte stored = e + 127.
+// oracle/mxfp8.py restates exactly this arithmetic in torch.
+__device__ __forceinline__ int mx_exponent(float amax) {
+  const unsigned int b = __float_as_uint(amax * (1.0f / 448.0f));
+  int e = (int)((b >> 23) & 255u) - 127 + ((b & 0x7fffffu) ? 1 : 0);
+  return e < -120 ? -120 : (e > 120 ? 120 : e);
+}
+__device__ __forceinline__ float mx_inv_scale(int e) { return __uint_as_float((unsigned int)(127 - e) << 23); }
+// four fp32 -> four e4m3 bytes (round to nearest even), clamped to +-448 first
+__device__ __forceinline__ unsigned int pack_fp8x4(float a, float b, float c, float d) {
+  a = __builtin_amdgcn_fmed3f(a, -448.0f, 448.0f); b = __builtin_amdgcn_fmed3f(b, -448.0f, 448.0f);
+  c = __builtin_amdgcn_fmed3f(c, -448.0f, 448.0f); d = __builtin_amdgcn_fmed3f(d, -448.0f, 448.0f);
+  int v = 0;
+  v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, v, false);
+  v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
+  return (unsigned int)v;
+}
+
 // ---- epilogue selectors of the bf16 MFMA GEMM -------------------------------------------------
 enum GemmEpi : int {
   EPI_BIAS_BF16 = 0,       // out_bf16[m][n] = acc + bias
@@ -60,6 +80,7 @@ enum GemmEpi : int {
   EPI_QK_ROPE = 4,         // N = 2*inner: +bias, RoPE, scatter to q / k [B2,H,pitch,64]
   EPI_V_T = 5,             // N = inner:   +bias, scatter to v^T [B2,H,64,npad]
   EPI_NONE = 6,            // benchmarking only: K loop without an epilogue (one guarded store keeps the MFMAs live)
+  EPI_BIAS_GELU_F8 = 7,    // out_f8 / out_mx = MXFP8(gelu_tanh(acc + bias))   (fp8 path only)
 };
 
 struct GemmParams {
@@ -88,6 +109,13 @@ struct GemmParams {
   const float* rope_cos;  // [seq_valid, 32]
   const float* rope_sin;
   int heads, npad;
+  // fp8 path (f8 != 0): A and W point at e4m3 bytes (same [rows][K] layouts, K % 128 == 0); activations carry MX block
+  // scales, weights one fp32 scale per output channel (applied in the epilogue)
+  int f8;
+  const uint8_t* a_mx;    // [M][K/32] E8M0 bytes
+  const float* w_scale;   // [Nw]
+  uint8_t* out_f8;        // EPI_BIAS_GELU_F8: [M][ldc] e4m3
+  uint8_t* out_mx;        //                   [M][ldc/32]
 };
 
 // ---- internal launchers (one per .hip translation unit) ----------------------------------------
@@ -104,12 +132,22 @@ struct AttnParams {
   int pitch;         // rows per sample of q / k / out (>= n)
   int variant;       // 0 = auto, 1 = 4-wave kernel, 2 = split-KV 8-wave kernel
   float scale;
+  uint8_t* out8;     // fp8 path: when set, the output is written as MXFP8 here ([B2*pitch, H*64] e4m3) instead of `out`
+  uint8_t* out_mx;   //           [B2*pitch, H*2] E8M0
 };
 hipError_t launch_attention(const AttnParams& p, hipStream_t s);
 
 // out_bf16[m][c] = LN(x[m][:])[c] * (1 + scale[c]) + shift[c]; scale/shift read from the AdaLN table row of the current step
 hipError_t launch_ln_mod(const float* x, bf16_t* out, int M, int D, const float* tab, int tab_stride,
                          int scale_off, int shift_off, const int* step_idx, hipStream_t s);
+
+// same LayerNorm-modulate, written as MXFP8 (out8 [M][D] e4m3 + mx [M][D/32] E8M0) for the fp8 GEMMs
+hipError_t launch_ln_mod_f8(const float* x, uint8_t* out8, uint8_t* mx, int M, int D, const float* tab, int tab_stride,
+                            int scale_off, int shift_off, const int* step_idx, hipStream_t s);
+// fp32 rows -> MXFP8 (K % 32 == 0)
+hipError_t launch_mx_quant_rows(const float* x, int M, int K, uint8_t* out8, uint8_t* mx, hipStream_t s);
+// weights [N][K] fp32 -> e4m3 with one fp32 scale per row (scale = amax / 448; 0-rows get scale 1)
+hipError_t launch_w_quant_f8(const float* w, int N, int K, uint8_t* out8, float* scale, hipStream_t s);
 
 struct ConvPosParams {
   const float* in_f32;    // conv1 input  [B2*N, C] fp32 (nullptr when in_bf16 is used)

@@ -26,6 +26,8 @@ static const char* kProfNames[PC_COUNT] = {"inproj_f32", "convpos", "ln_mod", "g
 
 struct BlockW {
   DevBuf wqkv, wo, w1, w2;  // bf16
+  DevBuf wqkv8, wo8, w18, w28;   // e4m3 copies for the fp8 path (built on first use of option "fp8")
+  DevBuf sqkv, so, s1, s2;       // fp32 per-output-channel scales
   DevBuf bqkv;              // fp32 [3*inner]
   const float *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
 };
@@ -42,6 +44,8 @@ struct lemas_dit {
   bool profile = false;
   bool table_cache = true;  // reuse the AdaLN/time tables while the t-grid is unchanged
   bool dual = true;         // run the two CFG branches as concurrent lanes (second stream / parallel graph branch)
+  bool fp8 = false;         // block GEMMs on the MXFP8 path (BASELINE config 5); weights quantised on first use
+  bool fp8_ready = false;
   hipStream_t s2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 
@@ -62,6 +66,7 @@ struct lemas_dit {
   DevBuf d_cond_eff, d_step_cond, d_pm, d_pt;             // conditioning
   DevBuf d_te, d_rowmask, d_t1, d_t2, d_t3, d_gx, d_ct;   // text embedding scratch
   DevBuf d_pconst, d_y, d_xres, d_hbf, d_q, d_k, d_vt, d_abf, d_ff, d_cmid, d_pred;
+  DevBuf d_h8, d_hmx, d_a8, d_amx, d_ff8, d_ffmx;         // MXFP8 activations of the fp8 path (bytes + E8M0 scales)
   int tab_stride = 0;
 
   std::map<std::string, hipGraphExec_t> graphs;
@@ -79,9 +84,11 @@ struct lemas_dit {
     for (DevBuf* b : {&wproj_out, &bproj_out, &wconv[0], &wconv[1], &d_step, &d_dt, &d_cfg, &d_t, &d_tab, &d_rope_cos,
                       &d_rope_sin, &d_len, &d_sin, &d_h1, &d_temb, &d_st, &d_cond_eff, &d_step_cond, &d_pm, &d_pt, &d_te,
                       &d_rowmask, &d_t1, &d_t2, &d_t3, &d_gx, &d_ct, &d_pconst, &d_y, &d_xres, &d_hbf, &d_q, &d_k, &d_vt,
-                      &d_abf, &d_ff, &d_cmid, &d_pred})
+                      &d_abf, &d_ff, &d_cmid, &d_pred, &d_h8, &d_hmx, &d_a8, &d_amx, &d_ff8, &d_ffmx})
       b->release();
-    for (auto& b : blocks) { b.wqkv.release(); b.wo.release(); b.w1.release(); b.w2.release(); b.bqkv.release(); }
+    for (auto& b : blocks) {
+      for (DevBuf* w : {&b.wqkv, &b.wo, &b.w1, &b.w2, &b.bqkv, &b.wqkv8, &b.wo8, &b.w18, &b.w28, &b.sqkv, &b.so, &b.s1, &b.s2}) w->release();
+    }
     ws.release();
   }
 
@@ -90,6 +97,7 @@ struct lemas_dit {
 
   void declare_schema();
   int finalize();
+  int quantize_fp8();
   int prepare(const lemas_sample_args* a, hipStream_t s);
   int solve(const lemas_sample_args* a, hipStream_t s);
   int enqueue_forward(hipStream_t s);
@@ -172,11 +180,43 @@ void lemas_dit::declare_schema() {
   D(T("proj_out.bias"), {md});
 }
 
+// e4m3 copies of the block GEMM weights with one fp32 scale per output channel
+int lemas_dit::quantize_fp8() {
+  if (fp8_ready) return 0;
+  const int d = cfg.dim, in = inner(), ffd = cfg.ff_mult * d;
+  hipStream_t s = nullptr;
+  for (int i = 0; i < cfg.depth; ++i) {
+    const std::string p = T("transformer_blocks." + std::to_string(i) + ".");
+    BlockW& b = blocks[i];
+    RC_TRY(b.wqkv8.ensure((size_t)3 * in * d));
+    RC_TRY(b.sqkv.ensure((size_t)3 * in * 4));
+    int j = 0;
+    for (const char* n : {"to_q", "to_k", "to_v"}) {
+      HIP_TRY(launch_w_quant_f8(ws.ptr(p + "attn." + n + ".weight"), in, d, b.wqkv8.as<uint8_t>() + (size_t)j * in * d,
+                                b.sqkv.as<float>() + (size_t)j * in, s));
+      ++j;
+    }
+    RC_TRY(b.wo8.ensure((size_t)d * in));
+    RC_TRY(b.so.ensure((size_t)d * 4));
+    HIP_TRY(launch_w_quant_f8(ws.ptr(p + "attn.to_out.0.weight"), d, in, b.wo8.as<uint8_t>(), b.so.as<float>(), s));
+    RC_TRY(b.w18.ensure((size_t)ffd * d));
+    RC_TRY(b.s1.ensure((size_t)ffd * 4));
+    HIP_TRY(launch_w_quant_f8(ws.ptr(p + "ff.ff.0.0.weight"), ffd, d, b.w18.as<uint8_t>(), b.s1.as<float>(), s));
+    RC_TRY(b.w28.ensure((size_t)d * ffd));
+    RC_TRY(b.s2.ensure((size_t)d * 4));
+    HIP_TRY(launch_w_quant_f8(ws.ptr(p + "ff.ff.2.weight"), d, ffd, b.w28.as<uint8_t>(), b.s2.as<float>(), s));
+  }
+  HIP_TRY(hipStreamSynchronize(s));
+  fp8_ready = true;
+  return 0;
+}
+
 int lemas_dit::finalize() {
   RC_TRY(ws.check_complete());
   const int d = cfg.dim, in = inner(), ffd = cfg.ff_mult * d;
   hipStream_t s = nullptr;
   blocks.resize(cfg.depth);
+  fp8_ready = false;
   for (int i = 0; i < cfg.depth; ++i) {
     const std::string p = T("transformer_blocks." + std::to_string(i) + ".");
     BlockW& b = blocks[i];
@@ -380,6 +420,15 @@ int lemas_dit::prepare(const lemas_sample_args* a, hipStream_t s) {
   RC_TRY(d_ff.ensure((size_t)rows * cfg.ff_mult * d * 2));
   RC_TRY(d_cmid.ensure((size_t)rows * d * 2));
   RC_TRY(d_pred.ensure((size_t)rows * md * 4));
+  if (fp8) {
+    RC_TRY(quantize_fp8());
+    RC_TRY(d_h8.ensure((size_t)rows * d));
+    RC_TRY(d_hmx.ensure((size_t)rows * (d / 32)));
+    RC_TRY(d_a8.ensure((size_t)rows * in));
+    RC_TRY(d_amx.ensure((size_t)rows * (in / 32)));
+    RC_TRY(d_ff8.ensure((size_t)rows * cfg.ff_mult * d));
+    RC_TRY(d_ffmx.ensure((size_t)rows * (cfg.ff_mult * d / 32)));
+  }
   prepared = true;
   return 0;
 }
@@ -406,9 +455,12 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
   // From here on the two CFG branches (conditional rows, unconditional rows) are independent chains.  With "dual" on
   // they run as two concurrent lanes (second HIP stream / parallel hipGraph branch): each GEMM then has one round of
   // ~120 tiles, and one lane's epilogue / prologue / launch gap overlaps the other lane's K loop.
-  const int lanes = (dual && use_cfg && !profile && s != nullptr) ? 2 : 1;
-  hipStream_t st[2] = {s, lanes == 2 ? s2 : s};
-  if (lanes == 2) {
+  const int lanes = (dual && use_cfg && s != nullptr) ? 2 : 1;
+  // profile mode keeps the per-lane launch shapes but runs the lanes back to back on one stream, so the HIP events
+  // around a launch time that kernel alone (two concurrent streams would add the other lane's queueing to it)
+  const bool fork = lanes == 2 && !profile;
+  hipStream_t st[2] = {s, fork ? s2 : s};
+  if (fork) {
     HIP_TRY(hipEventRecord(ev_fork, s));
     HIP_TRY(hipStreamWaitEvent(s2, ev_fork, 0));
   }
@@ -449,36 +501,61 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     at.scale = 1.0f / sqrtf((float)cfg.dim_head);
     const BlockW& w = blocks[l];
     const int base = l * 6 * d;  // [shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp] (modules.py:312)
+    uint8_t* h8 = fp8 ? d_h8.as<uint8_t>() + r0 * d : nullptr;
+    uint8_t* hmx = fp8 ? d_hmx.as<uint8_t>() + r0 * (d / 32) : nullptr;
+    uint8_t* a8 = fp8 ? d_a8.as<uint8_t>() + r0 * in : nullptr;
+    uint8_t* amx = fp8 ? d_amx.as<uint8_t>() + r0 * (in / 32) : nullptr;
+    uint8_t* ff8 = fp8 ? d_ff8.as<uint8_t>() + r0 * ffd : nullptr;
+    uint8_t* ffmx = fp8 ? d_ffmx.as<uint8_t>() + r0 * (ffd / 32) : nullptr;
+    g.f8 = fp8 ? 1 : 0;
+    // A / W / their scales for one GEMM: bf16 operands, or (fp8) MXFP8 activations x per-channel-scaled e4m3 weights
+    auto operands = [&](const bf16_t* abf16, const uint8_t* af8, const uint8_t* afmx, const DevBuf& wb, const DevBuf& w8, const DevBuf& wsc,
+                        size_t row_off, int K) {
+      if (fp8) {
+        g.A = reinterpret_cast<const bf16_t*>(af8); g.a_mx = afmx;
+        g.W = reinterpret_cast<const bf16_t*>(w8.as<uint8_t>() + row_off * K); g.w_scale = wsc.as<float>() + row_off;
+      } else {
+        g.A = abf16; g.W = wb.as<bf16_t>() + row_off * K;
+      }
+    };
     RC_TRY(pbegin(PC_LN, q));
-    HIP_TRY(launch_ln_mod(xres, hbf, rows, d, tab, tab_stride, base + d, base, step, q));
+    if (fp8) HIP_TRY(launch_ln_mod_f8(xres, h8, hmx, rows, d, tab, tab_stride, base + d, base, step, q));
+    else HIP_TRY(launch_ln_mod(xres, hbf, rows, d, tab, tab_stride, base + d, base, step, q));
     RC_TRY(pend(q));
     RC_TRY(pbegin(PC_GEMM_QK, q));
-    g.A = hbf; g.W = w.wqkv.as<bf16_t>(); g.bias = w.bqkv.as<float>(); g.N = 2 * in; g.K = d; g.n_valid = 2 * in;
+    operands(hbf, h8, hmx, w.wqkv, w.wqkv8, w.sqkv, 0, d);
+    g.bias = w.bqkv.as<float>(); g.N = 2 * in; g.K = d; g.n_valid = 2 * in;
     g.kv_len = nullptr;
     HIP_TRY(launch_gemm_bf16(EPI_QK_ROPE, g, q));
     RC_TRY(pend(q));
     RC_TRY(pbegin(PC_GEMM_V, q));
-    g.W = w.wqkv.as<bf16_t>() + (size_t)2 * in * d; g.bias = w.bqkv.as<float>() + 2 * in; g.N = in; g.n_valid = in;
+    operands(hbf, h8, hmx, w.wqkv, w.wqkv8, w.sqkv, (size_t)2 * in, d);
+    g.bias = w.bqkv.as<float>() + 2 * in; g.N = in; g.n_valid = in;
     HIP_TRY(launch_gemm_bf16(EPI_V_T, g, q));
     RC_TRY(pend(q));
     RC_TRY(pbegin(PC_ATTN, q));
+    at.out8 = a8; at.out_mx = amx;
     HIP_TRY(launch_attention(at, q));
     RC_TRY(pend(q));
     RC_TRY(pbegin(PC_GEMM_OUT, q));
-    g.A = abf; g.W = w.wo.as<bf16_t>(); g.bias = w.bo; g.N = d; g.K = in; g.n_valid = d;
+    operands(abf, a8, amx, w.wo, w.wo8, w.so, 0, in);
+    g.bias = w.bo; g.N = d; g.K = in; g.n_valid = d;
     g.out_f32 = xres; g.ldc = d; g.gate_off = base + 2 * d; g.kv_len = has_len ? d_len.as<int>() : nullptr;
     HIP_TRY(launch_gemm_bf16(EPI_GATE_RES, g, q));
     RC_TRY(pend(q));
     RC_TRY(pbegin(PC_LN, q));
-    HIP_TRY(launch_ln_mod(xres, hbf, rows, d, tab, tab_stride, base + 4 * d, base + 3 * d, step, q));
+    if (fp8) HIP_TRY(launch_ln_mod_f8(xres, h8, hmx, rows, d, tab, tab_stride, base + 4 * d, base + 3 * d, step, q));
+    else HIP_TRY(launch_ln_mod(xres, hbf, rows, d, tab, tab_stride, base + 4 * d, base + 3 * d, step, q));
     RC_TRY(pend(q));
     RC_TRY(pbegin(PC_GEMM_FF1, q));
-    g.A = hbf; g.W = w.w1.as<bf16_t>(); g.bias = w.b1; g.N = ffd; g.K = d; g.n_valid = ffd;
-    g.out_bf16 = ffb; g.ldc = ffd; g.kv_len = nullptr;
-    HIP_TRY(launch_gemm_bf16(EPI_BIAS_GELU_BF16, g, q));
+    operands(hbf, h8, hmx, w.w1, w.w18, w.s1, 0, d);
+    g.bias = w.b1; g.N = ffd; g.K = d; g.n_valid = ffd;
+    g.out_bf16 = ffb; g.out_f8 = ff8; g.out_mx = ffmx; g.ldc = ffd; g.kv_len = nullptr;
+    HIP_TRY(launch_gemm_bf16(fp8 ? EPI_BIAS_GELU_F8 : EPI_BIAS_GELU_BF16, g, q));
     RC_TRY(pend(q));
     RC_TRY(pbegin(PC_GEMM_FF2, q));
-    g.A = ffb; g.W = w.w2.as<bf16_t>(); g.bias = w.b2; g.N = d; g.K = ffd; g.n_valid = d;
+    operands(ffb, ff8, ffmx, w.w2, w.w28, w.s2, 0, ffd);
+    g.bias = w.b2; g.N = d; g.K = ffd; g.n_valid = d;
     g.out_f32 = xres; g.ldc = d; g.gate_off = base + 5 * d;
     HIP_TRY(launch_gemm_bf16(EPI_GATE_RES, g, q));
     RC_TRY(pend(q));
@@ -506,7 +583,7 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
   for (int l = 0; l < cfg.depth; ++l)
     for (int ln = 0; ln < lanes; ++ln) RC_TRY(block(l, ln));
   for (int ln = 0; ln < lanes; ++ln) RC_TRY(head(ln));
-  if (lanes == 2) {
+  if (fork) {
     HIP_TRY(hipEventRecord(ev_join, s2));
     HIP_TRY(hipStreamWaitEvent(s, ev_join, 0));
   }
@@ -544,7 +621,7 @@ int lemas_dit::solve(const lemas_sample_args* a, hipStream_t s) {
       graph_generation = DevBuf::generation;
     }
     char key[96];
-    snprintf(key, sizeof key, "B%d_N%d_cfg%d_len%d_dual%d", B, N, (int)use_cfg, (int)has_len, (int)dual);
+    snprintf(key, sizeof key, "B%d_N%d_cfg%d_len%d_dual%d_f8%d", B, N, (int)use_cfg, (int)has_len, (int)dual, (int)fp8);
     auto it = graphs.find(key);
     if (it == graphs.end()) {
       hipGraph_t graph = nullptr;
@@ -608,6 +685,11 @@ int lemas_dit_set_option(lemas_dit* m, const char* key, int64_t value) {
     m->dual = value != 0;
     for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.second);
     m->graphs.clear();
+    return 0;
+  }
+  if (!strcmp(key, "fp8")) {      // block GEMMs on the MXFP8 path; takes effect at the next prepare()
+    if (m->fp8 != (value != 0)) m->prepared = false;
+    m->fp8 = value != 0;
     return 0;
   }
   if (!strcmp(key, "profile")) {

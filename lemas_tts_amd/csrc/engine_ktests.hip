@@ -114,6 +114,69 @@ int lemas_k_linear_f32(const float* A, const float* W, const float* bias, float*
   return 0;
 }
 
+int lemas_k_mx_quant(const float* x, int32_t M, int32_t K, uint8_t* out8, uint8_t* mx, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(launch_mx_quant_rows(x, M, K, out8, mx, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return 0;
+}
+
+int lemas_k_w_quant_f8(const float* w, int32_t N, int32_t K, uint8_t* out8, float* scale, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(launch_w_quant_f8(w, N, K, out8, scale, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return 0;
+}
+
+int lemas_k_ln_mod_f8(const float* x, const float* scale, const float* shift, uint8_t* out8, uint8_t* mx, int32_t M, int32_t D,
+                      void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  Scratch sc;
+  float* tab = sc.get<float>((size_t)2 * D);
+  if (!tab) { set_error("lemas_k_ln_mod_f8: out of memory"); return LEMAS_E_STATE; }
+  HIP_TRY(hipMemcpyAsync(tab, scale, (size_t)D * 4, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipMemcpyAsync(tab + D, shift, (size_t)D * 4, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(launch_ln_mod_f8(x, out8, mx, M, D, tab, 0, 0, D, nullptr, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return 0;
+}
+
+int lemas_k_linear_f8(const float* A, const float* W, const float* bias, float* out, int32_t M, int32_t N, int32_t K, int32_t act,
+                      uint8_t* out8, uint8_t* outmx, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (K % 128 != 0) { set_error("lemas_k_linear_f8: K must be a multiple of 128"); return LEMAS_E_ARG; }
+  if (act == 2 && (N % 128 != 0 || !out8 || !outmx)) { set_error("lemas_k_linear_f8: act 2 needs N %% 128 == 0 and out8/outmx"); return LEMAS_E_ARG; }
+  Scratch sc;
+  const int Np = (N + 127) & ~127;
+  uint8_t* a8 = sc.get<uint8_t>((size_t)M * K);
+  uint8_t* amx = sc.get<uint8_t>((size_t)M * (K / 32));
+  uint8_t* w8 = sc.get<uint8_t>((size_t)Np * K);
+  float* wsc = sc.get<float>(Np);
+  float* b = sc.get<float>(Np);
+  bf16_t* ob = sc.get<bf16_t>((size_t)M * N);
+  if (!a8 || !amx || !w8 || !wsc || !b || !ob) { set_error("lemas_k_linear_f8: out of memory"); return LEMAS_E_STATE; }
+  HIP_TRY(launch_mx_quant_rows(A, M, K, a8, amx, s));
+  HIP_TRY(launch_w_quant_f8(W, N, K, w8, wsc, s));
+  if (bias) HIP_TRY(hipMemcpyAsync(b, bias, (size_t)N * 4, hipMemcpyDeviceToDevice, s));
+  GemmParams p{};
+  p.A = reinterpret_cast<const bf16_t*>(a8); p.W = reinterpret_cast<const bf16_t*>(w8); p.bias = b; p.M = M; p.N = Np; p.K = K;
+  p.n_valid = N; p.ldc = N; p.seq_pitch = M; p.seq_valid = M; p.batch = 1;
+  p.f8 = 1; p.a_mx = amx; p.w_scale = wsc;
+  if (act == 1) {
+    p.out_bf16 = ob;
+    HIP_TRY(launch_gemm_bf16(EPI_BIAS_GELU_BF16, p, s));
+    hipLaunchKernelGGL(widen_kernel, dim3(1024), dim3(256), 0, s, ob, out, (size_t)M * N);
+  } else if (act == 2) {
+    p.out_f8 = out8; p.out_mx = outmx;
+    HIP_TRY(launch_gemm_bf16(EPI_BIAS_GELU_F8, p, s));
+  } else {
+    p.out_f32 = out;
+    HIP_TRY(launch_gemm_bf16(EPI_BIAS_F32, p, s));
+  }
+  HIP_TRY(hipStreamSynchronize(s));
+  return 0;
+}
+
 int lemas_k_attention(const float* q, const float* k, const float* v, const int32_t* seq_len, float* out, int32_t B,
                       int32_t H, int32_t N, void* stream) {
   hipStream_t s = (hipStream_t)stream;
@@ -184,7 +247,9 @@ extern "C" int lemas_k_bench(const char* what, int32_t M, int32_t N, int32_t K, 
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0));
   HIP_TRY(hipEventCreate(&e1));
-  const std::string w(what);
+  std::string w(what);
+  const bool f8 = w.rfind("f8_", 0) == 0;
+  if (f8) w = w.substr(3);
   float ms = 0.f;
   int rc = 0;
   auto time_it = [&](auto&& fn) -> int {
@@ -196,7 +261,7 @@ extern "C" int lemas_k_bench(const char* what, int32_t M, int32_t N, int32_t K, 
     HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
     return 0;
   };
-  if (w == "gemm_gelu" || w == "gemm_gate" || w == "gemm_qk" || w == "gemm_v" || w == "gemm_f32out" || w == "gemm_none" || w == "gemm_nodma") {
+  if (w == "gemm_gelu" || w == "gemm_gelu8" || w == "gemm_gate" || w == "gemm_qk" || w == "gemm_v" || w == "gemm_f32out" || w == "gemm_none" || w == "gemm_nodma") {
     const int Np = (N + 127) & ~127;
     bf16_t* a = sc.get<bf16_t>((size_t)M * K);
     bf16_t* wt = sc.get<bf16_t>((size_t)Np * K);
@@ -219,7 +284,16 @@ extern "C" int lemas_k_bench(const char* what, int32_t M, int32_t N, int32_t K, 
     p.A = a; p.W = wt; p.bias = b; p.M = M; p.N = Np; p.K = K; p.n_valid = N; p.ldc = N; p.out_bf16 = ob; p.out_f32 = of;
     p.tab = tab; p.tab_stride = 0; p.gate_off = 0; p.step_idx = step; p.seq_pitch = M; p.seq_valid = M; p.batch = 1; p.heads = 16; p.npad = npad;
     p.q = q; p.k = k; p.vt = vt; p.rope_cos = rc_; p.rope_sin = rs_;
-    const int epi = w == "gemm_gelu" ? EPI_BIAS_GELU_BF16 : w == "gemm_gate" ? EPI_GATE_RES : w == "gemm_qk" ? EPI_QK_ROPE : w == "gemm_v" ? EPI_V_T : (w == "gemm_none" || w == "gemm_nodma") ? EPI_NONE : EPI_BIAS_F32;
+    if (f8) {
+      uint8_t* amx = sc.get<uint8_t>((size_t)M * (K / 32));
+      float* wsc = sc.get<float>(Np);
+      uint8_t* o8 = sc.get<uint8_t>((size_t)M * Np);
+      uint8_t* omx = sc.get<uint8_t>((size_t)M * (Np / 32));
+      if (!amx || !wsc || !o8 || !omx) { set_error("bench: out of memory"); return LEMAS_E_STATE; }
+      HIP_TRY(hipMemsetAsync(amx, 127, (size_t)M * (K / 32), s));
+      p.f8 = 1; p.a_mx = amx; p.w_scale = wsc; p.out_f8 = o8; p.out_mx = omx;
+    }
+    const int epi = w == "gemm_gelu8" ? EPI_BIAS_GELU_F8 : w == "gemm_gelu" ? EPI_BIAS_GELU_BF16 : w == "gemm_gate" ? EPI_GATE_RES : w == "gemm_qk" ? EPI_QK_ROPE : w == "gemm_v" ? EPI_V_T : (w == "gemm_none" || w == "gemm_nodma") ? EPI_NONE : EPI_BIAS_F32;
     if (w == "gemm_nodma") p.n_valid = -1;
     if ((epi == EPI_QK_ROPE && N != 2048) || (epi == EPI_V_T && N != 1024)) { set_error("bench: gemm_qk needs N = 2048, gemm_v N = 1024"); return LEMAS_E_ARG; }
     rc = time_it([&]() { return launch_gemm_bf16_variant(epi, p, variant, s); });

@@ -73,6 +73,11 @@ struct SlabF32 {    // [WTM rows][WTN f32] + 16 B pad per row
   static constexpr int PITCH = WTN * 4 + 16, BYTES = WTM * PITCH, CPR = WTN * 4 / 16, RPI = 64 / CPR, ITERS = WTM / RPI;
 };
 
+template <int WTM, int WTN>
+struct SlabF8 {     // [WTM rows][WTN e4m3] + 16 B pad per row
+  static constexpr int PITCH = WTN + 16, BYTES = WTM * PITCH, CPR = WTN / 16, RPI = 64 / CPR, ITERS = WTM / RPI;
+};
+
 template <int EPI, int TI, int TJ>
 __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x16 (&acc)[TI][TJ], char* slab, int mw, int nw,
                                               int lane) {
@@ -177,6 +182,44 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x16 (&acc)
       o[6] = (bf16_t)(b.z * c.w - b.w * sn.w); o[7] = (bf16_t)(b.w * c.w + b.z * sn.w);
       if (live) store_wt_b128(base + ((size_t)b2 * p.heads * p.seq_pitch + pos) * 64, __builtin_bit_cast(u32x4, o));
     }
+  } else if (EPI == EPI_BIAS_GELU_F8) {
+    // MXFP8 output: a 32-column block of one row lives in two lanes (l, l ^ 32) x 16 registers
+    using S = SlabF8<WTM, WTN>;
+    const int mxld = p.ldc >> 5;
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+      const int m = mw + i * 32 + l31;
+      const int b2 = m / p.seq_pitch, pos = m - b2 * p.seq_pitch;
+      const bool live = m < p.M && pos < p.seq_valid;
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        float v[16];
+        float amax = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 bias = *reinterpret_cast<const float4*>(p.bias + nw + j * 32 + 8 * g + 4 * hi);
+          v[4 * g + 0] = gelu_tanh_f(acc[i][j][4 * g + 0] + bias.x); v[4 * g + 1] = gelu_tanh_f(acc[i][j][4 * g + 1] + bias.y);
+          v[4 * g + 2] = gelu_tanh_f(acc[i][j][4 * g + 2] + bias.z); v[4 * g + 3] = gelu_tanh_f(acc[i][j][4 * g + 3] + bias.w);
+          amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[4 * g + 0]), fabsf(v[4 * g + 1]))), fmaxf(fabsf(v[4 * g + 2]), fabsf(v[4 * g + 3])));
+        }
+        amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+        const int e = mx_exponent(amax);
+        const float inv = mx_inv_scale(e);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<unsigned int*>(slab + (i * 32 + l31) * S::PITCH + j * 32 + 8 * g + 4 * hi) =
+              pack_fp8x4(v[4 * g + 0] * inv, v[4 * g + 1] * inv, v[4 * g + 2] * inv, v[4 * g + 3] * inv);
+        if (hi == 0 && live) p.out_mx[(size_t)m * mxld + ((nw + j * 32) >> 5)] = (uint8_t)(e + 127);
+      }
+    }
+    const int rr = lane / S::CPR, ch = lane % S::CPR;
+#pragma unroll
+    for (int it = 0; it < S::ITERS; ++it) {
+      const int m = mw + it * S::RPI + rr;
+      const int b2 = m / p.seq_pitch, pos = m - b2 * p.seq_pitch;
+      const u32x4 d = *reinterpret_cast<const u32x4*>(slab + (it * S::RPI + rr) * S::PITCH + ch * 16);
+      if (m < p.M && pos < p.seq_valid) store_wt_b128(p.out_f8 + (size_t)m * p.ldc + nw + ch * 16, d);
+    }
   } else {   // bf16 outputs: plain, GELU-tanh
     using S = SlabBf16<WTM, WTN>;
 #pragma unroll
@@ -244,18 +287,30 @@ template <int EPI, int WTM, int WTN>
 constexpr int slab_bytes() {
   return (EPI == EPI_GATE_RES || EPI == EPI_BIAS_F32 || EPI == EPI_QK_ROPE) ? SlabF32<WTM, WTN>::BYTES
          : (EPI == EPI_V_T)                           ? SlabBf16<WTN, WTM>::BYTES
+         : (EPI == EPI_BIAS_GELU_F8)                  ? SlabF8<WTM, WTN>::BYTES
                                                       : SlabBf16<WTM, WTN>::BYTES;
 }
 
-template <int EPI, int TBM, int TBN, int NSTAGE, int NWM, int NWN, int SPREAD, bool SWAP>
+template <bool F8> struct FragT { using type = bf16x8; };
+template <> struct FragT<true> { using type = i32x8; };
+
+// F8: operands are e4m3 bytes (a 128-B LDS row = 128 K elements), the MFMA is v_mfma_scale_f32_32x32x64_f8f6f4 (2x the
+// bf16 rate) and the activation tile carries MX block scales: one dword (4 E8M0 bytes = the 4 K-blocks of the tile)
+// per row, brought in by one extra 4-B-per-lane LDS-DMA per wave and tile.  Operand layout of the instruction
+// (probed on the hardware, tools/exp/mx_probe.hip): lane (i = l&31, h = l>>5) holds row i; registers 0-3 are K
+// 16h..16h+15 and registers 4-7 are K 32+16h..; the scale of K-block beta (32 K) comes from lane i + 32 beta.
+template <int EPI, int TBM, int TBN, int NSTAGE, int NWM, int NWN, int SPREAD, bool SWAP, bool F8>
 __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, int m0, int n0) {
+  using frag_t = typename FragT<F8>::type;
   constexpr int NW = NWM * NWN;                       // waves per workgroup
   constexpr int WTM = TBM / NWM, WTN = TBN / NWN;     // wave tile
   constexpr int TI = WTM / 32, TJ = WTN / 32;         // 32x32 MFMA tiles per wave
-  constexpr int A_BYTES = TBM * 128, STAGE = (TBM + TBN) * 128;
+  constexpr int A_BYTES = TBM * 128, SC_OFF = (TBM + TBN) * 128, STAGE = SC_OFF + (F8 ? TBM * 4 : 0);
   constexpr int A_PW = TBM / 8 / NW, B_PW = TBN / 8 / NW;  // 1-KiB DMA instructions per wave per tile
-  constexpr int PW = A_PW + B_PW;
+  constexpr int PW = A_PW + B_PW + (F8 ? 1 : 0);           // + the scale piece
+  constexpr int KS = F8 ? 2 : 4;                           // MFMA k-steps per 128-B K tile
   static_assert((TBM / 8) % NW == 0 && (TBN / 8) % NW == 0, "DMA pieces must divide over the waves");
+  static_assert(!F8 || SPREAD != 2, "the mid-barrier loop is bf16 only");
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -264,29 +319,41 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, int m
 
   // DMA source pointers: instruction q of this wave covers LDS rows 8 (wave + NW q) .. +7; lane -> (row, phys chunk)
   const int lr = lane >> 3, lp = lane & 7;
-  const bf16_t* asrc[A_PW];
-  const bf16_t* wsrc[B_PW];
+  const size_t rowb = F8 ? (size_t)p.K : (size_t)p.K * 2;   // bytes per operand row
+  const char* asrc[A_PW];
+  const char* wsrc[B_PW];
 #pragma unroll
   for (int q = 0; q < A_PW; ++q) {
     const int r = 8 * (wave + NW * q) + lr;
     int am = m0 + r;
     am = am < p.M ? am : p.M - 1;  // clamp: out-of-range rows are computed and discarded
-    asrc[q] = p.A + (size_t)am * p.K + ((lp ^ ((r >> 1) & 7)) << 3);
+    asrc[q] = reinterpret_cast<const char*>(p.A) + (size_t)am * rowb + ((lp ^ ((r >> 1) & 7)) << 4);
   }
 #pragma unroll
   for (int q = 0; q < B_PW; ++q) {
     const int r = 8 * (wave + NW * q) + lr;
-    wsrc[q] = p.W + (size_t)(n0 + r) * p.K + ((lp ^ ((r >> 1) & 7)) << 3);
+    wsrc[q] = reinterpret_cast<const char*>(p.W) + (size_t)(n0 + r) * rowb + ((lp ^ ((r >> 1) & 7)) << 4);
   }
-  // piece x of a tile: x < A_PW -> A rows, else W rows; each piece is one 1-KiB global_load_lds_dwordx4
+  // MX scales: every wave copies the dwords of 64 rows (row group wave % (TBM/64); duplicates write identical bytes)
+  const int sgrp = wave % (TBM / 64);
+  const char* ssrc = nullptr;
+  if (F8) {
+    int am = m0 + sgrp * 64 + lane;
+    am = am < p.M ? am : p.M - 1;
+    ssrc = reinterpret_cast<const char*>(p.a_mx) + (size_t)am * (p.K >> 5);
+  }
+  // piece x of a tile: x < A_PW -> A rows, then W rows (one 1-KiB global_load_lds_dwordx4 each), then the scale dwords
   auto issue_piece = [&](int stage, int kt, int x) {
     char* base = smem + stage * STAGE + wave * 1024;
     if (x < A_PW)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[x] + kt * BK),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[x] + kt * 128),
                                        (__attribute__((address_space(3))) void*)(base + x * (NW * 1024)), 16, 0, 0);
-    else
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[x - A_PW] + kt * BK),
+    else if (x < A_PW + B_PW)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[x - A_PW] + kt * 128),
                                        (__attribute__((address_space(3))) void*)(base + A_BYTES + (x - A_PW) * (NW * 1024)), 16, 0, 0);
+    else
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ssrc + kt * 4),
+                                       (__attribute__((address_space(3))) void*)(smem + stage * STAGE + SC_OFF + sgrp * 256), 4, 0, 0);
   };
   auto issue = [&](int stage, int kt) {
 #pragma unroll
@@ -301,18 +368,36 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, int m
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = p.K / BK;
+  const int nk = (int)(rowb >> 7);
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s)
     if (s < nk) issue(s, s);
 
-  auto frag_a = [&](const char* sA, int kk, int t) {
-    return *reinterpret_cast<const bf16x8*>(sA + lds_off(wm * WTM + t * 32 + l31, kk * 2 + hi));
+  auto ldfrag = [&](const char* sX, int row, int kk) -> frag_t {
+    if constexpr (F8) {
+      const u32x4 lo = *reinterpret_cast<const u32x4*>(sX + lds_off(row, kk * 4 + hi));
+      const u32x4 up = *reinterpret_cast<const u32x4*>(sX + lds_off(row, kk * 4 + 2 + hi));
+      i32x8 f;
+      f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = up[0]; f[5] = up[1]; f[6] = up[2]; f[7] = up[3];
+      return f;
+    } else {
+      return *reinterpret_cast<const bf16x8*>(sX + lds_off(row, kk * 2 + hi));
+    }
   };
-  auto frag_b = [&](const char* sB, int kk, int t) {
-    return *reinterpret_cast<const bf16x8*>(sB + lds_off(wn * WTN + t * 32 + l31, kk * 2 + hi));
+  auto frag_a = [&](const char* sA, int kk, int t) { return ldfrag(sA, wm * WTM + t * 32 + l31, kk); };
+  auto frag_b = [&](const char* sB, int kk, int t) { return ldfrag(sB, wn * WTN + t * 32 + l31, kk); };
+  // one MFMA of k-step kk; asc = this lane's scale dword for the A row-fragment, already shifted by 8 hi
+  auto mfma1 = [&](const frag_t& fa, const frag_t& fb, f32x16& c, int kk, int asc) {
+    if constexpr (F8) {
+      if (SWAP) c = kk == 0 ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb, fa, c, 0, 0, 0, 127, 0, asc)
+                            : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb, fa, c, 0, 0, 0, 127, 2, asc);
+      else c = kk == 0 ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa, fb, c, 0, 0, 0, asc, 0, 127)
+                       : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa, fb, c, 0, 0, 2, asc, 0, 127);
+    } else {
+      c = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb, fa, c, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, c, 0, 0, 0);
+    }
   };
-  if (SPREAD == 2) {
+  if constexpr (SPREAD == 2 && !F8) {
     // Mid-iteration barrier: the wait + barrier that publishes tile kt+1 sits between k-steps 1 and 2 of tile kt, so the
     // first fragments of tile kt+1 are read under the last MFMAs of tile kt and no iteration opens with every wave
     // waiting on LDS at once (with the barrier at the top, all 8 waves issue their reads together and the matrix pipe
@@ -411,33 +496,33 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, int m
       const char* sB = sA + A_BYTES;
       // fragments are double-buffered in registers: the ds_read_b128 of k-step kk+1 are in flight under the MFMAs of kk;
       // sched_barrier pins that order (the scheduler otherwise sinks the reads next to their consumers)
-      bf16x8 af[2][TI], bf[2][TJ];
+      frag_t af[2][TI], bf[2][TJ];
+      int asc[TI];
   #pragma unroll
-      for (int t = 0; t < TI; ++t) af[0][t] = *reinterpret_cast<const bf16x8*>(sA + lds_off(wm * WTM + t * 32 + l31, hi));
+      for (int t = 0; t < TI; ++t) {
+        af[0][t] = frag_a(sA, 0, t);
+        asc[t] = F8 ? (*reinterpret_cast<const int*>(sA + SC_OFF + (wm * WTM + t * 32 + l31) * 4) >> (8 * hi)) : 0;
+      }
   #pragma unroll
-      for (int t = 0; t < TJ; ++t) bf[0][t] = *reinterpret_cast<const bf16x8*>(sB + lds_off(wn * WTN + t * 32 + l31, hi));
+      for (int t = 0; t < TJ; ++t) bf[0][t] = frag_b(sB, 0, t);
   #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        if (kk < 3) {
+      for (int kk = 0; kk < KS; ++kk) {
+        if (kk < KS - 1) {
   #pragma unroll
-          for (int t = 0; t < TI; ++t)
-            af[(kk + 1) & 1][t] = *reinterpret_cast<const bf16x8*>(sA + lds_off(wm * WTM + t * 32 + l31, (kk + 1) * 2 + hi));
+          for (int t = 0; t < TI; ++t) af[(kk + 1) & 1][t] = frag_a(sA, kk + 1, t);
   #pragma unroll
-          for (int t = 0; t < TJ; ++t)
-            bf[(kk + 1) & 1][t] = *reinterpret_cast<const bf16x8*>(sB + lds_off(wn * WTN + t * 32 + l31, (kk + 1) * 2 + hi));
+          for (int t = 0; t < TJ; ++t) bf[(kk + 1) & 1][t] = frag_b(sB, kk + 1, t);
         }
         if (SPREAD && refill) {   // DMA issue slots hidden behind the MFMAs instead of a burst after the barrier
   #pragma unroll
-          for (int x = (PW * kk) / 4; x < (PW * (kk + 1)) / 4; ++x) issue_piece(ns, nt, x);
+          for (int x = (PW * kk) / KS; x < (PW * (kk + 1)) / KS; ++x) issue_piece(ns, nt, x);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (PRIO) __builtin_amdgcn_s_setprio(1);
   #pragma unroll
         for (int i = 0; i < TI; ++i)
   #pragma unroll
-          for (int j = 0; j < TJ; ++j)
-            acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[kk & 1][j], af[kk & 1][i], acc[i][j], 0, 0, 0)
-                             : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TJ; ++j) mfma1(af[kk & 1][i], bf[kk & 1][j], acc[i][j], kk, asc[i]);
         if (PRIO) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -455,6 +540,30 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, int m
     if (t == 123.456f) p.out_f32[0] = t;
     return;
   }
+  if constexpr (F8) {   // per-output-channel weight scale
+    const float* ws = p.w_scale + n0 + wn * WTN;
+    if (SWAP) {
+#pragma unroll
+      for (int j = 0; j < TJ; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 w4 = *reinterpret_cast<const float4*>(ws + j * 32 + 8 * g + 4 * hi);
+#pragma unroll
+          for (int i = 0; i < TI; ++i) {
+            acc[i][j][4 * g + 0] *= w4.x; acc[i][j][4 * g + 1] *= w4.y; acc[i][j][4 * g + 2] *= w4.z; acc[i][j][4 * g + 3] *= w4.w;
+          }
+        }
+    } else {
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        const float w1 = ws[j * 32 + l31];
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] *= w1;
+      }
+    }
+  }
   __syncthreads();   // every wave is done with the ring: its LDS becomes the epilogue slabs
   // one 32-row block of the wave tile at a time through a small wave-private slab (LDS ops of a wave execute in order, so
   // the slab can be rewritten right after it was read): keeps the kernel's LDS footprint = the ring, not ring + big slabs
@@ -467,33 +576,50 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, int m
   }
 }
 
-template <int EPI, int TBM, int TBN, int NSTAGE, int NWM, int NWN, int SPREAD>
+template <int EPI, int TBM, int TBN, int NSTAGE, int NWM, int NWN, int SPREAD, bool F8 = false>
 __global__ __launch_bounds__(64 * NWM * NWN) void gemm_bf16_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tiles_n = p.N / TBN;
   const int lid = xcd_tile_id();
   const int m0 = (lid / tiles_n) * TBM, n0 = (lid % tiles_n) * TBN;
-  gemm_body<EPI, TBM, TBN, NSTAGE, NWM, NWN, SPREAD, EPI != EPI_V_T>(p, smem, m0, n0);
+  gemm_body<EPI, TBM, TBN, NSTAGE, NWM, NWN, SPREAD, EPI != EPI_V_T, F8>(p, smem, m0, n0);
 }
 
-template <int EPI, int TBM, int TBN, int NSTAGE, int NWM, int NWN, int SPREAD>
+template <int EPI, int TBM, int TBN, int NSTAGE, int NWM, int NWN, int SPREAD, bool F8 = false>
 hipError_t launch_cfg(const GemmParams& p, hipStream_t s) {
   if (p.N % TBN != 0) return hipErrorInvalidValue;
-  constexpr int ring = NSTAGE * (TBM + TBN) * 128;
+  constexpr int ring = NSTAGE * ((TBM + TBN) * 128 + (F8 ? TBM * 4 : 0));
   constexpr int slabs = NWM * NWN * slab_bytes<EPI, 32, TBN / NWN>();
   constexpr int lds = ring > slabs ? ring : slabs;
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   if (lds > 65536 && !attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<EPI, TBM, TBN, NSTAGE, NWM, NWN, SPREAD>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<EPI, TBM, TBN, NSTAGE, NWM, NWN, SPREAD, F8>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   const int tiles_m = (p.M + TBM - 1) / TBM, tiles_n = p.N / TBN;
-  hipLaunchKernelGGL((gemm_bf16_kernel<EPI, TBM, TBN, NSTAGE, NWM, NWN, SPREAD>), dim3(tiles_m * tiles_n),
+  hipLaunchKernelGGL((gemm_bf16_kernel<EPI, TBM, TBN, NSTAGE, NWM, NWN, SPREAD, F8>), dim3(tiles_m * tiles_n),
                      dim3(64 * NWM * NWN), lds, s, p);
   return hipGetLastError();
+}
+
+template <int EPI>
+hipError_t dispatch_f8(const GemmParams& p, int variant, hipStream_t s) {
+  if (variant == 0) {
+    static const int force = getenv("LEMAS_GEMM_F8") ? atoi(getenv("LEMAS_GEMM_F8")) : 0;   // development A/B switch
+    const long t256 = (long)((p.M + 255) / 256) * (p.N / 128), t128 = (long)((p.M + 127) / 128) * (p.N / 128);
+    variant = t256 >= 200 ? 6 : t128 >= 200 ? 10 : 4;
+    if (force) variant = force;
+  }
+  switch (variant) {
+    case 4: return launch_cfg<EPI, 128, 64, 3, 2, 2, 1, true>(p, s);
+    case 6: return launch_cfg<EPI, 256, 128, 3, 4, 2, 1, true>(p, s);
+    case 10: return launch_cfg<EPI, 128, 128, 3, 2, 4, 1, true>(p, s);
+    case 11: return launch_cfg<EPI, 128, 128, 4, 2, 4, 1, true>(p, s);
+    default: return hipErrorInvalidValue;
+  }
 }
 
 template <int EPI>
@@ -530,6 +656,19 @@ hipError_t dispatch(const GemmParams& p, int variant, hipStream_t s) {
 
 hipError_t launch_gemm_bf16_variant(int epi, const GemmParams& p, int variant, hipStream_t s) {
   if (p.K % BK != 0 || p.N % 128 != 0 || p.M <= 0 || p.seq_pitch <= 0) return hipErrorInvalidValue;
+  if (p.f8) {
+    if (p.K % 128 != 0 || !p.a_mx || !p.w_scale) return hipErrorInvalidValue;
+    switch (epi) {
+      case EPI_BIAS_GELU_BF16: return dispatch_f8<EPI_BIAS_GELU_BF16>(p, variant, s);
+      case EPI_BIAS_GELU_F8: return dispatch_f8<EPI_BIAS_GELU_F8>(p, variant, s);
+      case EPI_BIAS_F32: return dispatch_f8<EPI_BIAS_F32>(p, variant, s);
+      case EPI_GATE_RES: return dispatch_f8<EPI_GATE_RES>(p, variant, s);
+      case EPI_QK_ROPE: return dispatch_f8<EPI_QK_ROPE>(p, variant, s);
+      case EPI_V_T: return dispatch_f8<EPI_V_T>(p, variant, s);
+      case EPI_NONE: return dispatch_f8<EPI_NONE>(p, variant, s);
+    }
+    return hipErrorInvalidValue;
+  }
   switch (epi) {
     case EPI_BIAS_BF16: return dispatch<EPI_BIAS_BF16>(p, variant, s);
     case EPI_BIAS_GELU_BF16: return dispatch<EPI_BIAS_GELU_BF16>(p, variant, s);

