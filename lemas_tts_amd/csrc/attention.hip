@@ -500,7 +500,10 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
   // measured (tools/kbench_attn.py): the split-KV kernel wins at every size tried (B=1: 47 vs 53 us; BH=256: 136 vs 154 us)
   const bool split = p.variant != 1;
   if (p.out8 && (!split || !p.out_mx)) return hipErrorInvalidValue;   // the MXFP8 epilogue lives in the split-KV kernel
-  if (split) hipLaunchKernelGGL(attn_fwd_splitkv_kernel, grid, dim3(512), 0, s, p);
+  if (p.ev_start) {
+    if (split) hipExtLaunchKernelGGL(attn_fwd_splitkv_kernel, grid, dim3(512), 0, s, p.ev_start, p.ev_stop, 0, p);
+    else hipExtLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, s, p.ev_start, p.ev_stop, 0, p);
+  } else if (split) hipLaunchKernelGGL(attn_fwd_splitkv_kernel, grid, dim3(512), 0, s, p);
   else hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, s, p);
   return hipGetLastError();
 }

@@ -1,6 +1,7 @@
 // Shared device helpers and internal launch prototypes for liblemas_hip.so (gfx950 / CDNA4 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 typedef __bf16 bf16_t;
@@ -116,6 +117,9 @@ struct GemmParams {
   const float* w_scale;   // [Nw]
   uint8_t* out_f8;        // EPI_BIAS_GELU_F8: [M][ldc] e4m3
   uint8_t* out_mx;        //                   [M][ldc/32]
+  // profiling: when set, the launch goes through hipExtLaunchKernelGGL, which stamps these events with the dispatch's own
+  // begin / end times (what rocprofv3 --kernel-trace reports), instead of bracketing the launch with stream events
+  hipEvent_t ev_start, ev_stop;
 };
 
 // ---- internal launchers (one per .hip translation unit) ----------------------------------------
@@ -134,6 +138,7 @@ struct AttnParams {
   float scale;
   uint8_t* out8;     // fp8 path: when set, the output is written as MXFP8 here ([B2*pitch, H*64] e4m3) instead of `out`
   uint8_t* out_mx;   //           [B2*pitch, H*2] E8M0
+  hipEvent_t ev_start, ev_stop;   // profiling: kernel begin / end stamps (see GemmParams)
 };
 hipError_t launch_attention(const AttnParams& p, hipStream_t s);
 

@@ -702,8 +702,12 @@ hipError_t launch_cfg(const GemmParams& p, hipStream_t s) {
     attr_set = true;
   }
   const int tiles_m = (p.M + TBM - 1) / TBM, tiles_n = p.N / TBN;
-  hipLaunchKernelGGL((gemm_bf16_kernel<EPI, TBM, TBN, NSTAGE, NWM, NWN, SPREAD, F8>), dim3(tiles_m * tiles_n),
-                     dim3(64 * NWM * NWN), lds, s, p);
+  if (p.ev_start)
+    hipExtLaunchKernelGGL((gemm_bf16_kernel<EPI, TBM, TBN, NSTAGE, NWM, NWN, SPREAD, F8>), dim3(tiles_m * tiles_n),
+                          dim3(64 * NWM * NWN), lds, s, p.ev_start, p.ev_stop, 0, p);
+  else
+    hipLaunchKernelGGL((gemm_bf16_kernel<EPI, TBM, TBN, NSTAGE, NWM, NWN, SPREAD, F8>), dim3(tiles_m * tiles_n),
+                       dim3(64 * NWM * NWN), lds, s, p);
   return hipGetLastError();
 }
 
