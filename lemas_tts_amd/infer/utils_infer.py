@@ -186,10 +186,13 @@ def infer_batch_process(ref_audio, ref_text, gen_text_batches, model_obj, vocode
                         target_rms=0.1, cross_fade_duration=0.15, nfe_step=32, cfg_strength=2.0, sway_sampling_coef=-1,
                         use_acc_grl=True, use_prosody_encoder=True, ref_ratio=None, no_ref_audio=False, speed=1,
                         fix_duration=None, device=None, streaming=False, chunk_size=2048, seed=None,
-                        prosody_embeds=None, noise=None):
+                        prosody_embeds=None, noise=None, batch_lines=1):
     """:464-625 generator.  Yields ``(final_wave, 24000, combined_mel)`` (or chunks when ``streaming``).
     ``noise`` (list of y0 tensors, one per line) and ``prosody_embeds`` are explicit inputs the reference draws /
-    computes on its own device."""
+    computes on its own device.  ``batch_lines`` > 1 runs up to that many lines of ``gen_text`` as ONE
+    ``CFM.sample`` batch (one captured graph per step for all of them) instead of the reference's serial loop
+    (:572-579); lines of unequal length then follow the reference's own B > 1 semantics (``lens`` / duration masks,
+    cfm.py:336-339)."""
     rms = None
     if isinstance(ref_audio, tuple):
         audio, sr = ref_audio
@@ -209,27 +212,58 @@ def infer_batch_process(ref_audio, ref_text, gen_text_batches, model_obj, vocode
         ref_audio_len = cond.shape[1] - 1                                       # F = nw // hop + 1
 
     generated_waves, spectrograms = [], []
-    for li, gen_text in enumerate(gen_text_batches):                             # serial, like :572-579
-        final_text_list = [list(ref_text) + list(gen_text)]                      # :517
+
+    def line_duration(gen_text):
         if fix_duration is not None:
-            duration = int(fix_duration * target_sample_rate / hop_length)       # :522
-        else:
-            duration = ref_audio_len + int(ref_audio_len / len(ref_text) * len(gen_text) / speed)   # :525-527
-        generated, _ = model_obj.sample(
-            cond=cond, text=final_text_list, duration=duration, steps=nfe_step, cfg_strength=cfg_strength,
-            sway_sampling_coef=sway_sampling_coef, use_acc_grl=use_acc_grl, use_prosody_encoder=use_prosody_encoder,
-            ref_ratio=ref_ratio, no_ref_audio=no_ref_audio, seed=seed,
-            y0=None if noise is None else noise[li], prosody_embeds=prosody_embeds)
-        generated = generated.to(torch.float32)[:, ref_audio_len:, :].permute(0, 2, 1)    # :545-547
-        gain = float(rms / target_rms) if (rms is not None and rms < target_rms) else 1.0  # :552-553
-        wave = vocoder.engine.decode(generated, gain=gain) if hasattr(vocoder, "engine") else vocoder.decode(generated) * gain
-        wave = wave.squeeze().cpu().numpy()                                      # :557
-        if streaming:
-            for j in range(0, len(wave), chunk_size):
-                yield wave[j: j + chunk_size], target_sample_rate
-        else:
-            generated_waves.append(wave)
-            spectrograms.append(generated[0].cpu().numpy())
+            return int(fix_duration * target_sample_rate / hop_length)          # :522
+        return ref_audio_len + int(ref_audio_len / len(ref_text) * len(gen_text) / speed)   # :525-527
+
+    gain = float(rms / target_rms) if (rms is not None and rms < target_rms) else 1.0      # :552-553
+
+    def vocode(gen_mel):
+        wave = vocoder.engine.decode(gen_mel, gain=gain) if hasattr(vocoder, "engine") else vocoder.decode(gen_mel) * gain
+        return wave.squeeze().cpu().numpy()                                      # :557
+
+    lines = list(gen_text_batches)
+    group = max(1, int(batch_lines)) if not streaming else 1
+    for g0 in range(0, len(lines), group):
+        chunk = lines[g0: g0 + group]
+        if len(chunk) == 1:                                                      # the reference's path: one line, B = 1
+            gen_text = chunk[0]
+            generated, _ = model_obj.sample(
+                cond=cond, text=[list(ref_text) + list(gen_text)], duration=line_duration(gen_text), steps=nfe_step,
+                cfg_strength=cfg_strength, sway_sampling_coef=sway_sampling_coef, use_acc_grl=use_acc_grl,
+                use_prosody_encoder=use_prosody_encoder, ref_ratio=ref_ratio, no_ref_audio=no_ref_audio, seed=seed,
+                y0=None if noise is None else noise[g0], prosody_embeds=prosody_embeds)
+            mels = [generated.to(torch.float32)[:, ref_audio_len:, :].permute(0, 2, 1)]    # :545-547
+        else:                                                                    # several lines as one batch
+            nb = len(chunk)
+            durs = torch.tensor([line_duration(t) for t in chunk], dtype=torch.long)
+            cond_b = cond if cond.ndim == 2 and cond.shape[0] == nb else cond.expand(nb, *cond.shape[1:])
+            y0 = None
+            if noise is not None:
+                y0 = torch.nn.utils.rnn.pad_sequence([noise[g0 + j][0] for j in range(nb)], batch_first=True)
+            pros = prosody_embeds
+            if pros is not None and pros.shape[0] == 1:
+                pros = pros.expand(nb, -1)
+            generated, _ = model_obj.sample(
+                cond=cond_b, text=[list(ref_text) + list(t) for t in chunk], duration=durs, steps=nfe_step,
+                cfg_strength=cfg_strength, sway_sampling_coef=sway_sampling_coef, use_acc_grl=use_acc_grl,
+                use_prosody_encoder=use_prosody_encoder, ref_ratio=ref_ratio, no_ref_audio=no_ref_audio, seed=seed,
+                y0=y0, prosody_embeds=pros)
+            generated = generated.to(torch.float32)
+            # frames of line j: the sampler raises a duration below max(tokens, ref frames) + 1 (cfm.py:300-302)
+            f_ref = cond.shape[1] if cond.ndim == 3 else ref_audio_len + 1
+            eff = [max(max(len(ref_text) + len(t), f_ref) + 1, int(d)) for t, d in zip(chunk, durs)]
+            mels = [generated[j: j + 1, ref_audio_len: eff[j], :].permute(0, 2, 1).contiguous() for j in range(nb)]
+        for gen_mel in mels:
+            wave = vocode(gen_mel)
+            if streaming:
+                for j in range(0, len(wave), chunk_size):
+                    yield wave[j: j + chunk_size], target_sample_rate
+            else:
+                generated_waves.append(wave)
+                spectrograms.append(gen_mel[0].cpu().numpy())
     if streaming:
         return
     if generated_waves:

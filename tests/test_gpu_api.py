@@ -97,3 +97,53 @@ def test_infer_batch_process_from_raw_audio_with_rms_rescale():
     rel = float(np.sqrt(((wav - ref_wav) ** 2).mean()) / np.sqrt((ref_wav ** 2).mean()))
     print(f"\n[infer_batch_process raw audio] mel-MSE {mse:.3e}  waveform relative rms error {rel:.3e}")
     assert mse <= 1e-4 and rel < 5e-2
+
+
+def test_infer_batch_process_batched_lines_vs_oracle_batch():
+    """three lines of unequal length as ONE CFM.sample batch (``batch_lines=3``) -- against the oracle
+    sampling the same batch (the reference's B > 1 semantics: `lens`, duration masks), and equal-length lines against
+    the serial path bit for bit (what the data-parallel split relies on)."""
+    from lemas_tts_amd.engine import VocosEngine
+    from lemas_tts_amd.infer.utils_infer import cross_fade_concat, infer_batch_process
+    from lemas_tts_amd.model.cfm import CFM
+    from oracle import lemas_oracle as O
+
+    arch = DiTArch(depth=2)
+    vocab = {f"p{i}": i for i in range(898)}
+    sd = synth.synth_cfm_state_dict(arch, 898, 81)
+    vsd = synth.synth_vocos_state_dict(82)
+    model = CFM(arch, 898, sd, vocab_char_map=vocab, device="cuda:0")
+
+    class _V:            # what load_vocoder returns: an object with .engine
+        engine = VocosEngine(vsd, device="cuda:0")
+    F_ = 80
+    ref_mel = torch.from_numpy(synth.synth_cond_mel(83, F_))
+    ref_text = [f"p{i}" for i in synth.synth_tokens(84, 14, 898)]
+    lines = [[f"p{i}" for i in synth.synth_tokens(85 + k, n, 898)] for k, n in enumerate((9, 17, 12))]
+    ref_len = F_ - 1
+    durs = [ref_len + int(ref_len / len(ref_text) * len(g)) for g in lines]
+    noise = [torch.from_numpy(synth.synth_noise(90 + k, d))[None] for k, d in enumerate(durs)]
+    kw = dict(nfe_step=3, cfg_strength=2.0, sway_sampling_coef=5, use_acc_grl=False)
+    wav, sr, spec = next(infer_batch_process(ref_mel, ref_text, lines, model, _V, noise=noise, batch_lines=3, **kw))
+
+    text = O.tokens_to_idx([ref_text + g for g in lines], vocab)
+    y0 = torch.nn.utils.rnn.pad_sequence([n[0] for n in noise], batch_first=True)
+    out, _ = O.OracleCFM(sd, arch).sample(ref_mel[None].expand(3, -1, -1), text, torch.tensor(durs), y0=y0, steps=3, cfg_strength=2.0,
+                                          sway_sampling_coef=5)
+    voc = O.OracleVocos(vsd)
+    mels = [out[j: j + 1, ref_len: durs[j], :].permute(0, 2, 1) for j in range(3)]
+    ref_spec = np.concatenate([m[0].numpy() for m in mels], axis=1)
+    ref_wav = np.clip(cross_fade_concat([voc.decode(m)[0].numpy() for m in mels], 0.15), -0.999, 0.999)
+    assert spec.shape == ref_spec.shape and wav.shape == ref_wav.shape
+    mse = float(((spec - ref_spec) ** 2).mean())
+    rel = float(np.sqrt(((wav - ref_wav) ** 2).mean()) / np.sqrt((ref_wav ** 2).mean()))
+    print(f"\n[batch_lines=3 vs oracle batch] mel-MSE {mse:.3e}  waveform relative rms error {rel:.3e}")
+    assert mse <= 1e-4 and rel < 5e-2
+
+    # equal lengths: batched == serial, bit for bit
+    same = [lines[1], [f"p{i}" for i in synth.synth_tokens(99, len(lines[1]), 898)]]
+    nz = [noise[1], torch.from_numpy(synth.synth_noise(98, durs[1]))[None]]
+    a = next(infer_batch_process(ref_mel, ref_text, same, model, _V, noise=nz, batch_lines=2, **kw))
+    b = next(infer_batch_process(ref_mel, ref_text, same, model, _V, noise=nz, batch_lines=1, **kw))
+    np.testing.assert_array_equal(a[2], b[2])
+    np.testing.assert_array_equal(a[0], b[0])
