@@ -120,6 +120,9 @@ struct GemmParams {
   // profiling: when set, the launch goes through hipExtLaunchKernelGGL, which stamps these events with the dispatch's own
   // begin / end times (what rocprofv3 --kernel-trace reports), instead of bracketing the launch with stream events
   hipEvent_t ev_start, ev_stop;
+  // how many launches of this size run concurrently (the CFG lanes): the tile heuristic aims at ~256 / concurrency
+  // workgroups, i.e. larger, more efficient tiles when another lane's kernel fills the other half of the chip.  0 = 1.
+  int concurrency;
 };
 
 // ---- internal launchers (one per .hip translation unit) ----------------------------------------

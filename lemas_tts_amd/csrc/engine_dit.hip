@@ -520,6 +520,7 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     uint8_t* ff8 = fp8 ? d_ff8.as<uint8_t>() + r0 * ffd : nullptr;
     uint8_t* ffmx = fp8 ? d_ffmx.as<uint8_t>() + r0 * (ffd / 32) : nullptr;
     g.f8 = fp8 ? 1 : 0;
+    g.concurrency = lanes;
     // A / W / their scales for one GEMM: bf16 operands, or (fp8) MXFP8 activations x per-channel-scaled e4m3 weights
     auto operands = [&](const bf16_t* abf16, const uint8_t* af8, const uint8_t* afmx, const DevBuf& wb, const DevBuf& w8, const DevBuf& wsc,
                         size_t row_off, int K) {
