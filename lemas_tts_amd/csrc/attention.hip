@@ -353,19 +353,20 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_splitkv_kernel(const AttnPara
       const char* sK = smem + SG * STAGE2 + grp * 2 * TILE;
       const char* sV = sK + TILE;
       f32x16 s[2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+      const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         bf16x8 a[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) a[t] = *reinterpret_cast<const bf16x8*>(sK + t * 4096 + kx[kk]);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t], qf[kk], s[t], 0, 0, 0);
+        for (int t = 0; t < 2; ++t)   // first k-step accumulates onto the inline constant 0: no register zeroing
+          s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t], qf[kk], kk == 0 ? zero : s[t], 0, 0, 0);
       }
-      if ((j + 1) * KB > kvlen) {
+      if (__builtin_expect((j + 1) * KB > kvlen, 0)) {
+        // only the last (partial) tile of a sample masks keys.  The empty asm keeps this a real, rarely taken branch: left
+        // to itself the compiler if-converts it into 32 compare/select pairs (+ the key-index adds) executed for EVERY tile
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
