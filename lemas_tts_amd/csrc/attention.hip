@@ -55,6 +55,25 @@ __device__ __forceinline__ int xcd_block_id() {
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// Hand-scheduled LDS fragment reads (split-KV kernel): asm reads the compiler does not track, and waits with exact counts
+// that are tied to the fragment registers so that the consuming MFMAs cannot be scheduled above them.
+template <int OFF>
+__device__ __forceinline__ void lds_read_b128(u32x4& d, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+// both 32-row halves of one k-step: rows r and r + 32 share the swizzle, the k-step only flips bits 5-6 of the address
+// (chunk = (2 kk) ^ hi ^ swizzle), so one base register serves all four steps instead of four address registers
+template <int X>
+__device__ __forceinline__ void lds_read_kstep(u32x4& d0, u32x4& d1, unsigned base) {
+  unsigned t;
+  asm volatile("v_xor_b32 %2, %4, %3\n\tds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:4096"
+               : "=&v"(d0), "=&v"(d1), "=&v"(t) : "v"(base), "n"(X) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_lgkm_frags(u32x4& a, u32x4& b) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
+}
+
 struct Ctx {
   char* smem;
   const char* kg;   // K of this (b, h), bytes
@@ -279,8 +298,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
 // Ring: 2 stages of [K0 | V0^T | K1 | V1^T] (32 KiB each), one barrier per tile pair.
 constexpr int STAGE2 = 4 * TILE;
 
-__global__ __launch_bounds__(512, 2) void attn_fwd_splitkv_kernel(const AttnParams p) {
+__global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_fwd_splitkv_kernel(const AttnParams p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE2];
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -321,12 +341,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_splitkv_kernel(const AttnPara
 
   const int krow = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
   const int ksw = (krow >> 1) & 7, vsw = (l31 >> 1) & 7;
-  int kx[4], vx[4];
+  const unsigned kx0 = krow * 128 + ((hi ^ ksw) << 4);   // k-step kk: kx0 ^ (kk << 5)
+  int vx[4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    kx[e] = krow * 128 + (((e * 2 + hi) ^ ksw) << 4);
-    vx[e] = l31 * 128 + (((2 * e + hi) ^ vsw) << 4);
-  }
+  for (int e = 0; e < 4; ++e) vx[e] = l31 * 128 + (((2 * e + hi) ^ vsw) << 4);
 
   bf16x8 qf[4];
   {
@@ -350,18 +368,26 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_splitkv_kernel(const AttnPara
     if (i + 1 < nsup && !(p.variant == 3 && i > 0)) issue(SG ^ 1, i + 1);   // variant 3: timing experiment without DMA
     const int j = 2 * i + grp;
     if (j < ntiles) {
-      const char* sK = smem + SG * STAGE2 + grp * 2 * TILE;
-      const char* sV = sK + TILE;
+      // K fragment schedule (2 x ds_read_b128 per k-step, double-buffered in fk[2][2]): the reads of step kk+1 are in flight
+      // under the MFMAs of step kk.  Left to the compiler every step was read -> s_waitcnt lgkmcnt(0) -> MFMA.
+      const unsigned sKa = lds_base + SG * STAGE2 + grp * 2 * TILE;
+      u32x4 fk[2][2];
       f32x16 s[2];
       const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      const unsigned ka = sKa + kx0;
+      lds_read_kstep<0>(fk[0][0], fk[0][1], ka);
+      lds_read_kstep<32>(fk[1][0], fk[1][1], ka);
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        bf16x8 a[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) a[t] = *reinterpret_cast<const bf16x8*>(sK + t * 4096 + kx[kk]);
+        u32x4 (&f)[2] = fk[kk & 1];
+        if (kk < 3) wait_lgkm_frags<2>(f[0], f[1]);      // the two youngest outstanding reads are the next step's
+        else wait_lgkm_frags<0>(f[0], f[1]);
 #pragma unroll
         for (int t = 0; t < 2; ++t)   // first k-step accumulates onto the inline constant 0: no register zeroing
-          s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t], qf[kk], kk == 0 ? zero : s[t], 0, 0, 0);
+          s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f[t]), qf[kk], kk == 0 ? zero : s[t], 0, 0, 0);
+        if (kk == 0) lds_read_kstep<64>(f[0], f[1], ka);
+        if (kk == 1) lds_read_kstep<96>(f[0], f[1], ka);
+        __builtin_amdgcn_sched_barrier(0);   // keep wait -> MFMAs -> refill in this order (sinking the MFMAs costs a third buffer)
       }
       if (__builtin_expect((j + 1) * KB > kvlen, 0)) {
         // only the last (partial) tile of a sample masks keys.  The empty asm keeps this a real, rarely taken branch: left
@@ -404,6 +430,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_splitkv_kernel(const AttnPara
 #pragma unroll
         for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
       }
+      // P.V keeps the compiler's schedule (single-buffered V^T fragments, softmax tail interleaved with the MFMAs): a second
+      // fragment buffer here lifts the kernel to 138 VGPRs and costs the fourth wave per SIMD (measured 51.8 vs 45.7 us)
+      const char* sV = smem + SG * STAGE2 + grp * 2 * TILE + TILE;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         bf16x8 a[2];
