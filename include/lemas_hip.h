@@ -14,6 +14,7 @@
  *   lemas_vocos_decode                      <- vocoder.decode call, lemas_tts/infer/utils_infer.py:549 and
  *                                              lemas_tts/scripts/speech_edit_multilingual.py:198
  *   lemas_mel_create/forward                <- lemas_tts/model/modules.py:104-143 MelSpec.forward (cfm.py:232-236)
+ *   lemas_resample_create/forward           <- torchaudio Resample call, lemas_tts/infer/utils_infer.py:494-496
  *   lemas_k_*                               <- single-kernel entry points used by the parity tests
  *
  * Conventions: plain pointers and sizes only.  "device" pointers are HIP device addresses on the current device
@@ -40,6 +41,7 @@ extern "C" {
 typedef struct lemas_dit lemas_dit;
 typedef struct lemas_vocos lemas_vocos;
 typedef struct lemas_mel lemas_mel;
+typedef struct lemas_resample lemas_resample;
 
 /* model.arch of lemas_tts/configs/multilingual_grl.yaml:48-58 (+ derived sizes) */
 typedef struct {
@@ -116,6 +118,14 @@ int lemas_vocos_decode(lemas_vocos* v, const float* mel, int32_t batch, int32_t 
 int lemas_mel_create(int32_t n_fft, int32_t hop_length, int32_t n_mels, int32_t sample_rate, lemas_mel** out);
 void lemas_mel_destroy(lemas_mel* m);
 int lemas_mel_forward(lemas_mel* m, const float* wav, int32_t batch, int32_t samples, float* mel, void* stream);
+
+/* ---- prompt resampling to the model rate (torchaudio.transforms.Resample(sr, 24000) at lemas_tts/infer/utils_infer.py:494-496
+ * and lemas_tts/model/cfm.py:254): sinc_interp_hann polyphase filter, lowpass_filter_width 6, rolloff 0.99.
+ * wav device [B, samples] fp32 -> out device [B, lemas_resample_out_len(samples)] fp32 ---- */
+int lemas_resample_create(int32_t orig_freq, int32_t new_freq, lemas_resample** out);
+void lemas_resample_destroy(lemas_resample* r);
+int64_t lemas_resample_out_len(const lemas_resample* r, int64_t samples);   /* ceil(new * samples / orig) */
+int lemas_resample_forward(lemas_resample* r, const float* wav, int32_t batch, int32_t samples, float* out, void* stream);
 
 /* ---- single-kernel entry points (parity tests) ---- all pointers device fp32 unless noted */
 /* out[M,N] = act(A[M,K] . W[N,K]^T + bias) through the bf16 MFMA GEMM (inputs rounded to bf16); act: 0 none, 1 gelu-tanh */

@@ -66,6 +66,10 @@ def lib():
         "lemas_mel_create": (C.c_int, [i32, i32, i32, i32, C.POINTER(vp)]),
         "lemas_mel_destroy": (None, [vp]),
         "lemas_mel_forward": (C.c_int, [vp, vp, i32, i32, vp, vp]),
+        "lemas_resample_create": (C.c_int, [i32, i32, C.POINTER(vp)]),
+        "lemas_resample_destroy": (None, [vp]),
+        "lemas_resample_out_len": (C.c_int64, [vp, C.c_int64]),
+        "lemas_resample_forward": (C.c_int, [vp, vp, i32, i32, vp, vp]),
         "lemas_k_linear_bf16": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
         "lemas_k_linear_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
         "lemas_k_attention": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
@@ -92,7 +96,8 @@ EXPORTED = [
     "lemas_dit_finalize", "lemas_dit_set_option", "lemas_dit_sample", "lemas_dit_prepare", "lemas_dit_solve",
     "lemas_dit_forward", "lemas_dit_profile_read", "lemas_vocos_create", "lemas_vocos_destroy",
     "lemas_vocos_load_weight", "lemas_vocos_finalize", "lemas_vocos_decode", "lemas_mel_create", "lemas_mel_destroy",
-    "lemas_mel_forward", "lemas_k_linear_bf16",
+    "lemas_mel_forward", "lemas_resample_create", "lemas_resample_destroy", "lemas_resample_out_len", "lemas_resample_forward",
+    "lemas_k_linear_bf16",
     "lemas_k_linear_f32", "lemas_k_attention", "lemas_k_ln_mod", "lemas_k_convpos", "lemas_k_bench", "lemas_k_set_attention_variant", "lemas_k_bench_overlap",
     "lemas_k_mx_quant", "lemas_k_w_quant_f8", "lemas_k_ln_mod_f8", "lemas_k_linear_f8",
 ]

@@ -93,3 +93,88 @@ int lemas_mel_forward(lemas_mel* m, const float* wav, int32_t batch, int32_t sam
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------------
+// lemas_resample: prompt resampling to 24 kHz, the other half of the front edge.  Replaces the
+// torchaudio.transforms.Resample call at lemas_tts/infer/utils_infer.py:494-496 (also cfm.py:254).  Arithmetic: torchaudio's
+// sinc_interp_hann polyphase resampler with its defaults (lowpass_filter_width 6, rolloff 0.99) -- third party, not in
+// the tree, not installed: PARITY UNPINNED (restated from the published algorithm; oracle: resample_sinc_hann).
+//   o = orig / gcd, n = new / gcd, base = min(o, n) * rolloff, width = ceil(lpw * o / base)
+//   kernel[p][k] = sinc(pi t) * cos^2(pi t / (2 lpw)) * base / o,  t = clamp((-p / n + (k - width) / o) * base, +-lpw)
+//   out[m n + p] = sum_k kernel[p][k] * xpad[m o + k],  xpad = x padded (width, width + o), length ceil(n * len / o)
+namespace {
+__global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ x, int B, int len, const float* __restrict__ kern,
+                                                       int o, int n, int width, int klen, float* __restrict__ out, int out_len) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= (size_t)B * out_len) return;
+  const int b = (int)(i / out_len), j = (int)(i - (size_t)b * out_len);
+  const int m = j / n, p = j - m * n;
+  const float* xr = x + (size_t)b * len;
+  const float* kr = kern + (size_t)p * klen;
+  const int base = m * o - width;          // xpad[m o + k] = x[m o + k - width]
+  float acc = 0.f;
+  for (int k = 0; k < klen; ++k) {
+    const int idx = base + k;
+    const float v = (idx >= 0 && idx < len) ? xr[idx] : 0.f;
+    acc = fmaf(kr[k], v, acc);
+  }
+  out[i] = acc;
+}
+}  // namespace
+
+struct lemas_resample {
+  int o = 1, n = 1, width = 0, klen = 0;
+  DevBuf kern;
+  ~lemas_resample() { kern.release(); }
+};
+
+extern "C" {
+
+int lemas_resample_create(int32_t orig_freq, int32_t new_freq, lemas_resample** out) {
+  if (!out || orig_freq <= 0 || new_freq <= 0) { set_error("lemas_resample_create: bad arguments"); return LEMAS_E_ARG; }
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0) {
+    set_error("lemas_resample_create: no HIP device (this library has no CPU path)");
+    return e != hipSuccess ? -(int)e : LEMAS_E_STATE;
+  }
+  int a = orig_freq, b = new_freq;
+  while (b) { const int t = a % b; a = b; b = t; }
+  lemas_resample* r = new lemas_resample();
+  r->o = orig_freq / a; r->n = new_freq / a;
+  const double lpw = 6.0, rolloff = 0.99;
+  const double base = (double)(r->o < r->n ? r->o : r->n) * rolloff;
+  r->width = (int)std::ceil(lpw * r->o / base);
+  r->klen = 2 * r->width + r->o;
+  std::vector<float> k((size_t)r->n * r->klen);
+  for (int p = 0; p < r->n; ++p)
+    for (int j = 0; j < r->klen; ++j) {
+      double t = (-(double)p / r->n + (double)(j - r->width) / r->o) * base;
+      t = t < -lpw ? -lpw : (t > lpw ? lpw : t);
+      const double c = std::cos(t * M_PI / lpw / 2.0);
+      const double tp = t * M_PI;
+      const double sinc = tp == 0.0 ? 1.0 : std::sin(tp) / tp;
+      k[(size_t)p * r->klen + j] = (float)(sinc * c * c * (base / r->o));
+    }
+  int rc = r->kern.ensure(k.size() * 4);
+  if (rc == 0 && hipMemcpy(r->kern.p, k.data(), k.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { set_error("lemas_resample_create: upload failed"); rc = LEMAS_E_STATE; }
+  if (rc != 0) { delete r; return rc; }
+  *out = r;
+  return 0;
+}
+void lemas_resample_destroy(lemas_resample* r) { delete r; }
+int64_t lemas_resample_out_len(const lemas_resample* r, int64_t samples) {
+  if (!r || samples < 0) return -1;
+  return (samples * r->n + r->o - 1) / r->o;
+}
+int lemas_resample_forward(lemas_resample* r, const float* wav, int32_t batch, int32_t samples, float* out, void* stream) {
+  if (!r || !wav || !out || batch <= 0 || samples <= 0) { set_error("lemas_resample_forward: bad arguments"); return LEMAS_E_ARG; }
+  const int out_len = (int)lemas_resample_out_len(r, samples);
+  const size_t total = (size_t)batch * out_len;
+  hipLaunchKernelGGL(resample_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, wav, batch, samples,
+                     r->kern.as<float>(), r->o, r->n, r->width, r->klen, out, out_len);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

@@ -262,3 +262,37 @@ class MelEngine(_Streamed):
             _lib.check(_lib.lib().lemas_mel_forward(self._h, wav.data_ptr(), B, nw, mel.data_ptr(), s), "lemas_mel_forward")
             self._exit()
         return mel
+
+
+class ResampleEngine(_Streamed):
+    """``torchaudio.transforms.Resample(orig_freq, new_freq)`` replacement for the prompt (utils_infer.py:494-496):
+    wav [B, nw] at ``orig_freq`` -> [B, ceil(new * nw / orig)] at ``new_freq``."""
+
+    def __init__(self, orig_freq: int, new_freq: int = 24000, device="cuda:0"):
+        super().__init__(device)
+        self.orig_freq, self.new_freq = int(orig_freq), int(new_freq)
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().lemas_resample_create(self.orig_freq, self.new_freq, C.byref(self._h)), "lemas_resample_create")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().lemas_resample_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __call__(self, wav: torch.Tensor) -> torch.Tensor:
+        with torch.cuda.device(self.device):
+            wav = wav.to(self.device, torch.float32).contiguous()
+            B, nw = wav.shape
+            n_out = int(_lib.lib().lemas_resample_out_len(self._h, nw))
+            out = torch.empty((B, n_out), device=self.device, dtype=torch.float32)
+            s = self._enter(wav, out)
+            _lib.check(_lib.lib().lemas_resample_forward(self._h, wav.data_ptr(), B, nw, out.data_ptr(), s), "lemas_resample_forward")
+            self._exit()
+        return out

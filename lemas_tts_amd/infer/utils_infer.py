@@ -201,8 +201,9 @@ def infer_batch_process(ref_audio, ref_text, gen_text_batches, model_obj, vocode
         rms = torch.sqrt(torch.mean(torch.square(audio)))                       # :491
         if rms < target_rms:
             audio = audio * target_rms / rms                                    # :492-493
-        if sr != target_sample_rate:
-            raise NotImplementedError("resampling the prompt (torchaudio Resample, :494-496) is not built; pass 24 kHz audio")
+        if sr != target_sample_rate:                                            # :494-496
+            from ..engine import ResampleEngine
+            audio = ResampleEngine(int(sr), target_sample_rate, device=getattr(model_obj, "device", device) or "cuda:0")(audio).cpu()
         cond = audio
         ref_audio_len = audio.shape[-1] // hop_length                           # :520
     else:

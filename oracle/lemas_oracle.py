@@ -20,6 +20,10 @@ Pinning status
     package absent, no reference tests or vectors exist: PARITY UNPINNED.  This restatement follows
     the published VocosBackbone / ConvNeXtBlock / ISTFTHead(padding="center") definitions and is
     cross-checked against ``torch.istft`` in tests.
+  * torchaudio (==2.3.1, requirements.txt:166; absent): the wav -> log-mel front edge (MelSpectrogram) and the prompt
+    resampler (``resample_sinc_hann``) are restated from the published algorithms and cross-checked against explicit
+    DFT / analytic properties in tests: PARITY UNPINNED.
+  * The fp8 GEMM variant (``OracleDiT(fp8=True)``, oracle/mxfp8.py) is not a reference feature: the oracle defines it.
 """
 from __future__ import annotations
 
@@ -318,6 +322,33 @@ class OracleCFM:
 # ----------------------------------------------------------------------------------------------
 # wav -> log-mel front edge (model/modules.py:75-101; torchaudio MelSpectrogram is third-party: PARITY UNPINNED)
 # ----------------------------------------------------------------------------------------------
+def resample_sinc_hann(wav: Tensor, orig_freq: int, new_freq: int, lowpass_filter_width: int = 6,
+                       rolloff: float = 0.99) -> Tensor:
+    """Prompt resampling, ``torchaudio.transforms.Resample(sr, 24000)`` at utils_infer.py:494-496 (and cfm.py:254).
+    torchaudio is third party, not in the tree and not installed: PARITY UNPINNED.  Restated from the published
+    ``torchaudio.functional.resample`` (``sinc_interp_hann``): reduce the rates by their gcd, build one windowed-sinc
+    kernel per output phase in float64, zero-pad (width, width + orig), strided correlation, truncate to
+    ceil(new * len / orig).  wav [B, len] -> [B, ceil(new * len / orig)]."""
+    g = math.gcd(int(orig_freq), int(new_freq))
+    o, n = int(orig_freq) // g, int(new_freq) // g
+    if o == n:
+        return wav.clone()
+    base = min(o, n) * rolloff
+    width = int(math.ceil(lowpass_filter_width * o / base))
+    idx = torch.arange(-width, width + o, dtype=torch.float64)[None, None] / o
+    t = torch.arange(0, -n, -1, dtype=torch.float64)[:, None, None] / n + idx
+    t = (t * base).clamp(-lowpass_filter_width, lowpass_filter_width)
+    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    kernels = torch.where(t == 0, torch.ones_like(t), t.sin() / t) * window * (base / o)
+    kernels = kernels.to(torch.float32)                                   # [n, 1, 2 width + o]
+    length = wav.shape[-1]
+    x = F.pad(wav.float(), (width, width + o))
+    y = F.conv1d(x[:, None], kernels, stride=o)                           # [B, n, frames]
+    y = y.transpose(1, 2).reshape(wav.shape[0], -1)
+    return y[..., : int(math.ceil(n * length / o))]
+
+
 def htk_filterbank(n_freqs: int = 513, n_mels: int = 100, sample_rate: int = 24000) -> Tensor:
     """torchaudio.functional.melscale_fbanks(n_freqs, 0, sr/2, n_mels, sr, norm=None, mel_scale='htk') -> [n_freqs, n_mels]."""
     all_freqs = torch.linspace(0, sample_rate // 2, n_freqs, dtype=torch.float64)
