@@ -61,6 +61,77 @@ class VocosArch:
     hop_length: int = 256
 
 
+@dataclass(frozen=True)
+class ProsodyArch:
+    """ECAPA-TDNN prosody encoder, ``lemas_tts/model/backbones/prosody_encoder.py:390-403``.  The reference reads these
+    numbers from ``pretssel_cfg.json`` (``model.prosody_*``), a file that is NOT in the tree: the defaults below are the
+    published Pretssel / SeamlessExpressive values and are an assumption until that file is available."""
+    channels: tuple = (512, 512, 512, 512, 1536)
+    kernel_sizes: tuple = (5, 3, 3, 3, 1)
+    dilations: tuple = (1, 2, 3, 4, 1)
+    attention_channels: int = 128
+    res2net_scale: int = 8
+    se_channels: int = 128
+    global_context: bool = True
+    groups: tuple = (1, 1, 1, 1, 1)
+    embed_dim: int = 512
+    input_dim: int = 80
+
+    @staticmethod
+    def from_pretssel_cfg(model_cfg: dict) -> "ProsodyArch":
+        """``_build_prosody_encoder`` key mapping (prosody_encoder.py:390-403)."""
+        return ProsodyArch(channels=tuple(model_cfg["prosody_channels"]), kernel_sizes=tuple(model_cfg["prosody_kernel_sizes"]),
+                           dilations=tuple(model_cfg["prosody_dilations"]), attention_channels=model_cfg["prosody_attention_channels"],
+                           res2net_scale=model_cfg["prosody_res2net_scale"], se_channels=model_cfg["prosody_se_channels"],
+                           global_context=model_cfg["prosody_global_context"], groups=tuple(model_cfg["prosody_groups"]),
+                           embed_dim=model_cfg["prosody_embed_dim"], input_dim=model_cfg["input_feat_per_channel"])
+
+    def reference_kwargs(self) -> dict:
+        return dict(channels=list(self.channels), kernel_sizes=list(self.kernel_sizes), dilations=list(self.dilations),
+                    attention_channels=self.attention_channels, res2net_scale=self.res2net_scale, se_channels=self.se_channels,
+                    global_context=self.global_context, groups=list(self.groups), embed_dim=self.embed_dim, input_dim=self.input_dim)
+
+
+def prosody_param_shapes(a: ProsodyArch) -> "OrderedDict[str, tuple]":
+    """state-dict names / shapes of ``ECAPA_TDNN`` (prosody_encoder.py:36-101, 136-331), the names the reference's own
+    loader expects after stripping ``prosody_encoder.`` (:406-424)."""
+    if any(g != 1 for g in a.groups):
+        raise NotImplementedError("grouped TDNN convolutions (groups != 1) are not built")
+    s: "OrderedDict[str, tuple]" = OrderedDict()
+
+    def tdnn(p, cin, cout, k):
+        s[p + "conv.weight"] = (cout, cin, k)
+        s[p + "conv.bias"] = (cout,)
+        s[p + "norm.weight"] = (cout,)
+        s[p + "norm.bias"] = (cout,)
+
+    ch = a.channels
+    tdnn("blocks.0.", a.input_dim, ch[0], a.kernel_sizes[0])
+    for i in range(1, len(ch) - 1):
+        p = f"blocks.{i}."
+        tdnn(p + "tdnn1.", ch[i - 1], ch[i], 1)
+        sub = ch[i] // a.res2net_scale
+        for j in range(a.res2net_scale - 1):
+            tdnn(p + f"res2net_block.blocks.{j}.", sub, sub, a.kernel_sizes[i])
+        tdnn(p + "tdnn2.", ch[i], ch[i], 1)
+        s[p + "se_block.conv1.weight"] = (a.se_channels, ch[i], 1)
+        s[p + "se_block.conv1.bias"] = (a.se_channels,)
+        s[p + "se_block.conv2.weight"] = (ch[i], a.se_channels, 1)
+        s[p + "se_block.conv2.bias"] = (ch[i],)
+        if ch[i - 1] != ch[i]:
+            s[p + "shortcut.weight"] = (ch[i], ch[i - 1], 1)
+            s[p + "shortcut.bias"] = (ch[i],)
+    tdnn("mfa.", ch[-1], ch[-1], a.kernel_sizes[-1])
+    tdnn("asp.tdnn.", ch[-1] * (3 if a.global_context else 1), a.attention_channels, 1)
+    s["asp.conv.weight"] = (ch[-1], a.attention_channels, 1)
+    s["asp.conv.bias"] = (ch[-1],)
+    s["asp_norm.weight"] = (2 * ch[-1],)
+    s["asp_norm.bias"] = (2 * ch[-1],)
+    s["fc.weight"] = (a.embed_dim, 2 * ch[-1], 1)
+    s["fc.bias"] = (a.embed_dim,)
+    return s
+
+
 def cfm_param_shapes(a: DiTArch, vocab_size: int, prosody: bool = False) -> "OrderedDict[str, tuple]":
     """name -> shape for every tensor of the (stripped) CFM state dict the loader must accept."""
     d, td, inner = a.dim, a.text_dim, a.heads * a.dim_head

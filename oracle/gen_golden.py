@@ -117,6 +117,23 @@ def run_case(name, arch, *, wseed, B, F, lens, Nt, duration, steps, cfg, coef, n
           f"traj[-1] std {traj[-1].std():.4f}")
 
 
+def run_prosody_case(name, wseed, frames):
+    """ECAPA-TDNN prosody encoder: the reference class on synthetic weights and features.  The
+    architecture numbers are ProsodyArch's defaults (pretssel_cfg.json is not in the tree)."""
+    ref_shims.install()
+    from lemas_tts.model.backbones.prosody_encoder import ECAPA_TDNN
+    from lemas_tts_amd.model.layout import ProsodyArch
+    arch = ProsodyArch()
+    sd = synth.synth_prosody_encoder_state_dict(wseed, arch)
+    model = ECAPA_TDNN(**arch.reference_kwargs()).eval()
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    fbank = np.stack([synth.synth_fbank(wseed + 1 + b, frames) for b in range(2)])
+    with torch.no_grad():
+        emb = torch.stack([model(torch.from_numpy(fbank[b: b + 1]), padding_mask=None)[0] for b in range(2)])   # per sample, cfm.py:248-262
+    np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), wseed=wseed, wchecksum=synth.checksum(sd), fbank=fbank, emb=emb.numpy())
+    print(f"{name}: frames={frames} emb norm {emb.norm(dim=-1).tolist()}")
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     torch.set_num_threads(8)
@@ -130,6 +147,8 @@ def main():
              cfg=2.0, coef=3.0, noise_seed=104, edit_spans=[(0.4, 0.7), (1.3, 1.6)])
     run_case("mini_prosody", DiTArch(depth=2), wseed=15, B=2, F=64, lens=None, Nt=[20, 26],
              duration=[130, 144], steps=3, cfg=2.0, coef=5, noise_seed=105, prosody=True)
+    run_prosody_case("prosody_enc_short", 17, 41)
+    run_prosody_case("prosody_enc_10s", 18, 998)
     run_case("full_plain", FULL, wseed=16, B=1, F=150, lens=None, Nt=[60], duration=400, steps=3,
              cfg=2.0, coef=5, noise_seed=106)
 
