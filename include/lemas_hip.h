@@ -15,6 +15,8 @@
  *                                              lemas_tts/scripts/speech_edit_multilingual.py:198
  *   lemas_mel_create/forward                <- lemas_tts/model/modules.py:104-143 MelSpec.forward (cfm.py:232-236)
  *   lemas_resample_create/forward           <- torchaudio Resample call, lemas_tts/infer/utils_infer.py:494-496
+ *   lemas_prosody_*                         <- lemas_tts/model/backbones/prosody_encoder.py ProsodyEncoder / extract_fbank_16k,
+ *                                              called per sample at lemas_tts/model/cfm.py:248-262
  *   lemas_k_*                               <- single-kernel entry points used by the parity tests
  *
  * Conventions: plain pointers and sizes only.  "device" pointers are HIP device addresses on the current device
@@ -42,6 +44,7 @@ typedef struct lemas_dit lemas_dit;
 typedef struct lemas_vocos lemas_vocos;
 typedef struct lemas_mel lemas_mel;
 typedef struct lemas_resample lemas_resample;
+typedef struct lemas_prosody lemas_prosody;
 
 /* model.arch of lemas_tts/configs/multilingual_grl.yaml:48-58 (+ derived sizes) */
 typedef struct {
@@ -135,6 +138,27 @@ int lemas_k_linear_bf16(const float* A, const float* W, const float* bias, float
 int lemas_k_linear_f32(const float* A, const float* W, const float* bias, float* out, int32_t M, int32_t N, int32_t K,
                        int32_t act, void* stream);
 /* q,k,v [B,H,N,64] (already rotated) -> out [B,N,H*64]; seq_len device int32 [B] or NULL */
+/* ---- prosody encoder (ECAPA-TDNN), the prompt's global prosody embedding ----
+ * Architecture numbers = the reference's pretssel_cfg.json "model.prosody_*" keys (prosody_encoder.py:390-403). */
+typedef struct lemas_prosody_config {
+  int32_t n_layers;            /* len(prosody_channels) */
+  int32_t channels[8];
+  int32_t kernel_sizes[8];
+  int32_t dilations[8];
+  int32_t groups[8];           /* must be 1 */
+  int32_t attention_channels, res2net_scale, se_channels, global_context, embed_dim, input_dim;
+} lemas_prosody_config;
+int lemas_prosody_create(const lemas_prosody_config* cfg, lemas_prosody** out);
+void lemas_prosody_destroy(lemas_prosody* p);
+/* weight names as in the reference module's state dict after its loader strips "prosody_encoder." (prosody_encoder.py:406-424) */
+int lemas_prosody_load_weight(lemas_prosody* p, const char* name, const float* host_data, const int64_t* shape, int32_t ndim);
+int lemas_prosody_finalize(lemas_prosody* p);
+/* kaldi fbank of extract_fbank_16k (prosody_encoder.py:334-361): wav16k device [samples >= 400] -> fbank device [frames, 80] */
+int64_t lemas_prosody_fbank_frames(int64_t samples_16k);      /* 1 + (samples - 400) / 160, 0 if samples < 400 */
+int lemas_prosody_fbank(lemas_prosody* p, const float* wav16k, int32_t samples, float* fbank, void* stream);
+/* one sample, padding_mask=None (how cfm.py:259 calls it): fbank device [frames, input_dim] -> emb device [embed_dim], L2-normalised */
+int lemas_prosody_encode(lemas_prosody* p, const float* fbank, int32_t frames, float* emb, void* stream);
+
 /* fp8 (MXFP8) path of the GEMMs -- BASELINE config 5 "fp8 MFMA weights".  Activations: e4m3 bytes + one E8M0 scale per
  * 32 consecutive K (OCP MX); weights: e4m3 + one fp32 scale per output channel.  All pointers device. */
 int lemas_k_mx_quant(const float* x, int32_t M, int32_t K, uint8_t* out8, uint8_t* mx, void* stream);

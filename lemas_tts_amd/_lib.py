@@ -20,6 +20,12 @@ class DitConfig(C.Structure):
         "conv_pos_kernel", "conv_pos_groups", "time_freq_dim", "has_prosody")]
 
 
+class ProsodyConfig(C.Structure):
+    _fields_ = [("n_layers", C.c_int32), ("channels", C.c_int32 * 8), ("kernel_sizes", C.c_int32 * 8), ("dilations", C.c_int32 * 8),
+                ("groups", C.c_int32 * 8), ("attention_channels", C.c_int32), ("res2net_scale", C.c_int32), ("se_channels", C.c_int32),
+                ("global_context", C.c_int32), ("embed_dim", C.c_int32), ("input_dim", C.c_int32)]
+
+
 class SampleArgs(C.Structure):
     _fields_ = [
         ("batch", C.c_int32), ("frames", C.c_int32), ("cond_frames", C.c_int32), ("text_len", C.c_int32),
@@ -66,6 +72,13 @@ def lib():
         "lemas_mel_create": (C.c_int, [i32, i32, i32, i32, C.POINTER(vp)]),
         "lemas_mel_destroy": (None, [vp]),
         "lemas_mel_forward": (C.c_int, [vp, vp, i32, i32, vp, vp]),
+        "lemas_prosody_create": (C.c_int, [vp, C.POINTER(vp)]),
+        "lemas_prosody_destroy": (None, [vp]),
+        "lemas_prosody_load_weight": (C.c_int, [vp, C.c_char_p, vp, C.POINTER(C.c_int64), i32]),
+        "lemas_prosody_finalize": (C.c_int, [vp]),
+        "lemas_prosody_fbank_frames": (C.c_int64, [C.c_int64]),
+        "lemas_prosody_fbank": (C.c_int, [vp, vp, i32, vp, vp]),
+        "lemas_prosody_encode": (C.c_int, [vp, vp, i32, vp, vp]),
         "lemas_resample_create": (C.c_int, [i32, i32, C.POINTER(vp)]),
         "lemas_resample_destroy": (None, [vp]),
         "lemas_resample_out_len": (C.c_int64, [vp, C.c_int64]),
@@ -97,6 +110,8 @@ EXPORTED = [
     "lemas_dit_forward", "lemas_dit_profile_read", "lemas_vocos_create", "lemas_vocos_destroy",
     "lemas_vocos_load_weight", "lemas_vocos_finalize", "lemas_vocos_decode", "lemas_mel_create", "lemas_mel_destroy",
     "lemas_mel_forward", "lemas_resample_create", "lemas_resample_destroy", "lemas_resample_out_len", "lemas_resample_forward",
+    "lemas_prosody_create", "lemas_prosody_destroy", "lemas_prosody_load_weight", "lemas_prosody_finalize", "lemas_prosody_fbank_frames",
+    "lemas_prosody_fbank", "lemas_prosody_encode",
     "lemas_k_linear_bf16",
     "lemas_k_linear_f32", "lemas_k_attention", "lemas_k_ln_mod", "lemas_k_convpos", "lemas_k_bench", "lemas_k_set_attention_variant", "lemas_k_bench_overlap",
     "lemas_k_mx_quant", "lemas_k_w_quant_f8", "lemas_k_ln_mod_f8", "lemas_k_linear_f8",

@@ -181,6 +181,8 @@ enum F32Epi : int {
   F32_BIAS_SILU = 2,   // out = silu(acc + bias)
   F32_BIAS_RES_SCALE = 3,  // out = res + colscale[n] * (acc + bias)      (colscale may be null => 1)
   F32_BIAS_ADD2 = 4,   // out[m] = acc + bias? + add[m] and out[m + M] = acc + add[m + M]  (input-proj x-part broadcast to cond/uncond)
+  F32_BIAS_RELU = 5,   // out = max(acc + bias, 0)         (prosody encoder TDNN / SE)
+  F32_BIAS_SIGMOID = 6,  // out = 1 / (1 + exp(-(acc + bias)))  exact expf (SE gate)
 };
 struct GemmF32Params {
   const float* A; int lda;   // [M, K]

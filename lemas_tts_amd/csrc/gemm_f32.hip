@@ -81,6 +81,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Params p) {
         float v = acc[i][j][r] + bias;
         if (EPI == F32_BIAS_GELU) v = gelu_erf_f(v);
         if (EPI == F32_BIAS_SILU) v = silu_f(v);
+        if (EPI == F32_BIAS_RELU) v = fmaxf(v, 0.f);
+        if (EPI == F32_BIAS_SIGMOID) v = 1.0f / (1.0f + expf(-v));
         if (EPI == F32_BIAS_RES_SCALE) v = p.res[(size_t)m * p.ldres + n] + cs * v;
         if (EPI == F32_BIAS_ADD2) {
           p.out[(size_t)m * p.ldc + n] = v + p.add[(size_t)m * p.ldc + n];
@@ -110,6 +112,8 @@ hipError_t launch_gemm_f32(int epi, const GemmF32Params& p, hipStream_t s) {
     case F32_BIAS_SILU: return launch<F32_BIAS_SILU>(p, s);
     case F32_BIAS_RES_SCALE: return launch<F32_BIAS_RES_SCALE>(p, s);
     case F32_BIAS_ADD2: return launch<F32_BIAS_ADD2>(p, s);
+    case F32_BIAS_RELU: return launch<F32_BIAS_RELU>(p, s);
+    case F32_BIAS_SIGMOID: return launch<F32_BIAS_SIGMOID>(p, s);
   }
   return hipErrorInvalidValue;
 }

@@ -31,3 +31,14 @@ hipError_t launch_stft_frames(const float* wav, const float* window, int B, int 
 hipError_t launch_rdft_basis(int nfft, int rows, float* basis, hipStream_t s);
 hipError_t launch_magnitude(const float* spec, int rows, int nb, int lds_, int ldm, float* mag, hipStream_t s);
 hipError_t launch_log_clamp(float* x, size_t n, float lo, hipStream_t s);
+
+// prosody encoder (ECAPA-TDNN, prosody_kernels.hip) -- activations are time-major [T][ld] fp32
+hipError_t launch_im2col_dil(const float* x, int ldx, const float* add, int ldadd, int T, int C, int k, int dil, float* col, hipStream_t s);
+hipError_t launch_ln_rows(const float* x, int ldx, int T, int C, const float* w, const float* b, float eps, int act_tanh, float* out, int ldo, hipStream_t s);
+hipError_t launch_copy_cols(const float* x, int ldx, int T, int C, float* out, int ldo, hipStream_t s);
+hipError_t launch_col_stats(const float* x, int ldx, int T, int C, float eps, float* mean, float* stdv, hipStream_t s);
+hipError_t launch_scale_cols_add(const float* x, int ldx, const float* scale, const float* res, int ldr, int T, int C, float* out, int ldo, hipStream_t s);
+hipError_t launch_softmax_pool(const float* att, int lda, const float* x, int ldx, int T, int C, float eps, float* mean, float* stdv, hipStream_t s);
+hipError_t launch_l2_normalize(const float* x, int n, float eps, float* out, hipStream_t s);
+hipError_t launch_kaldi_frames(const float* wav, int n, int frames, int win, int shift, int padded, float preemph, float* out, hipStream_t s);
+hipError_t launch_power(const float* spec, int rows, int nb, int lds_, int ldp, float* pw, hipStream_t s);

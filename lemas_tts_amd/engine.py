@@ -296,3 +296,55 @@ class ResampleEngine(_Streamed):
             _lib.check(_lib.lib().lemas_resample_forward(self._h, wav.data_ptr(), B, nw, out.data_ptr(), s), "lemas_resample_forward")
             self._exit()
         return out
+
+
+class ProsodyEngine(_Streamed):
+    """Owns one ``lemas_prosody`` (ECAPA-TDNN weights + workspaces + the kaldi-fbank constants) on one device."""
+
+    def __init__(self, arch, state_dict: dict, device="cuda:0"):
+        super().__init__(device)
+        self.arch = arch
+        L = _lib.lib()
+        n = len(arch.channels)
+        pad = lambda t: (C.c_int32 * 8)(*(list(t) + [0] * (8 - n)))
+        cfg = _lib.ProsodyConfig(n, pad(arch.channels), pad(arch.kernel_sizes), pad(arch.dilations), pad(arch.groups),
+                                 arch.attention_channels, arch.res2net_scale, arch.se_channels, int(arch.global_context),
+                                 arch.embed_dim, arch.input_dim)
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(L.lemas_prosody_create(C.byref(cfg), C.byref(self._h)), "lemas_prosody_create")
+            for name, v in state_dict.items():
+                _load(L.lemas_prosody_load_weight, self._h, name, v)
+            _lib.check(L.lemas_prosody_finalize(self._h), "lemas_prosody_finalize")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().lemas_prosody_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def fbank(self, wav16k: torch.Tensor) -> torch.Tensor:
+        """16 kHz audio [n] (n >= 400) -> kaldi fbank [frames, 80]"""
+        with torch.cuda.device(self.device):
+            w = wav16k.reshape(-1).to(self.device, torch.float32).contiguous()
+            frames = int(_lib.lib().lemas_prosody_fbank_frames(w.numel()))
+            out = torch.empty((max(frames, 0), 80), device=self.device, dtype=torch.float32)
+            s = self._enter(w, out)
+            _lib.check(_lib.lib().lemas_prosody_fbank(self._h, w.data_ptr(), w.numel(), out.data_ptr(), s), "lemas_prosody_fbank")
+            self._exit()
+        return out
+
+    def encode(self, fbank: torch.Tensor) -> torch.Tensor:
+        """fbank [T, input_dim] -> L2-normalised embedding [embed_dim] (one sample, no padding mask: cfm.py:259)"""
+        with torch.cuda.device(self.device):
+            f = fbank.to(self.device, torch.float32).contiguous()
+            emb = torch.empty((self.arch.embed_dim,), device=self.device, dtype=torch.float32)
+            s = self._enter(f, emb)
+            _lib.check(_lib.lib().lemas_prosody_encode(self._h, f.data_ptr(), f.shape[0], emb.data_ptr(), s), "lemas_prosody_encode")
+            self._exit()
+        return emb

@@ -138,6 +138,9 @@ def load_model(model_cls, model_cfg, ckpt_path, mel_spec_type=mel_spec_type, voc
         vocab_size = len(vocab_char_map)
     args = dict(arch=arch, vocab_size=vocab_size, vocab_char_map=vocab_char_map, use_prosody_encoder=use_prosody_encoder,
                 num_channels=n_mel_channels, odeint_kwargs=dict(method=ode_method))
+    if use_prosody_encoder and prosody_ckpt_path:                      # cfm.py:139-145: the Pretssel ECAPA encoder next to the CFM
+        from ..model.prosody_encoder import ProsodyEncoder
+        args["prosody_encoder"] = ProsodyEncoder(prosody_cfg_path or None, prosody_ckpt_path, device=_cuda(device))
     if state_dict is not None:
         return CFM(state_dict=state_dict, device=_cuda(device), **args)
     return load_checkpoint(args, ckpt_path, device, use_ema=use_ema)

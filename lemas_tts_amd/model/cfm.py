@@ -60,7 +60,8 @@ class CFM:
 
     def __init__(self, arch: DiTArch, vocab_size: int, state_dict: dict, *, vocab_char_map: Optional[dict] = None,
                  device="cuda:0", use_prosody_encoder: bool = False, num_channels: int = 100,
-                 odeint_kwargs: dict = dict(method="euler"), mel_spec_module=None, fp8_weights: bool = False):
+                 odeint_kwargs: dict = dict(method="euler"), mel_spec_module=None, fp8_weights: bool = False,
+                 prosody_encoder=None):
         if odeint_kwargs.get("method", "euler") != "euler":
             raise NotImplementedError("only the fixed-grid Euler solver of the shipped configs is built")
         self.arch = arch
@@ -71,7 +72,7 @@ class CFM:
             from .modules import MelSpec
             mel_spec_module = MelSpec(n_mel_channels=num_channels, device=device)
         self.mel_spec = mel_spec_module
-        self.prosody_encoder = None              # Pretssel ECAPA encoder: a "next" row
+        self.prosody_encoder = prosody_encoder   # model.prosody_encoder.ProsodyEncoder (cfm.py:139-145), or None: embeds are inputs
         self.odeint_kwargs = odeint_kwargs
         self.engine = DiTEngine(arch, vocab_size, state_dict, device=device, prosody=use_prosody_encoder)
         if fp8_weights:      # BASELINE config 5: block GEMMs on fp8-e4m3 MFMA (MXFP8 activations, per-channel weight scales)
@@ -101,6 +102,9 @@ class CFM:
             raise NotImplementedError("ref_ratio < 1 (random clip-and-shuffle of the prompt) is outside the hot path")
         dev = self.device
         if cond.ndim == 2:
+            raw_audio = cond
+            if prosody_embeds is None and self.prosody_encoder is not None and use_prosody_encoder and self.use_prosody_encoder:
+                prosody_embeds = self.prosody_encoder.embed_prompt(raw_audio, self.mel_spec.target_sample_rate)   # cfm.py:248-262
             cond = self.mel_spec(cond).permute(0, 2, 1)              # cfm.py:232-236
         assert cond.shape[-1] == self.num_channels
         cond = cond.to(dev, torch.float32)
