@@ -147,10 +147,55 @@ def main():
              cfg=2.0, coef=3.0, noise_seed=104, edit_spans=[(0.4, 0.7), (1.3, 1.6)])
     run_case("mini_prosody", DiTArch(depth=2), wseed=15, B=2, F=64, lens=None, Nt=[20, 26],
              duration=[130, 144], steps=3, cfg=2.0, coef=5, noise_seed=105, prosody=True)
+    run_edit_mask_cases()
     run_prosody_case("prosody_enc_short", 17, 41)
     run_prosody_case("prosody_enc_10s", 18, 998)
     run_case("full_plain", FULL, wseed=16, B=1, F=150, lens=None, Nt=[60], duration=400, steps=3,
              cfg=2.0, coef=5, noise_seed=106)
+
+
+def run_edit_mask_cases():
+    """Edit-mask builder of the speech-edit entry point (scripts/speech_edit_multilingual.py:125-161, SURVEY.md 8a row a-E):
+    the reference's own ``gen_wav_multilingual`` is run with a stand-in ``tts`` whose sampler records what it is handed."""
+    import types
+    ref_shims.install()
+    api_stub = types.ModuleType("lemas_tts.api")
+    api_stub.TTS = object
+    sys.modules.setdefault("lemas_tts.api", api_stub)
+    from lemas_tts.scripts.speech_edit_multilingual import gen_wav_multilingual
+
+    class _Model:
+        mel_spec = types.SimpleNamespace(target_sample_rate=24000, hop_length=256)
+
+        def sample(self, cond, text, duration, **kw):
+            self.got = dict(edit_mask=kw["edit_mask"].clone(), duration=duration, text=text, nw=cond.shape[-1], kw={k: v for k, v in kw.items() if k != "edit_mask"})
+            return torch.zeros(1, duration + 1, 100), None
+
+    class _Voc:
+        def decode(self, mel):
+            return torch.zeros(1, 256 * (mel.shape[-1] - 1))
+
+    cases = {
+        "one_span": (72000, [(1.0, 1.5)]),
+        "three_spans_30s": (720000, [(4.0, 6.5), (12.0, 15.0), (22.0, 24.0)]),
+        "span_at_start": (48000, [(0.0, 0.4)]),
+        "span_to_the_end": (50000, [(1.7, 2.0833)]),
+        "touching_margins": (96000, [(1.0, 1.2), (1.35, 1.6)]),
+        "odd_length": (61111, [(0.33, 0.77), (1.9, 2.2)]),
+    }
+    out = {}
+    for name, (nw, spans) in cases.items():
+        tts = types.SimpleNamespace(device="cpu", ema_model=_Model(), vocoder=_Voc(), frontend=None, mel_spec_type="vocos")
+        g = torch.Generator().manual_seed(nw)
+        audio = torch.randn(nw, generator=g) * 0.3          # rms > 0.1: no rescale
+        gen_wav_multilingual(tts, audio, 24000, "ab", spans, nfe_step=2, cfg_strength=2.0, sway_sampling_coef=3.0, seed=0)
+        got = tts.ema_model.got
+        out[name + "/nw"] = np.int64(nw)
+        out[name + "/spans"] = np.asarray(spans, dtype=np.float64)
+        out[name + "/edit_mask"] = got["edit_mask"].numpy()
+        out[name + "/duration"] = np.int64(got["duration"])
+        print(f"edit mask {name}: frames {got['edit_mask'].shape[-1]} regenerated {int((~got['edit_mask']).sum())} duration {got['duration']} text {got['text']}")
+    np.savez_compressed(os.path.join(GOLDEN, "edit_masks.npz"), **out)
 
 
 if __name__ == "__main__":
