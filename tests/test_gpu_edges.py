@@ -113,3 +113,37 @@ def test_no_cfg_and_no_sway_paths():
         out, _ = m.sample(cond, text, N, y0=y0, steps=3, cfg_strength=cfg, sway_sampling_coef=coef, use_acc_grl=False)
         ref, _ = o.sample(cond, text, N, y0=y0, steps=3, cfg_strength=cfg, sway_sampling_coef=coef)
         assert _mse(out.cpu(), ref, [F_], [N]) <= 1e-4, (cfg, coef)
+
+
+def test_shape_churn_reuses_one_engine_correctly():
+    """one engine, a sequence of different shapes / batch sizes / option flips (graph cache keyed by shape, workspaces that
+    only grow, AdaLN-table cache keyed by the t-grid): every result must equal what a fresh run of that case gives"""
+    m, o = _pair()
+
+    def case(B, F_, N, nt, steps, seed):
+        cond = torch.stack([torch.from_numpy(synth.synth_cond_mel(seed + b, F_)) for b in range(B)])
+        text = torch.stack([torch.from_numpy(synth.synth_tokens(seed + 10 + b, nt, VOCAB)) for b in range(B)])
+        y0 = torch.stack([torch.from_numpy(synth.synth_noise(seed + 20 + b, N)) for b in range(B)])
+        return cond, text, y0, dict(steps=steps, cfg_strength=2.0, sway_sampling_coef=5)
+
+    plan = [(1, 40, 200, 30, 3, 300), (2, 64, 333, 50, 2, 310), (1, 40, 200, 30, 3, 300), (4, 30, 129, 20, 3, 320), (1, 100, 640, 90, 2, 330),
+            (1, 40, 200, 30, 4, 300), (1, 40, 200, 30, 3, 300)]
+    first = {}
+    for i, (B, F_, N, nt, steps, seed) in enumerate(plan):
+        if i == 3:
+            m.engine.set_option("dual", 0)
+        if i == 4:
+            m.engine.set_option("graph", 0)
+        if i == 5:
+            m.engine.set_option("dual", 1); m.engine.set_option("graph", 1)
+        cond, text, y0, kw = case(B, F_, N, nt, steps, seed)
+        out, _ = m.sample(cond, text, N, y0=y0, use_acc_grl=False, **kw)
+        out = out.cpu()
+        key = (B, F_, N, nt, steps, seed)
+        if key in first:
+            np.testing.assert_array_equal(out.numpy(), first[key].numpy(), err_msg=f"step {i}: same case, different bits")
+        else:
+            first[key] = out
+            ref, _ = o.sample(cond, text, N, y0=y0, **kw)
+            assert _mse(out, ref, [F_] * B, [N] * B) <= 1e-4, (i, key)
+    m.engine.set_option("dual", 1); m.engine.set_option("graph", 1)
