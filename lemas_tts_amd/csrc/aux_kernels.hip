@@ -89,17 +89,20 @@ __global__ __launch_bounds__(256) void ln_affine_kernel(const float* __restrict_
 
 // ---- GRN (modules.py:225-234): Gx[b,c] = ||x[b,:,c]||_2 over the SEQUENCE; Nx = Gx / (mean_c Gx + 1e-6);
 // out = gamma * (x * Nx) + beta + x.   Kernel 1: column norms; kernel 2: apply.
-__global__ __launch_bounds__(256) void grn_norm_kernel(const float* __restrict__ x, float* __restrict__ gx, int N, int C) {
+// partial sums of squares: grid (C/64, B, GRN_SPLIT); chunk z covers rows z, z + GRN_SPLIT*4, ... (fixed order: deterministic)
+constexpr int GRN_SPLIT = 16;
+__global__ __launch_bounds__(256) void grn_norm_kernel(const float* __restrict__ x, float* __restrict__ gx_part, int N, int C) {
   __shared__ float part[4][64];
-  const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+  const int b = blockIdx.y, z = blockIdx.z, c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
   float s = 0.f;
-  for (int n = rg; n < N; n += 4) {
+  for (int n = z * 4 + rg; n < N; n += 4 * GRN_SPLIT) {
     const float v = x[((size_t)b * N + n) * C + c];
     s = fmaf(v, v, s);
   }
   part[rg][threadIdx.x & 63] = s;
   __syncthreads();
-  if (rg == 0) gx[(size_t)b * C + c] = sqrtf(part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+  if (rg == 0)
+    gx_part[((size_t)b * GRN_SPLIT + z) * C + c] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
 }
 template <int C>
 __global__ __launch_bounds__(256) void grn_apply_kernel(float* __restrict__ x, const float* __restrict__ gx,
@@ -111,7 +114,13 @@ __global__ __launch_bounds__(256) void grn_apply_kernel(float* __restrict__ x, c
   const int lane = threadIdx.x & 63, b = row / N;
   float g[PER], s = 0.f;
 #pragma unroll
-  for (int i = 0; i < PER; ++i) { g[i] = gx[(size_t)b * C + lane + 64 * i]; s += g[i]; }
+  for (int i = 0; i < PER; ++i) {
+    float q = 0.f;
+#pragma unroll
+    for (int z = 0; z < GRN_SPLIT; ++z) q += gx[((size_t)b * GRN_SPLIT + z) * C + lane + 64 * i];
+    g[i] = sqrtf(q);
+    s += g[i];
+  }
   const float denom = wave_sum(s) * (1.0f / C) + 1e-6f;
   float* xr = x + (size_t)row * C;
 #pragma unroll
@@ -284,7 +293,7 @@ hipError_t launch_ln_affine(const float* x, const float* w, const float* b, floa
 }
 hipError_t launch_grn(float* x, float* gx_scratch, const float* gamma, const float* beta, int B, int N, int C, hipStream_t s) {
   if (C != 1024) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(grn_norm_kernel, dim3(C / 64, B), dim3(256), 0, s, x, gx_scratch, N, C);
+  hipLaunchKernelGGL(grn_norm_kernel, dim3(C / 64, B, GRN_SPLIT), dim3(256), 0, s, x, gx_scratch, N, C);   // gx_scratch: [B][GRN_SPLIT][C]
   hipLaunchKernelGGL(grn_apply_kernel<1024>, dim3((B * N + 3) / 4), dim3(256), 0, s, x, gx_scratch, gamma, beta, B * N, N);
   return hipGetLastError();
 }

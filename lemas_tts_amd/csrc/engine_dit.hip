@@ -343,7 +343,7 @@ int lemas_dit::text_embed(const lemas_sample_args* a, hipStream_t s) {
     RC_TRY(d_t1.ensure((size_t)rows * td * 4));
     RC_TRY(d_t2.ensure((size_t)rows * td * 4));
     RC_TRY(d_t3.ensure((size_t)rows * 2 * td * 4));
-    RC_TRY(d_gx.ensure((size_t)BB * 2 * td * 4));
+    RC_TRY(d_gx.ensure((size_t)BB * 16 * 2 * td * 4));   // [BB][GRN_SPLIT = 16][2 td] partial sums of squares
     for (int i = 0; i < cfg.conv_layers; ++i) {
       const std::string p = T("text_embed.text_blocks." + std::to_string(i) + ".");
       HIP_TRY(launch_dwconv7(d_te.as<float>(), ws.ptr(p + "dwconv.weight"), ws.ptr(p + "dwconv.bias"), d_t1.as<float>(), BB, N, td, s));
