@@ -145,3 +145,35 @@ def test_config2_full_size_last_two_euler_steps():
     print(f"\n[config2 full size] last-2-steps mel-MSE {mse:.3e}; CFG flow relative rms error at t=0 {rel:.3e}")
     assert mse <= 1e-4
     assert rel < 1e-2
+
+
+def test_config1_plumbing_sentence_nfe16():
+    """configs[0]: one pre-phonemised English sentence through the token-list path, 4 s prompt
+    (F = 375), N = 750, NFE = 16, cfg 2, coef 5, vocoder included.  The reference runs this case on its CPU path; the build
+    has no CPU path (tier rule), so it is a GPU parity case against the oracle like the others."""
+    from lemas_tts_amd.engine import VocosEngine
+    from lemas_tts_amd.model.cfm import CFM
+    from oracle import lemas_oracle as O
+    phones = ("(en) ð ə _ k w ɪ k _ b ɹ aʊ n _ f ɑ k s _ dʒ ʌ m p s _ oʊ v ɚ _ ð ə _ l eɪ z i _ d ɔ ɡ .").split()
+    ref_phones = "(en) h ə l oʊ _ w ɜ l d .".split()
+    symbols = sorted(set(phones) | set(ref_phones))
+    vocab = {s: i for i, s in enumerate(symbols)}
+    arch = DiTArch(depth=2)
+    sd = synth.synth_cfm_state_dict(arch, len(vocab), 131)
+    vsd = synth.synth_vocos_state_dict(132)
+    F_, N, S = 375, 750, 16
+    cond = torch.from_numpy(synth.synth_cond_mel(133, F_))[None]
+    y0 = torch.from_numpy(synth.synth_noise(134, N))[None]
+    m = CFM(arch, len(vocab), sd, vocab_char_map=vocab, device="cuda:0")
+    out, _ = m.sample(cond, [ref_phones + phones + ["<unk>"]], N, steps=S, cfg_strength=2.0, sway_sampling_coef=5, y0=y0, use_acc_grl=False)
+    text = O.tokens_to_idx([ref_phones + phones + ["<unk>"]], vocab)          # unknown token -> 0 (model/utils.py:87-94)
+    assert int(text[0, -1]) == 0
+    ref, _ = O.OracleCFM(sd, arch).sample(cond, text, N, y0=y0, steps=S, cfg_strength=2.0, sway_sampling_coef=5)
+    mse = _mse_generated(out.cpu(), ref, [F_], [N])
+    print(f"\n[config1 N=750 NFE=16] mel-MSE {mse:.3e}")
+    assert mse <= 1e-4
+    mel = out[:, F_ - 1:, :].permute(0, 2, 1)
+    wav = VocosEngine(vsd, device="cuda:0").decode(mel).cpu()
+    wref = O.OracleVocos(vsd).decode(mel.cpu())
+    assert wav.shape == (1, 256 * (N - F_))
+    assert (wav - wref).abs().max().item() < 1e-4 * max(1.0, wref.abs().max().item())
