@@ -90,12 +90,12 @@ class CFM:
                seed=None, max_duration=4096, vocoder: Optional[Callable] = None, no_ref_audio=False,
                duplicate_test=False, t_inter=0.1, edit_mask=None, use_acc_grl=True, use_prosody_encoder=True,
                ref_ratio=1, y0: Optional[torch.Tensor] = None, prosody_embeds: Optional[torch.Tensor] = None,
-               return_trajectory: bool = False):
+               return_trajectory: bool = False, cond_noise: Optional[torch.Tensor] = None):
         """Extra keyword-only inputs over the reference: ``y0`` (explicit ODE start; the reference draws it on
         its own device, cfm.py:430-435), ``prosody_embeds`` [B,512] (what the prosody encoder would return,
         cfm.py:261-263) and ``return_trajectory`` (the reference always returns it; its callers discard it)."""
-        if no_ref_audio or duplicate_test:
-            raise NotImplementedError("no_ref_audio / duplicate_test debug corners are outside the hot path")
+        if duplicate_test:
+            raise NotImplementedError("the duplicate_test debug corner (cfm.py:307-309) is outside the hot path")
         if use_acc_grl and ref_ratio is None:
             raise TypeError("'<' not supported between instances of 'NoneType' and 'int'")  # cfm.py:273 hazard
         if use_acc_grl and ref_ratio < 1:
@@ -109,6 +109,7 @@ class CFM:
         assert cond.shape[-1] == self.num_channels
         cond = cond.to(dev, torch.float32)
         batch, cond_seq_len = cond.shape[:2]
+        cond_mean = cond.mean(dim=1, keepdim=True)                           # cfm.py:239
         if lens is None:
             lens = torch.full((batch,), cond_seq_len, dtype=torch.long)
         lens = lens.to("cpu", torch.long)
@@ -128,6 +129,17 @@ class CFM:
         n = int(duration.amax())
 
         cond = F.pad(cond, (0, 0, 0, n - cond_seq_len), value=0.0)
+        pros = prosody_embeds if (use_prosody_encoder and self.use_prosody_encoder) else None
+        if no_ref_audio:
+            # cfm.py:320-324: the conditioning becomes noise around the prompt's mean (the draw is an explicit input here,
+            # ``cond_noise``; the reference takes it from the global RNG).  It overwrites cond AFTER the prosody-to-mel
+            # projection was added (:313-318), which the engine adds inside prepare(): that combination is not built.
+            if pros is not None:
+                raise NotImplementedError("no_ref_audio together with the prosody encoder is not built")
+            if cond_noise is None:
+                cond_noise = torch.randn(batch, n, self.num_channels, device=dev, dtype=torch.float32)
+            rc = cond_noise.to(dev, torch.float32) * 0.1 + cond_mean
+            cond = rc / rc.mean(dim=1, keepdim=True) * cond_mean
         cond_mask = F.pad(cond_mask, (0, n - cond_mask.shape[-1]), value=False)
         seq_len = duration.to(torch.int32) if batch > 1 else None          # cfm.py:336-339
 
@@ -141,10 +153,12 @@ class CFM:
         assert tuple(y0.shape) == (batch, n, self.num_channels), (tuple(y0.shape), (batch, n, self.num_channels))
 
         t = time_grid(steps, sway_sampling_coef)
-        pros = prosody_embeds if (use_prosody_encoder and self.use_prosody_encoder) else None
         out, y_final, traj = self.engine.sample(
             cond, cond_mask, text, t.numpy(), y0, cond_frames=cond_seq_len, cfg_strength=float(cfg_strength),
             seq_len=seq_len, prosody=pros, want_trajectory=return_trajectory)
+        if no_ref_audio:                                                     # cfm.py:464-466: re-centre the generated part
+            gen = out[:, cond_seq_len:, :]
+            out[:, cond_seq_len:, :] = gen - (gen.mean(dim=1, keepdim=True) - cond_mean)
         if vocoder is not None:
             out = vocoder(out.permute(0, 2, 1))
         return out, traj

@@ -40,7 +40,7 @@ def _reference_y0(seed: int, durations) -> torch.Tensor:
 
 
 def run_case(name, arch, *, wseed, B, F, lens, Nt, duration, steps, cfg, coef, noise_seed,
-             edit_spans=None, prosody=False, use_acc_grl=False):
+             edit_spans=None, prosody=False, use_acc_grl=False, no_ref_audio=False):
     sd_np = synth.synth_cfm_state_dict(arch, VOCAB, wseed, prosody=prosody)
     sd = {k: torch.from_numpy(v) for k, v in sd_np.items()}
     cfm = ref_shims.build_reference_cfm(arch.reference_kwargs(), VOCAB, sd, use_prosody=prosody)
@@ -84,9 +84,20 @@ def run_case(name, arch, *, wseed, B, F, lens, Nt, duration, steps, cfg, coef, n
         cond_in = audio
         kw["use_prosody_encoder"] = True
 
+    cond_noise = None
+    if no_ref_audio:
+        # cfm.py:321 draws randn_like(cond) from the global RNG before the (re-seeded) y0 draws: pin that draw
+        kw["no_ref_audio"] = True
+        n_pad = int(max(max(Nt[b], F) + 1 for b in range(B)) if isinstance(duration, int) else max(duration))
+        n_pad = max(n_pad, duration if isinstance(duration, int) else 0)
+        torch.manual_seed(noise_seed + 7)
+        cond_noise = torch.randn(B, n_pad, 100)
+        torch.manual_seed(noise_seed + 7)
     t0 = time.time()
     out, traj = cfm.sample(cond=cond_in, text=torch.from_numpy(text), duration=dur_arg, **kw)
     dt = time.time() - t0
+    if cond_noise is not None:
+        assert cond_noise.shape == out.shape, (cond_noise.shape, out.shape)
     N = out.shape[1]
     lens_eff = [F] * B if lens is None else lens
     durs = torch.maximum(torch.maximum(torch.tensor([int((text[b] != -1).sum()) for b in range(B)]),
@@ -95,7 +106,7 @@ def run_case(name, arch, *, wseed, B, F, lens, Nt, duration, steps, cfg, coef, n
     y0 = _reference_y0(noise_seed, durs.tolist())
     assert y0.shape == out.shape and torch.equal(y0, traj[0]), "y0 replication drifted"
 
-    if use_acc_grl is False and not prosody and edit_spans is None and B == 1:
+    if use_acc_grl is False and not prosody and edit_spans is None and B == 1 and not no_ref_audio:
         out2, _ = cfm.sample(cond=cond_in, text=torch.from_numpy(text), duration=dur_arg,
                              **{**kw, "use_acc_grl": True})
         assert torch.equal(out, out2), "accent-GRL flag must be a forward no-op at ref_ratio>=1"
@@ -112,6 +123,8 @@ def run_case(name, arch, *, wseed, B, F, lens, Nt, duration, steps, cfg, coef, n
         fx["edit_mask"] = edit_mask.numpy()
     if pros is not None:
         fx["prosody_embeds"] = pros
+    if cond_noise is not None:
+        fx["cond_noise"] = cond_noise.numpy()
     np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), **fx)
     print(f"{name}: N={N} steps={steps} ref {dt:.1f}s |out| mean {out.abs().mean():.4f} "
           f"traj[-1] std {traj[-1].std():.4f}")
@@ -147,6 +160,8 @@ def main():
              cfg=2.0, coef=3.0, noise_seed=104, edit_spans=[(0.4, 0.7), (1.3, 1.6)])
     run_case("mini_prosody", DiTArch(depth=2), wseed=15, B=2, F=64, lens=None, Nt=[20, 26],
              duration=[130, 144], steps=3, cfg=2.0, coef=5, noise_seed=105, prosody=True)
+    run_case("mini_noref", MINI, wseed=19, B=1, F=50, lens=None, Nt=[22], duration=140, steps=3,
+             cfg=2.0, coef=5, noise_seed=107, no_ref_audio=True)
     run_edit_mask_cases()
     run_prosody_case("prosody_enc_short", 17, 41)
     run_prosody_case("prosody_enc_10s", 18, 998)

@@ -278,12 +278,15 @@ class OracleCFM:
     def sample(self, cond: Tensor, text: Tensor, duration, *, y0: Tensor, lens: Optional[Tensor] = None,
                steps: int = 32, cfg_strength: float = 1.0, sway_sampling_coef: Optional[float] = None,
                max_duration: int = 4096, edit_mask: Optional[Tensor] = None,
-               prosody_embeds: Optional[Tensor] = None, t_grid: Optional[Tensor] = None):
+               prosody_embeds: Optional[Tensor] = None, t_grid: Optional[Tensor] = None,
+               no_ref_audio: bool = False, cond_noise: Optional[Tensor] = None):
         """``cond`` is a mel [B,F,100]; ``text`` int64 [B,Nt] padded with -1; ``y0`` [B,N,100] is the
         explicit ODE start (the reference draws it at cfm.py:430-435).  ``prosody_embeds`` [B,512]
-        stands for the prosody-encoder output (cfm.py:248-265, a "next" row)."""
+        stands for the prosody-encoder output (cfm.py:248-265, a "next" row).  ``no_ref_audio`` (cfm.py:320-324, 464-466)
+        replaces the conditioning by noise around the prompt's mean; ``cond_noise`` [B,N,100] is the ``randn_like`` draw."""
         cond = cond.float()
         b, f = cond.shape[:2]
+        cond_mean = cond.mean(dim=1, keepdim=True)                         # :239
         if lens is None:
             lens = torch.full((b,), f, dtype=torch.long)
         cond_mask = lens_to_mask(lens)                                     # :293
@@ -300,6 +303,9 @@ class OracleCFM:
             pm = F.pad(prosody_embeds[:, None, :].expand(-1, f, -1), (0, 0, 0, n - f))     # :265,:314-316
             cond = cond + F.linear(pm, *self.prosody_to_mel)               # :317-318
             prosody_text = prosody_embeds[:, None, :].expand(-1, text.shape[1], -1)        # :376-378
+        if no_ref_audio:                                                   # :320-324
+            rc = cond_noise.float() * 0.1 + cond_mean
+            cond = rc / rc.mean(dim=1, keepdim=True) * cond_mean
         cond_mask = F.pad(cond_mask, (0, n - cond_mask.shape[-1]), value=False)[..., None]  # :326-327
         step_cond = torch.where(cond_mask, cond, torch.zeros_like(cond))   # :388-390 (grl = identity fwd)
         mask = lens_to_mask(duration) if b > 1 else None                   # :336-339
@@ -316,6 +322,9 @@ class OracleCFM:
         traj = euler_solve(fn, y0.float(), t)                              # :456
         self.dit.clear_cache()                                             # :457
         out = torch.where(cond_mask, cond, traj[-1])                       # :459-461
+        if no_ref_audio:                                                   # :464-466
+            out = out.clone()
+            out[:, f:, :] = out[:, f:, :] - (out[:, f:, :].mean(dim=1, keepdim=True) - cond_mean)
         return out, traj
 
 

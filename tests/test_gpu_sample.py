@@ -15,7 +15,7 @@ from lemas_tts_amd.model.layout import DiTArch
 pytestmark = pytest.mark.gpu
 
 MSE_TOL = 1e-4
-GOLDEN_CASES = ["mini_plain", "mini_nocfg_nosway", "mini_batch", "mini_edit", "mini_prosody", "full_plain"]
+GOLDEN_CASES = ["mini_plain", "mini_nocfg_nosway", "mini_batch", "mini_edit", "mini_prosody", "mini_noref", "full_plain"]
 
 
 def _load(golden_dir, name):
@@ -50,6 +50,8 @@ def _run_case(fx, arch, sd, graph=True, traj=True):
         kw["edit_mask"] = torch.from_numpy(fx["edit_mask"])
     if "prosody_embeds" in fx:
         kw["prosody_embeds"] = torch.from_numpy(fx["prosody_embeds"])
+    if "cond_noise" in fx:
+        kw.update(no_ref_audio=True, cond_noise=torch.from_numpy(fx["cond_noise"]))
     dur = fx["duration"]
     out, tr = m.sample(torch.from_numpy(fx["cond"]), torch.from_numpy(fx["text"]),
                        int(dur[0]) if B == 1 else torch.from_numpy(dur), lens=torch.from_numpy(fx["lens"]),
@@ -85,7 +87,7 @@ def test_sampler_matches_reference_golden(golden_dir, name):
     assert np.array_equal(traj[0], fx["y0"])
     assert mse <= MSE_TOL, (mse, mx)
     # conditioning frames of `out` are copied, not computed (cfm.py:461): exact
-    if "edit_mask" not in fx and "prosody_embeds" not in fx:
+    if "edit_mask" not in fx and "prosody_embeds" not in fx and "cond_noise" not in fx:
         for b in range(int(fx["B"])):
             L = int(fx["lens"][b])
             np.testing.assert_array_equal(out[b, :L], fx["cond"][b, :L])

@@ -14,7 +14,7 @@ from lemas_tts_amd import synth
 from lemas_tts_amd.model.layout import DiTArch
 from oracle import lemas_oracle as O
 
-CASES = ["mini_plain", "mini_nocfg_nosway", "mini_batch", "mini_edit", "mini_prosody", "full_plain"]
+CASES = ["mini_plain", "mini_nocfg_nosway", "mini_batch", "mini_edit", "mini_prosody", "mini_noref", "full_plain"]
 ATOL = 5e-5   # measured max |err| 3.7e-6 (fp32 vs fp32, different summation order); |out| ~ 1.8
 
 
@@ -36,6 +36,8 @@ def oracle_sample(fx, arch, sd):
         kw["edit_mask"] = torch.from_numpy(fx["edit_mask"])
     if "prosody_embeds" in fx:
         kw["prosody_embeds"] = torch.from_numpy(fx["prosody_embeds"])
+    if "cond_noise" in fx:
+        kw.update(no_ref_audio=True, cond_noise=torch.from_numpy(fx["cond_noise"]))
     B = int(fx["B"])
     dur = fx["duration"]
     return cfm.sample(torch.from_numpy(fx["cond"]), torch.from_numpy(fx["text"]),
@@ -53,7 +55,7 @@ def test_oracle_matches_reference_golden(golden_dir, name):
     np.testing.assert_allclose(traj.numpy(), fx["trajectory"], atol=ATOL, rtol=0)
     np.testing.assert_allclose(out.numpy(), fx["out"], atol=ATOL, rtol=0)
     # the conditioning region of ``out`` is the (prosody-shifted) cond itself (cfm.py:461)
-    if "edit_mask" not in fx and "prosody_embeds" not in fx:
+    if "edit_mask" not in fx and "prosody_embeds" not in fx and "cond_noise" not in fx:
         for b in range(int(fx["B"])):
             L = int(fx["lens"][b])
             np.testing.assert_array_equal(out.numpy()[b, :L], fx["cond"][b, :L])
