@@ -72,6 +72,10 @@ typedef struct {
   float* y;                   /* device [B,N,mel]  in: y0 noise (cfm.py:430-435); out: trajectory[-1] */
   float* out;                 /* device [B,N,mel]  where(cond_mask, cond, y) (cfm.py:459-461); may be NULL */
   float* trajectory;          /* device [steps+1,B,N,mel] or NULL (callers discard it, utils_infer.py:543) */
+  const float* step_cond;     /* device [B,N,mel] or NULL: what the flow is conditioned on where cond_mask is set, when that is
+                               * not `cond` (+ prosody projection) itself -- the accent-GRL path conditions on cond_grl, built
+                               * from the RAW prompt mel before the prosody projection / no_ref_audio substitution and
+                               * optionally clipped-and-shuffled (cfm.py:266-283, 329-330, 387-388).  `out` still uses `cond`. */
 } lemas_sample_args;
 
 const char* lemas_last_error(void);

@@ -32,7 +32,7 @@ class SampleArgs(C.Structure):
         ("steps", C.c_int32), ("cfg_strength", C.c_float),
         ("cond", C.c_void_p), ("cond_mask", C.c_void_p), ("text", C.c_void_p), ("seq_len", C.c_void_p),
         ("prosody", C.c_void_p), ("t_grid", C.POINTER(C.c_float)),
-        ("y", C.c_void_p), ("out", C.c_void_p), ("trajectory", C.c_void_p),
+        ("y", C.c_void_p), ("out", C.c_void_p), ("trajectory", C.c_void_p), ("step_cond", C.c_void_p),
     ]
 
 

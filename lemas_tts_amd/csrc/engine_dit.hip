@@ -410,6 +410,10 @@ int lemas_dit::prepare(const lemas_sample_args* a, hipStream_t s) {
   }
   HIP_TRY(launch_cond_prepare(a->cond, a->cond_mask, pm, pm ? ws.ptr("prosody_to_mel.bias") : nullptr, B, N, F, md,
                               d_cond_eff.as<float>(), d_step_cond.as<float>(), s));
+  if (a->step_cond) {   // accent-GRL conditioning: step_cond = where(cond_mask, cond_grl, 0)  (cfm.py:387-388)
+    RC_TRY(d_t1.ensure((size_t)B * N * md * 4));
+    HIP_TRY(launch_cond_prepare(a->step_cond, a->cond_mask, nullptr, nullptr, B, N, F, md, d_t1.as<float>(), d_step_cond.as<float>(), s));
+  }
   RC_TRY(text_embed(a, s));
   // hoisted [cond | text] part of the input projection
   RC_TRY(d_ct.ensure((size_t)rows * (md + td) * 4));

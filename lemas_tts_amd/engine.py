@@ -101,7 +101,7 @@ class DiTEngine(_Streamed):
         _lib.check(_lib.lib().lemas_dit_set_option(self._h, key.encode(), int(value)), f"set_option({key})")
 
     # ------------------------------------------------------------------------------------------
-    def _args(self, cond, cond_mask, text, seq_len, prosody, t_grid, cfg_strength, cond_frames, y, out, traj):
+    def _args(self, cond, cond_mask, text, seq_len, prosody, t_grid, cfg_strength, cond_frames, y, out, traj, step_cond=None):
         B, N, _ = cond.shape
         tg = np.ascontiguousarray(np.asarray(t_grid, dtype=np.float32))
         self._tg_keep = tg
@@ -115,6 +115,7 @@ class DiTEngine(_Streamed):
         a.y = y.data_ptr() if y is not None else None
         a.out = out.data_ptr() if out is not None else None
         a.trajectory = traj.data_ptr() if traj is not None else None
+        a.step_cond = step_cond.data_ptr() if step_cond is not None else None
         return a
 
     def _canon(self, cond, cond_mask, text, seq_len, prosody):
@@ -128,17 +129,19 @@ class DiTEngine(_Streamed):
 
     def sample(self, cond, cond_mask, text, t_grid, y0, *, cond_frames: int, cfg_strength: float,
                seq_len: Optional[torch.Tensor] = None, prosody: Optional[torch.Tensor] = None,
-               want_trajectory: bool = False):
-        """cond [B,N,mel] zero-padded mel; cond_mask [B,N] bool; text [B,Nt] int64 (-1 pad); y0 [B,N,mel].
+               want_trajectory: bool = False, step_cond: Optional[torch.Tensor] = None):
+        """cond [B,N,mel] zero-padded mel; cond_mask [B,N] bool; text [B,Nt] int64 (-1 pad); y0 [B,N,mel];
+        step_cond [B,N,mel] or None: the accent-GRL conditioning (cfm.py:387-388) when it differs from cond.
         Returns (out, y_final, trajectory|None) as device tensors."""
         cond, cond_mask, text, seq_len, prosody = self._canon(cond, cond_mask, text, seq_len, prosody)
+        step_cond = None if step_cond is None else step_cond.to(self.device, torch.float32).contiguous()
         with torch.cuda.device(self.device):
             y = y0.to(self.device, torch.float32).contiguous().clone()
             out = torch.empty_like(y)
             S = len(t_grid) - 1
             traj = torch.empty((S + 1,) + tuple(y.shape), device=self.device, dtype=torch.float32) if want_trajectory else None
-            a = self._args(cond, cond_mask, text, seq_len, prosody, t_grid, cfg_strength, cond_frames, y, out, traj)
-            s = self._enter(cond, cond_mask, text, seq_len, prosody, y, out, traj)
+            a = self._args(cond, cond_mask, text, seq_len, prosody, t_grid, cfg_strength, cond_frames, y, out, traj, step_cond)
+            s = self._enter(cond, cond_mask, text, seq_len, prosody, y, out, traj, step_cond)
             _lib.check(_lib.lib().lemas_dit_sample(self._h, C.byref(a), s), "lemas_dit_sample")
             self._exit()
         return out, y, traj

@@ -37,6 +37,30 @@ def list_str_to_tensor(text, padding_value: int = -1) -> torch.Tensor:
     return torch.nn.utils.rnn.pad_sequence(rows, padding_value=padding_value, batch_first=True)
 
 
+def clip_and_shuffle(mel: torch.Tensor, mel_len: int, sample_rate: int = 24000, hop_length: int = 256, ratio=None) -> torch.Tensor:
+    """``cfm.py:39-84``: the accent-GRL conditioning segment -- a crop of the prompt mel [n_mels, T] cut into ~1 s pieces,
+    shuffled, and topped up with randomly chosen pieces to the original length.  Draws come from Python's ``random`` in the
+    reference's order (crop length unless ``ratio``, crop start, shuffle, then one ``choice`` per top-up piece), so a seeded
+    interpreter reproduces the reference's segment."""
+    import random
+    fps = int(sample_rate / hop_length)
+    seg = int(mel_len * ratio) if ratio else random.randint(int(0.25 * mel_len), int(0.75 * mel_len))
+    begin = random.randint(0, max(0, mel_len - seg))
+    piece = mel[:, begin: begin + seg]
+    pieces = [piece[:, j: j + fps] for j in range(0, piece.size(1), fps)]
+    random.shuffle(pieces)
+    order, have = list(pieces), piece.size(1)
+    if have < mel_len:
+        extra = 0
+        while extra < mel_len:
+            pick = random.choice(pieces)
+            order.append(pick)
+            extra += pick.size(1)
+    out = torch.cat(order, dim=1)[:, :mel_len]
+    assert out.shape == mel.shape, (out.shape, mel.shape)
+    return out
+
+
 def compute_sway_max(steps: int, t_start: float = 0.0, min_ratio: float = 1e-9, safety_factor: float = 0.7) -> float:
     """``cfm.py:343-373`` with the arguments of the call at ``:447``."""
     assert 0.0 <= t_start < 1.0
@@ -98,8 +122,6 @@ class CFM:
             raise NotImplementedError("the duplicate_test debug corner (cfm.py:307-309) is outside the hot path")
         if use_acc_grl and ref_ratio is None:
             raise TypeError("'<' not supported between instances of 'NoneType' and 'int'")  # cfm.py:273 hazard
-        if use_acc_grl and ref_ratio < 1:
-            raise NotImplementedError("ref_ratio < 1 (random clip-and-shuffle of the prompt) is outside the hot path")
         dev = self.device
         if cond.ndim == 2:
             raw_audio = cond
@@ -110,6 +132,14 @@ class CFM:
         cond = cond.to(dev, torch.float32)
         batch, cond_seq_len = cond.shape[:2]
         cond_mean = cond.mean(dim=1, keepdim=True)                           # cfm.py:239
+        cond_grl = None
+        if use_acc_grl:                                                      # cfm.py:266-283: built from the RAW prompt mel
+            if ref_ratio < 1:
+                if cond.shape[0] != 1:
+                    raise RuntimeError("ref_ratio < 1 needs a single prompt (the reference squeezes the batch dimension, cfm.py:274)")
+                cond_grl = clip_and_shuffle(cond[0].T.cpu(), cond.shape[1], ratio=ref_ratio).T[None].to(dev)
+            else:
+                cond_grl = cond
         if lens is None:
             lens = torch.full((batch,), cond_seq_len, dtype=torch.long)
         lens = lens.to("cpu", torch.long)
@@ -153,9 +183,14 @@ class CFM:
         assert tuple(y0.shape) == (batch, n, self.num_channels), (tuple(y0.shape), (batch, n, self.num_channels))
 
         t = time_grid(steps, sway_sampling_coef)
+        step_cond = None
+        if cond_grl is not None and (pros is not None or no_ref_audio or ref_ratio < 1):
+            # the flow is conditioned on cond_grl, not on the (prosody-shifted / replaced) cond (cfm.py:329-330, 387-388);
+            # when the two coincide the engine's default is already right
+            step_cond = F.pad(cond_grl, (0, 0, 0, n - cond_seq_len), value=0.0)
         out, y_final, traj = self.engine.sample(
             cond, cond_mask, text, t.numpy(), y0, cond_frames=cond_seq_len, cfg_strength=float(cfg_strength),
-            seq_len=seq_len, prosody=pros, want_trajectory=return_trajectory)
+            seq_len=seq_len, prosody=pros, want_trajectory=return_trajectory, step_cond=step_cond)
         if no_ref_audio:                                                     # cfm.py:464-466: re-centre the generated part
             gen = out[:, cond_seq_len:, :]
             out[:, cond_seq_len:, :] = gen - (gen.mean(dim=1, keepdim=True) - cond_mean)

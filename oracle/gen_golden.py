@@ -40,7 +40,7 @@ def _reference_y0(seed: int, durations) -> torch.Tensor:
 
 
 def run_case(name, arch, *, wseed, B, F, lens, Nt, duration, steps, cfg, coef, noise_seed,
-             edit_spans=None, prosody=False, use_acc_grl=False, no_ref_audio=False):
+             edit_spans=None, prosody=False, use_acc_grl=False, no_ref_audio=False, ref_ratio=1, pyseed=None):
     sd_np = synth.synth_cfm_state_dict(arch, VOCAB, wseed, prosody=prosody)
     sd = {k: torch.from_numpy(v) for k, v in sd_np.items()}
     cfm = ref_shims.build_reference_cfm(arch.reference_kwargs(), VOCAB, sd, use_prosody=prosody)
@@ -61,7 +61,7 @@ def run_case(name, arch, *, wseed, B, F, lens, Nt, duration, steps, cfg, coef, n
         assert edit_mask.shape[1] == F, (edit_mask.shape, F)
 
     kw = dict(steps=steps, cfg_strength=cfg, sway_sampling_coef=coef, seed=noise_seed,
-              edit_mask=edit_mask, use_acc_grl=use_acc_grl, ref_ratio=1, lens=lens_t)
+              edit_mask=edit_mask, use_acc_grl=use_acc_grl, ref_ratio=ref_ratio, lens=lens_t)
     pros = None
     cond_in = torch.from_numpy(cond)
     if prosody:
@@ -93,6 +93,9 @@ def run_case(name, arch, *, wseed, B, F, lens, Nt, duration, steps, cfg, coef, n
         torch.manual_seed(noise_seed + 7)
         cond_noise = torch.randn(B, n_pad, 100)
         torch.manual_seed(noise_seed + 7)
+    if pyseed is not None:          # clip_and_shuffle (cfm.py:39-84) draws from Python's random
+        import random as _pyrandom
+        _pyrandom.seed(pyseed)
     t0 = time.time()
     out, traj = cfm.sample(cond=cond_in, text=torch.from_numpy(text), duration=dur_arg, **kw)
     dt = time.time() - t0
@@ -106,7 +109,7 @@ def run_case(name, arch, *, wseed, B, F, lens, Nt, duration, steps, cfg, coef, n
     y0 = _reference_y0(noise_seed, durs.tolist())
     assert y0.shape == out.shape and torch.equal(y0, traj[0]), "y0 replication drifted"
 
-    if use_acc_grl is False and not prosody and edit_spans is None and B == 1 and not no_ref_audio:
+    if use_acc_grl is False and not prosody and edit_spans is None and B == 1 and not no_ref_audio and ref_ratio >= 1:
         out2, _ = cfm.sample(cond=cond_in, text=torch.from_numpy(text), duration=dur_arg,
                              **{**kw, "use_acc_grl": True})
         assert torch.equal(out, out2), "accent-GRL flag must be a forward no-op at ref_ratio>=1"
@@ -125,6 +128,11 @@ def run_case(name, arch, *, wseed, B, F, lens, Nt, duration, steps, cfg, coef, n
         fx["prosody_embeds"] = pros
     if cond_noise is not None:
         fx["cond_noise"] = cond_noise.numpy()
+    if use_acc_grl:
+        fx["use_acc_grl"] = np.int64(1)
+        fx["ref_ratio"] = np.float64(ref_ratio)
+    if pyseed is not None:
+        fx["pyseed"] = np.int64(pyseed)
     np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), **fx)
     print(f"{name}: N={N} steps={steps} ref {dt:.1f}s |out| mean {out.abs().mean():.4f} "
           f"traj[-1] std {traj[-1].std():.4f}")
@@ -162,6 +170,10 @@ def main():
              duration=[130, 144], steps=3, cfg=2.0, coef=5, noise_seed=105, prosody=True)
     run_case("mini_noref", MINI, wseed=19, B=1, F=50, lens=None, Nt=[22], duration=140, steps=3,
              cfg=2.0, coef=5, noise_seed=107, no_ref_audio=True)
+    run_case("mini_grl_prosody", DiTArch(depth=2), wseed=20, B=2, F=48, lens=None, Nt=[18, 25], duration=[120, 131], steps=3,
+             cfg=2.0, coef=5, noise_seed=108, prosody=True, use_acc_grl=True)
+    run_case("mini_grl_shuffle", MINI, wseed=21, B=1, F=230, lens=None, Nt=[40], duration=400, steps=3,
+             cfg=2.0, coef=5, noise_seed=109, use_acc_grl=True, ref_ratio=0.5, pyseed=4242)
     run_edit_mask_cases()
     run_prosody_case("prosody_enc_short", 17, 41)
     run_prosody_case("prosody_enc_10s", 18, 998)

@@ -70,6 +70,26 @@ def time_grid(steps: int, sway_sampling_coef: Optional[float]) -> Tensor:
     return t ** (1 + s)
 
 
+def clip_and_shuffle(mel: Tensor, mel_len: int, ratio=None, sample_rate: int = 24000, hop_length: int = 256) -> Tensor:
+    """cfm.py:39-84 (accent-GRL conditioning segment); consumes Python's ``random`` exactly as the reference does:
+    [randint crop length unless ratio], randint crop start, shuffle(chunks), choice(chunks) per top-up chunk."""
+    import random as _random
+    fps = int(sample_rate / hop_length)
+    total = mel_len
+    seg_len = int(total * ratio) if ratio else _random.randint(int(0.25 * total), int(0.75 * total))
+    start = _random.randint(0, max(0, total - seg_len))
+    seg = mel[:, start:start + seg_len]
+    chunks = [seg[:, i * fps:(i + 1) * fps] for i in range((seg.size(1) + fps - 1) // fps)]
+    _random.shuffle(chunks)
+    out = torch.cat(chunks, dim=1)
+    if out.size(1) < total:
+        rep = []
+        while sum(c.size(1) for c in rep) < total:
+            rep.append(_random.choice(chunks))
+        out = torch.cat([out] + rep, dim=1)
+    return out[:, :total]
+
+
 def build_edit_mask(n_samples: int, spans, sr: int = 24000, hop: int = 256) -> Tensor:
     """scripts/speech_edit_multilingual.py:125-158 -- True = keep original frame."""
     offset = 0.0
@@ -279,7 +299,8 @@ class OracleCFM:
                steps: int = 32, cfg_strength: float = 1.0, sway_sampling_coef: Optional[float] = None,
                max_duration: int = 4096, edit_mask: Optional[Tensor] = None,
                prosody_embeds: Optional[Tensor] = None, t_grid: Optional[Tensor] = None,
-               no_ref_audio: bool = False, cond_noise: Optional[Tensor] = None):
+               no_ref_audio: bool = False, cond_noise: Optional[Tensor] = None,
+               use_acc_grl: bool = False, ref_ratio: float = 1):
         """``cond`` is a mel [B,F,100]; ``text`` int64 [B,Nt] padded with -1; ``y0`` [B,N,100] is the
         explicit ODE start (the reference draws it at cfm.py:430-435).  ``prosody_embeds`` [B,512]
         stands for the prosody-encoder output (cfm.py:248-265, a "next" row).  ``no_ref_audio`` (cfm.py:320-324, 464-466)
@@ -287,6 +308,9 @@ class OracleCFM:
         cond = cond.float()
         b, f = cond.shape[:2]
         cond_mean = cond.mean(dim=1, keepdim=True)                         # :239
+        cond_grl = None
+        if use_acc_grl:                                                    # :266-283 (grad_reverse is the identity forward)
+            cond_grl = cond if ref_ratio >= 1 else clip_and_shuffle(cond[0].T, f, ratio=ref_ratio).T[None]
         if lens is None:
             lens = torch.full((b,), f, dtype=torch.long)
         cond_mask = lens_to_mask(lens)                                     # :293
@@ -307,7 +331,9 @@ class OracleCFM:
             rc = cond_noise.float() * 0.1 + cond_mean
             cond = rc / rc.mean(dim=1, keepdim=True) * cond_mean
         cond_mask = F.pad(cond_mask, (0, n - cond_mask.shape[-1]), value=False)[..., None]  # :326-327
-        step_cond = torch.where(cond_mask, cond, torch.zeros_like(cond))   # :388-390 (grl = identity fwd)
+        step_cond = torch.where(cond_mask, cond, torch.zeros_like(cond))   # :388-390
+        if cond_grl is not None:                                           # :329-330, :387-388
+            step_cond = torch.where(cond_mask, F.pad(cond_grl, (0, 0, 0, n - f)), torch.zeros_like(cond))
         mask = lens_to_mask(duration) if b > 1 else None                   # :336-339
 
         def fn(t, x):                                                      # :382-425

@@ -15,7 +15,7 @@ from lemas_tts_amd.model.layout import DiTArch
 pytestmark = pytest.mark.gpu
 
 MSE_TOL = 1e-4
-GOLDEN_CASES = ["mini_plain", "mini_nocfg_nosway", "mini_batch", "mini_edit", "mini_prosody", "mini_noref", "full_plain"]
+GOLDEN_CASES = ["mini_plain", "mini_nocfg_nosway", "mini_batch", "mini_edit", "mini_prosody", "mini_noref", "mini_grl_prosody", "mini_grl_shuffle", "full_plain"]
 
 
 def _load(golden_dir, name):
@@ -52,11 +52,17 @@ def _run_case(fx, arch, sd, graph=True, traj=True):
         kw["prosody_embeds"] = torch.from_numpy(fx["prosody_embeds"])
     if "cond_noise" in fx:
         kw.update(no_ref_audio=True, cond_noise=torch.from_numpy(fx["cond_noise"]))
+    grl = "use_acc_grl" in fx
+    if grl:
+        kw["ref_ratio"] = float(fx["ref_ratio"])
+    if "pyseed" in fx:                      # clip_and_shuffle draws from Python's random (cfm.py:39-84)
+        import random
+        random.seed(int(fx["pyseed"]))
     dur = fx["duration"]
     out, tr = m.sample(torch.from_numpy(fx["cond"]), torch.from_numpy(fx["text"]),
                        int(dur[0]) if B == 1 else torch.from_numpy(dur), lens=torch.from_numpy(fx["lens"]),
                        steps=int(fx["steps"]), cfg_strength=float(fx["cfg"]), sway_sampling_coef=coef,
-                       y0=torch.from_numpy(fx["y0"]), use_acc_grl=False, return_trajectory=traj, **kw)
+                       y0=torch.from_numpy(fx["y0"]), use_acc_grl=grl, return_trajectory=traj, **kw)
     torch.cuda.synchronize()
     return out.cpu().numpy(), None if tr is None else tr.cpu().numpy()
 

@@ -14,7 +14,7 @@ from lemas_tts_amd import synth
 from lemas_tts_amd.model.layout import DiTArch
 from oracle import lemas_oracle as O
 
-CASES = ["mini_plain", "mini_nocfg_nosway", "mini_batch", "mini_edit", "mini_prosody", "mini_noref", "full_plain"]
+CASES = ["mini_plain", "mini_nocfg_nosway", "mini_batch", "mini_edit", "mini_prosody", "mini_noref", "mini_grl_prosody", "mini_grl_shuffle", "full_plain"]
 ATOL = 5e-5   # measured max |err| 3.7e-6 (fp32 vs fp32, different summation order); |out| ~ 1.8
 
 
@@ -38,6 +38,11 @@ def oracle_sample(fx, arch, sd):
         kw["prosody_embeds"] = torch.from_numpy(fx["prosody_embeds"])
     if "cond_noise" in fx:
         kw.update(no_ref_audio=True, cond_noise=torch.from_numpy(fx["cond_noise"]))
+    if "use_acc_grl" in fx:
+        kw.update(use_acc_grl=True, ref_ratio=float(fx["ref_ratio"]))
+    if "pyseed" in fx:                      # clip_and_shuffle draws from Python's random (cfm.py:39-84)
+        import random
+        random.seed(int(fx["pyseed"]))
     B = int(fx["B"])
     dur = fx["duration"]
     return cfm.sample(torch.from_numpy(fx["cond"]), torch.from_numpy(fx["text"]),
@@ -55,7 +60,7 @@ def test_oracle_matches_reference_golden(golden_dir, name):
     np.testing.assert_allclose(traj.numpy(), fx["trajectory"], atol=ATOL, rtol=0)
     np.testing.assert_allclose(out.numpy(), fx["out"], atol=ATOL, rtol=0)
     # the conditioning region of ``out`` is the (prosody-shifted) cond itself (cfm.py:461)
-    if "edit_mask" not in fx and "prosody_embeds" not in fx and "cond_noise" not in fx:
+    if "edit_mask" not in fx and "prosody_embeds" not in fx and "cond_noise" not in fx:   # (also true for mini_grl_shuffle: out keeps cond)
         for b in range(int(fx["B"])):
             L = int(fx["lens"][b])
             np.testing.assert_array_equal(out.numpy()[b, :L], fx["cond"][b, :L])
