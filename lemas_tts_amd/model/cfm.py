@@ -174,11 +174,13 @@ class CFM:
         seq_len = duration.to(torch.int32) if batch > 1 else None          # cfm.py:336-339
 
         if y0 is None:
+            # cfm.py:430-435.  Drawn with the HOST generator, as the reference's CPU path does (its `self.device` is the CPU
+            # there): the same `seed` then gives the same noise, which is what "identical noise seed" parity needs.
             ys = []
             for dur in duration:
                 if seed is not None:
                     torch.manual_seed(seed)
-                ys.append(torch.randn(int(dur), self.num_channels, device=dev, dtype=torch.float32))
+                ys.append(torch.randn(int(dur), self.num_channels, dtype=torch.float32))
             y0 = torch.nn.utils.rnn.pad_sequence(ys, padding_value=0, batch_first=True)
         assert tuple(y0.shape) == (batch, n, self.num_channels), (tuple(y0.shape), (batch, n, self.num_channels))
 

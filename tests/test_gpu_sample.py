@@ -165,3 +165,19 @@ def test_utterance_shards_are_independent(golden_dir):
     # B=2 takes the masked path (seq_len given) while B=1 does not: same math, full-length mask
     np.testing.assert_array_equal(two[0].cpu().numpy(), two[1].cpu().numpy())
     np.testing.assert_allclose(two[0].cpu().numpy(), one[0].cpu().numpy(), atol=0, rtol=0)
+
+
+def test_seed_draws_the_reference_cpu_noise(golden_dir):
+    """north_star: parity on identical (phone-seq, ref-mel, NOISE SEED, NFE).  With `seed` given and no explicit y0 the mirror
+    draws what the reference's CPU path draws at cfm.py:430-435 (host generator, re-seeded per sample, zero right-pad): the
+    fixtures' y0 came out of the reference with seed 101 (mini_plain) / 103 (mini_batch, oracle/gen_golden.py)."""
+    for name, seed in (("mini_plain", 101), ("mini_batch", 103)):
+        fx, arch, sd = _load(golden_dir, name)
+        m = _model(arch, int(fx["vocab"]), int(fx["wseed"]), False, sd)
+        B = int(fx["B"])
+        dur = fx["duration"]
+        out, tr = m.sample(torch.from_numpy(fx["cond"]), torch.from_numpy(fx["text"]), int(dur[0]) if B == 1 else torch.from_numpy(dur),
+                           lens=torch.from_numpy(fx["lens"]), steps=int(fx["steps"]), cfg_strength=float(fx["cfg"]),
+                           sway_sampling_coef=float(fx["coef"]), seed=seed, use_acc_grl=False, return_trajectory=True)
+        np.testing.assert_array_equal(tr[0].cpu().numpy(), fx["y0"])
+        assert _gen_mse(out.cpu().numpy(), fx["out"], fx) <= MSE_TOL
