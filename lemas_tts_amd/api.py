@@ -86,7 +86,8 @@ class TTS:
             progress=progress, target_rms=target_rms, cross_fade_duration=cross_fade_duration, nfe_step=nfe_step,
             cfg_strength=cfg_strength, sway_sampling_coef=sway_sampling_coef, use_prosody_encoder=use_prosody_encoder,
             use_acc_grl=use_acc_grl, ref_ratio=ref_ratio, no_ref_audio=no_ref_audio, speed=speed,
-            fix_duration=fix_duration, device=self.device, seed=seed, **extra)
+            fix_duration=fix_duration, device=self.device, **extra)   # no per-line re-seeding: like api.py:194-197 + utils_infer.py:531-542,
+        # every line draws its noise from the generator seed_everything() just seeded, in order
         if file_wave is not None:
             self.export_wav(wav, file_wave)
         return wav, sr, spec

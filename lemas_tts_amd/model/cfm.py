@@ -167,7 +167,7 @@ class CFM:
             if pros is not None:
                 raise NotImplementedError("no_ref_audio together with the prosody encoder is not built")
             if cond_noise is None:
-                cond_noise = torch.randn(batch, n, self.num_channels, device=dev, dtype=torch.float32)
+                cond_noise = torch.randn(batch, n, self.num_channels, dtype=torch.float32)   # host generator, like the y0 draw below
             rc = cond_noise.to(dev, torch.float32) * 0.1 + cond_mean
             cond = rc / rc.mean(dim=1, keepdim=True) * cond_mean
         cond_mask = F.pad(cond_mask, (0, n - cond_mask.shape[-1]), value=False)

@@ -147,3 +147,35 @@ def test_infer_batch_process_batched_lines_vs_oracle_batch():
     b = next(infer_batch_process(ref_mel, ref_text, same, model, _V, noise=nz, batch_lines=1, **kw))
     np.testing.assert_array_equal(a[2], b[2])
     np.testing.assert_array_equal(a[0], b[0])
+
+
+def test_tts_infer_seed_reproduces_the_reference_noise_sequence():
+    """api.py:194-197 seeds python / torch once; every generated line then draws its y0 from that host generator in order
+    (utils_infer.py:531-542 passes no seed to the sampler).  TTS.infer(seed=S) must equal the pipeline fed with exactly those
+    draws, and two calls with the same seed must agree bit for bit."""
+    from lemas_tts_amd.api import TTS
+    import lemas_tts_amd.api as A
+    import lemas_tts_amd.infer.utils_infer as UI
+    arch_cfg = UI.load_arch_config
+    A.load_arch_config = lambda m: {**arch_cfg(m), "arch": {**arch_cfg(m)["arch"], "depth": 2}}
+    try:
+        vocab = {f"p{i}": i for i in range(898)}
+        tts = TTS(model="multilingual_grl", device="cuda:0", state_dict=synth.synth_cfm_state_dict(DiTArch(depth=2), 898, 61),
+                  vocoder_state_dict=synth.synth_vocos_state_dict(62), vocab_char_map=vocab)
+    finally:
+        A.load_arch_config = arch_cfg
+    F_ = 50
+    ref_mel = torch.from_numpy(synth.synth_cond_mel(63, F_))
+    ref_text = [f"p{i}" for i in synth.synth_tokens(64, 10, 898)]
+    lines = [[f"p{i}" for i in synth.synth_tokens(65 + k, 8 + 2 * k, 898)] for k in range(2)]
+    kw = dict(nfe_step=2, cfg_strength=2, sway_sampling_coef=5)
+    a = tts.infer(ref_mel, ref_text, lines, seed=77, **kw)
+    b = tts.infer(ref_mel, ref_text, lines, seed=77, **kw)
+    np.testing.assert_array_equal(a[0], b[0])
+    ref_len = F_ - 1
+    durs = [max(ref_len + int(ref_len / len(ref_text) * len(g)), F_ + 1, len(ref_text) + len(g) + 1) for g in lines]
+    torch.manual_seed(77)
+    noise = [torch.randn(d, 100)[None] for d in durs]               # the draws the reference would make, in order
+    c = tts.infer(ref_mel, ref_text, lines, seed=5, noise=noise, **kw)
+    np.testing.assert_array_equal(a[2], c[2])
+    np.testing.assert_array_equal(a[0], c[0])
