@@ -74,10 +74,17 @@ class TTS:
         seed_everything(seed)
         self.seed = seed
         if self.frontend is not None and isinstance(ref_text, str):
-            if getattr(self.frontend, "dtype", "phone") != "phone":
-                raise NotImplementedError("only the phone frontend of the shipped models is mirrored")
-            ref_text = self.frontend.text2phn(ref_text + ". ").replace("(cmn)", "(zh)").split("|")      # api.py:202
-            gen_text = [self.frontend.text2phn(x + ". ").replace("(cmn)", "(zh)").split("|") for x in gen_text.split("\n")]
+            kind = getattr(self.frontend, "dtype", "phone")
+            if kind == "phone":                                             # api.py:201-204
+                ref_text = self.frontend.text2phn(ref_text + ". ").replace("(cmn)", "(zh)").split("|")
+                gen_text = [self.frontend.text2phn(x + ". ").replace("(cmn)", "(zh)").split("|") for x in gen_text.split("\n")]
+            elif kind == "char":                                            # api.py:206-211: language tag + characters
+                lang, norm = self.frontend.text2norm(ref_text + ". ")
+                ref_text = ["(" + lang.replace("cmn", "zh") + ")"] + list(norm)
+                pairs = [self.frontend.text2norm(x + ". ") for x in gen_text.split("\n")]
+                gen_text = [["(" + lg.replace("cmn", "zh") + ")"] + list(tx) for lg, tx in pairs]
+            else:
+                raise NotImplementedError(f"frontend dtype {kind!r}")
         if separate_langs:
             ref_text = self.process_phone_list(ref_text)                    # api.py:214-216
             gen_text = [self.process_phone_list(x) for x in gen_text]

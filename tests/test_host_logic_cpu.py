@@ -42,3 +42,41 @@ def test_process_phone_list_rules():
     t.langs = {"en": "en-us", "zh": "zh"}
     out = t.process_phone_list(["(en)", "h", "@", "_", ",", "_", "(zh)", "n", "i3", "."])
     assert out == ["(en)h", "(en)@", ",", "(zh)n", "(zh)i3", "."]
+
+
+def test_tts_infer_frontend_dispatch_builds_the_reference_token_lists(monkeypatch):
+    """api.py:199-216: phone frontend -> '|'-split phones with (cmn)->(zh); char frontend -> language tag + characters;
+    one generation per '\\n'-separated line; separate_langs prefixes phones with the running language id."""
+    import lemas_tts_amd.api as A
+    seen = {}
+
+    def fake_infer_process(ref_file, ref_text, gen_text, *a, **k):
+        seen["ref"], seen["gen"] = ref_text, gen_text
+        return None, 24000, None
+    monkeypatch.setattr(A, "infer_process", fake_infer_process)
+    tts = A.TTS.__new__(A.TTS)
+    tts.ema_model = tts.vocoder = None
+    tts.mel_spec_type, tts.device = "vocos", "cuda:0"
+    tts.langs = {"cmn": "zh", "zh": "zh", "en": "en-us"}
+
+    class _Phone:
+        dtype = "phone"
+
+        @staticmethod
+        def text2phn(s):
+            return "(cmn)|" + "|".join(s.strip(". ").split())
+    tts.frontend = _Phone
+    tts.infer(None, "a b", "c d\ne", seed=1)
+    assert seen["ref"] == ["(zh)", "a", "b"] and seen["gen"] == [["(zh)", "c", "d"], ["(zh)", "e"]]
+    tts.infer(None, "a b", "c", seed=1, separate_langs=True)
+    assert seen["ref"] == ["(zh)a", "(zh)b"] and seen["gen"] == [["(zh)c"]]
+
+    class _Char:
+        dtype = "char"
+
+        @staticmethod
+        def text2norm(s):
+            return "cmn", s.strip(". ")
+    tts.frontend = _Char
+    tts.infer(None, "ab", "cd\nef", seed=1)
+    assert seen["ref"] == ["(zh)", "a", "b"] and seen["gen"] == [["(zh)", "c", "d"], ["(zh)", "e", "f"]]
