@@ -191,7 +191,8 @@ class CFM:
             # when the two coincide the engine's default is already right
             step_cond = F.pad(cond_grl, (0, 0, 0, n - cond_seq_len), value=0.0)
         out, y_final, traj = self.engine.sample(
-            cond, cond_mask, text, t.numpy(), y0, cond_frames=cond_seq_len, cfg_strength=float(cfg_strength),
+            cond, cond_mask, text, t.numpy(), y0, cond_frames=min(cond_seq_len, n), cfg_strength=float(cfg_strength),   # F.pad above CROPS the
+            # prompt when `lens` lets the duration fall below the prompt length (negative pad, as cfm.py:311 does)
             seq_len=seq_len, prosody=pros, want_trajectory=return_trajectory, step_cond=step_cond)
         if no_ref_audio:                                                     # cfm.py:464-466: re-centre the generated part
             gen = out[:, cond_seq_len:, :]

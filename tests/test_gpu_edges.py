@@ -147,3 +147,55 @@ def test_shape_churn_reuses_one_engine_correctly():
             ref, _ = o.sample(cond, text, N, y0=y0, **kw)
             assert _mse(out, ref, [F_] * B, [N] * B) <= 1e-4, (i, key)
     m.engine.set_option("dual", 1); m.engine.set_option("graph", 1)
+
+
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("LEMAS_FUZZ", "24")))))
+def test_randomised_small_configurations_vs_oracle(seed):
+    """seeded random draws over batch size, prompt / total lengths, token counts, ragged `lens`, edit masks, step counts,
+    CFG on / off and the three sway settings -- every combination the sampler's bookkeeping has to get right at once"""
+    rng = np.random.default_rng(1000 + seed)
+    m, o = _pair()
+    B = int(rng.integers(1, 4))
+    Fm = int(rng.integers(2, 90))
+    lens = [int(rng.integers(1, Fm + 1)) for _ in range(B)]
+    lens[int(rng.integers(0, B))] = Fm if rng.random() < 0.7 else lens[0]
+    durs = [int(rng.integers(l + 1, l + 140)) for l in lens]
+    nts = [int(rng.integers(1, max(2, d // 2))) for d in durs]
+    steps = int(rng.integers(1, 4))
+    cfg = float(rng.choice([0.0, 2.0, 3.5]))
+    coef = [None, -1.0, 5][int(rng.integers(0, 3))]
+    cond = torch.zeros(B, Fm, 100); text = torch.full((B, max(nts)), -1, dtype=torch.long)
+    for b in range(B):
+        cond[b] = torch.from_numpy(synth.synth_cond_mel(seed * 10 + b, Fm))
+        text[b, :nts[b]] = torch.from_numpy(synth.synth_tokens(seed * 10 + b, nts[b], VOCAB))
+    edit = None
+    if rng.random() < 0.4:
+        edit = torch.from_numpy(rng.random((B, Fm)) < 0.7)
+    kw = dict(steps=steps, cfg_strength=cfg, sway_sampling_coef=coef, lens=torch.tensor(lens))
+    if edit is not None:
+        kw["edit_mask"] = edit
+    dur_arg = durs[0] if B == 1 else torch.tensor(durs)
+    eff = [max(max(nts[b], lens[b]) + 1, durs[b]) for b in range(B)]
+    y0 = torch.zeros(B, max(eff), 100)
+    for b in range(B):
+        y0[b, :eff[b]] = torch.from_numpy(synth.synth_noise(seed * 10 + b, eff[b]))
+    if edit is not None and max(lens) < Fm:
+        # lens_to_mask(lens) is max(lens) wide and cannot be and-ed with an F-wide edit mask: the reference raises
+        # (cfm.py:293-295), and so must the mirror and the oracle
+        with pytest.raises(RuntimeError):
+            m.sample(cond, text, dur_arg, y0=y0, use_acc_grl=False, **kw)
+        with pytest.raises(RuntimeError):
+            o.sample(cond, text, dur_arg, y0=y0, **kw)
+        return
+    out, _ = m.sample(cond, text, dur_arg, y0=y0, use_acc_grl=False, **kw)
+    ref, _ = o.sample(cond, text, dur_arg, y0=y0, **kw)
+    assert out.shape == ref.shape
+    keep = torch.zeros(B, ref.shape[1], dtype=torch.bool)
+    for b in range(B):
+        keep[b, :lens[b]] = True
+        if edit is not None:
+            keep[b, :Fm] &= edit[b]
+        keep[b, eff[b]:] = True                     # beyond a sample's own duration nothing is compared
+    d = (out.cpu() - ref)[~keep]
+    mse = float((d.double() ** 2).mean()) if d.numel() else 0.0
+    assert mse <= 1e-4, (seed, B, Fm, lens, durs, nts, steps, cfg, coef, edit is not None, mse)
