@@ -135,7 +135,8 @@ int64_t lemas_resample_out_len(const lemas_resample* r, int64_t samples);   /* c
 int lemas_resample_forward(lemas_resample* r, const float* wav, int32_t batch, int32_t samples, float* out, void* stream);
 
 /* ---- single-kernel entry points (parity tests) ---- all pointers device fp32 unless noted */
-/* out[M,N] = act(A[M,K] . W[N,K]^T + bias) through the bf16 MFMA GEMM (inputs rounded to bf16); act: 0 none, 1 gelu-tanh */
+/* out[M,N] = act(A[M,K] . W[N,K]^T + bias) through the bf16 MFMA GEMM (inputs rounded to bf16); act: 0 none, 1 gelu-tanh.
+ * K % 64 == 0; N % 4 == 0 (act 0) / N % 8 == 0 (act 1): the epilogues store whole 16-byte chunks; anything else is refused. */
 int lemas_k_linear_bf16(const float* A, const float* W, const float* bias, float* out, int32_t M, int32_t N, int32_t K,
                         int32_t act, void* stream);
 /* out[M,N] = A . W^T + bias through the exact-fp32 MFMA GEMM; act: 0 none, 1 gelu-erf, 2 silu */

@@ -786,6 +786,11 @@ hipError_t dispatch(const GemmParams& p, int variant, hipStream_t s) {
 
 hipError_t launch_gemm_bf16_variant(int epi, const GemmParams& p, int variant, hipStream_t s) {
   if (p.K % BK != 0 || p.N % 128 != 0 || p.M <= 0 || p.seq_pitch <= 0) return hipErrorInvalidValue;
+  // the row-wise epilogues store whole 16-B chunks: 4 fp32 / 8 bf16 / 16 e4m3 columns, so the stored width and the row
+  // pitch must be multiples of that (every shape of the path is: 100, 1024, 2048)
+  if (epi == EPI_BIAS_F32 || epi == EPI_GATE_RES) { if ((p.n_valid > 0 && p.n_valid % 4) || p.ldc % 4) return hipErrorInvalidValue; }
+  if (epi == EPI_BIAS_BF16 || epi == EPI_BIAS_GELU_BF16) { if (p.n_valid % 8 || p.ldc % 8) return hipErrorInvalidValue; }
+  if (epi == EPI_BIAS_GELU_F8) { if (p.n_valid % 128 || p.ldc % 128) return hipErrorInvalidValue; }
   if (p.f8) {
     if (p.K % 128 != 0 || !p.a_mx || !p.w_scale) return hipErrorInvalidValue;
     switch (epi) {

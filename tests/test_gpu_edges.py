@@ -199,3 +199,43 @@ def test_randomised_small_configurations_vs_oracle(seed):
     d = (out.cpu() - ref)[~keep]
     mse = float((d.double() ** 2).mean()) if d.numel() else 0.0
     assert mse <= 1e-4, (seed, B, Fm, lens, durs, nts, steps, cfg, coef, edit is not None, mse)
+
+
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("LEMAS_FUZZ2", "16")))))
+def test_randomised_conditioning_flags_vs_oracle(seed):
+    """the conditioning switches of CFM.sample in random combination: prosody embedding, accent-GRL conditioning
+    (use_acc_grl with ref_ratio 1 or a clip-and-shuffle ratio), no_ref_audio -- against the oracle's restatement of
+    cfm.py:266-283, 313-324, 387-388, 464-466 (itself pinned by the mini_grl_* / mini_noref / mini_prosody goldens)"""
+    import random
+    rng = np.random.default_rng(5000 + seed)
+    prosody = bool(rng.random() < 0.5)
+    m, o = _pair(depth=2, seed=141, prosody=prosody)
+    B = 1 if rng.random() < 0.6 else int(rng.integers(2, 4))
+    F_ = int(rng.integers(30, 260))
+    durs = [int(rng.integers(F_ + 2, F_ + 160)) for _ in range(B)]
+    nts = [int(rng.integers(2, 40)) for _ in range(B)]
+    use_grl = bool(rng.random() < 0.6)
+    ref_ratio = float(rng.choice([1.0, 0.5, 0.3])) if (use_grl and B == 1) else 1.0
+    no_ref = bool((not prosody) and rng.random() < 0.3)
+    cond = torch.stack([torch.from_numpy(synth.synth_cond_mel(seed * 7 + b, F_)) for b in range(B)])
+    text = torch.full((B, max(nts)), -1, dtype=torch.long)
+    for b in range(B):
+        text[b, :nts[b]] = torch.from_numpy(synth.synth_tokens(seed * 7 + b, nts[b], VOCAB))
+    N = max(durs)
+    y0 = torch.zeros(B, N, 100)
+    for b in range(B):
+        y0[b, :durs[b]] = torch.from_numpy(synth.synth_noise(seed * 7 + b, durs[b]))
+    kw = dict(steps=int(rng.integers(1, 4)), cfg_strength=2.0, sway_sampling_coef=5, use_acc_grl=use_grl, ref_ratio=ref_ratio)
+    if prosody:
+        kw["prosody_embeds"] = torch.from_numpy(synth.synth_prosody_embed(seed + 900, B))
+    if no_ref:
+        kw.update(no_ref_audio=True, cond_noise=torch.from_numpy(synth.synth_noise(seed + 901, B * N).reshape(B, N, 100)))
+    dur_arg = durs[0] if B == 1 else torch.tensor(durs)
+    random.seed(seed)
+    out, _ = m.sample(cond, text, dur_arg, y0=y0, **kw)
+    random.seed(seed)
+    ref, _ = o.sample(cond, text, dur_arg, y0=y0, **kw)
+    mse = _mse(out.cpu(), ref, [F_] * B, durs)
+    assert mse <= 1e-4, (seed, prosody, B, F_, durs, use_grl, ref_ratio, no_ref, mse)
+    if not no_ref:       # kept frames are the (prosody-shifted) prompt itself
+        assert float((out.cpu()[:, :F_] - ref[:, :F_]).abs().max()) <= 1e-5

@@ -116,3 +116,55 @@ def test_convpos(B, N):
     L.check(lib.lemas_k_convpos(*[a.data_ptr() for a in args], out.data_ptr(), B, N, C_, G, T, None))
     err = (out.cpu() - ref).abs().max().item()
     assert err < 5e-3, err
+
+
+@pytest.mark.parametrize("seed", list(range(20)))
+def test_randomised_gemm_and_attention_shapes(seed):
+    """tile-edge hunting: random M (incl. 1 and just around multiples of 32 / 128 / 256), N, K for the bf16 GEMM; random
+    sequence lengths, head counts and ragged key lengths for both attention kernels"""
+    import numpy as np
+    L, lib = _lib()
+    rng = np.random.default_rng(300 + seed)
+    edge = [1, 2, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 383, 511, 513]
+    M = int(rng.choice(edge)) if rng.random() < 0.5 else int(rng.integers(1, 2500))
+    act = int(rng.integers(0, 2))
+    N = int(rng.choice([4, 12, 100, 128, 132, 252, 256, 1024, 1100])) if act == 0 else int(rng.choice([8, 24, 104, 128, 136, 248, 256, 1024, 1096]))
+    K = 64 * int(rng.integers(1, 33))
+    g = torch.Generator().manual_seed(seed)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) * 0.05 + (torch.arange(N)[:, None] % 5 - 2) * 0.01
+    b = torch.randn(N, generator=g)
+    ref = _bf(A) @ _bf(W).T + b
+    if act == 1:
+        ref = _bf(torch.nn.functional.gelu(ref, approximate="tanh"))
+    Ad, Wd, bd = _dev(A), _dev(W), _dev(b)
+    out = torch.empty(M, N, device="cuda:0")
+    L.check(lib.lemas_k_linear_bf16(Ad.data_ptr(), Wd.data_ptr(), bd.data_ptr(), out.data_ptr(), M, N, K, act, None))
+    err = (out.cpu() - ref).abs().max().item()
+    assert err < (2e-2 if act == 1 else 2e-3 * math.sqrt(K / 64)) * max(1.0, float(ref.abs().max()) / 4), (M, N, K, act, err)
+
+    # widths the 16-byte-chunk epilogues cannot store are refused, not mangled
+    bad = torch.empty(M, 7, device="cuda:0")
+    assert lib.lemas_k_linear_bf16(Ad.data_ptr(), Wd.data_ptr(), bd.data_ptr(), bad.data_ptr(), M, 7, K, 0, None) != 0
+
+    B, H = int(rng.integers(1, 4)), int(rng.choice([1, 2, 16]))
+    Ns = int(rng.choice(edge[5:])) if rng.random() < 0.5 else int(rng.integers(2, 700))
+    lens = None if rng.random() < 0.5 else [int(rng.integers(1, Ns + 1)) for _ in range(B)]
+    q, k, v = (torch.randn(B, H, Ns, 64, generator=g) for _ in range(3))
+    qb, kb, vb = _bf(q), _bf(k), _bf(v)
+    mask = None
+    if lens is not None:
+        mask = (torch.arange(Ns)[None, :] < torch.tensor(lens)[:, None])[:, None, None, :]
+    refa = torch.nn.functional.scaled_dot_product_attention(qb, kb, vb, attn_mask=mask).transpose(1, 2).reshape(B, Ns, H * 64)
+    for variant in (1, 2):
+        lib.lemas_k_set_attention_variant(variant)
+        qd, kd, vd = _dev(q), _dev(k), _dev(v)
+        ld = None if lens is None else torch.tensor(lens, dtype=torch.int32, device="cuda:0")
+        o = torch.empty(B, Ns, H * 64, device="cuda:0")
+        L.check(lib.lemas_k_attention(qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), ld.data_ptr() if ld is not None else None, o.data_ptr(), B, H, Ns, None))
+        d = (o.cpu() - refa).abs()
+        if lens is not None:                        # rows past a sample's length are unspecified
+            for bi in range(B):
+                d[bi, lens[bi]:] = 0
+        assert float(d.max()) < 3e-2, (variant, B, H, Ns, lens, float(d.max()))
+    lib.lemas_k_set_attention_variant(0)
