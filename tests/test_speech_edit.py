@@ -92,3 +92,23 @@ def test_gen_wav_multilingual_vs_oracle_pipeline():
     assert mse <= 1e-4
     wref = O.OracleVocos(vsd).decode(mel.cpu()) * (rms / 0.1)
     assert float((wav.cpu() - wref[0]).abs().max()) < 1e-4 * max(1.0, float(wref.abs().max()))
+
+
+def test_edit_mask_builders_agree_on_random_spans():
+    """the host mirror's run-length builder and the oracle's restatement are two independent writings of
+    scripts/speech_edit_multilingual.py:124-158; both reproduce the six reference-produced masks above, and they must keep
+    agreeing on thousands of random span layouts (overlapping margins, spans clipped at either end, odd lengths, other
+    sample rates / hops)"""
+    from lemas_tts_amd.scripts.speech_edit_multilingual import build_edit_mask
+    rng = np.random.default_rng(0)
+    for it in range(3000):
+        sr, hop = (24000, 256) if it % 5 else (int(rng.choice([16000, 22050, 44100])), int(rng.choice([160, 200, 512])))
+        nw = int(rng.integers(hop * 3, sr * 12))
+        total = nw / sr
+        k = int(rng.integers(0, 5))
+        pts = np.sort(rng.uniform(0, total, size=2 * k))
+        spans = [(float(pts[2 * i]), float(pts[2 * i + 1])) for i in range(k)]
+        a = build_edit_mask(spans, nw, sr, hop)
+        b = O.build_edit_mask(nw, spans, sr, hop)
+        assert a.shape == b.shape and torch.equal(a, b), (it, nw, sr, hop, spans)
+        assert a.shape[1] >= nw // hop + 1
