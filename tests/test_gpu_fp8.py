@@ -269,3 +269,42 @@ def test_fp8_flow_error_full_size():
     rel = float((pred[0] - pc[0]).norm() / pc[0].norm())
     print(f"\n[fp8 flow N={N}] relative error of the conditional flow at step 31: {rel:.4f}")
     assert rel < 0.03
+
+
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_fp8_randomised_small_configurations(seed):
+    """the fp8 variant on random batch sizes / lengths / masks / step counts (2 blocks): finite, within the reference tolerance
+    of the fp32 oracle, kept frames exact, and run-to-run deterministic"""
+    from lemas_tts_amd import synth
+    from lemas_tts_amd.model.layout import DiTArch
+    from oracle import lemas_oracle as O
+    rng = np.random.default_rng(9000 + seed)
+    arch = DiTArch(depth=2)
+    sd = synth.synth_cfm_state_dict(arch, 898, 171)
+    m = _fp8_model(arch, 898, sd)
+    B = int(rng.integers(1, 4))
+    Fm = int(rng.integers(3, 120))
+    lens = [Fm] + [int(rng.integers(1, Fm + 1)) for _ in range(B - 1)]
+    durs = [int(rng.integers(l + 1, l + 200)) for l in lens]
+    nts = [int(rng.integers(1, max(2, d // 3))) for d in durs]
+    cond = torch.stack([torch.from_numpy(synth.synth_cond_mel(seed * 5 + b, Fm)) for b in range(B)])
+    text = torch.full((B, max(nts)), -1, dtype=torch.long)
+    for b in range(B):
+        text[b, :nts[b]] = torch.from_numpy(synth.synth_tokens(seed * 5 + b, nts[b], 898))
+    eff = [max(max(nts[b], lens[b]) + 1, durs[b]) for b in range(B)]
+    y0 = torch.zeros(B, max(eff), 100)
+    for b in range(B):
+        y0[b, :eff[b]] = torch.from_numpy(synth.synth_noise(seed * 5 + b, eff[b]))
+    kw = dict(steps=int(rng.integers(2, 5)), cfg_strength=2.0, sway_sampling_coef=5, lens=torch.tensor(lens))
+    dur_arg = durs[0] if B == 1 else torch.tensor(durs)
+    out, _ = m.sample(cond, text, dur_arg, y0=y0, use_acc_grl=False, **kw)
+    out2, _ = m.sample(cond, text, dur_arg, y0=y0, use_acc_grl=False, **kw)
+    np.testing.assert_array_equal(out.cpu().numpy(), out2.cpu().numpy())
+    ref, _ = O.OracleCFM(sd, arch).sample(cond, text, dur_arg, y0=y0, **kw)
+    assert bool(torch.isfinite(out).all())
+    se = cnt = 0.0
+    for b in range(B):
+        d = (out.cpu()[b, lens[b]:eff[b]] - ref[b, lens[b]:eff[b]]).double()
+        se += float((d ** 2).sum()); cnt += d.numel()
+        np.testing.assert_array_equal(out.cpu().numpy()[b, :lens[b]], cond.numpy()[b, :lens[b]])
+    assert se / max(cnt, 1) <= 1e-4, (seed, B, Fm, lens, durs, se / max(cnt, 1))
