@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void convpos_kernel(const ConvPosParams p) 
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             const bf16x8 w = *reinterpret_cast<const bf16x8*>(sW + tp * WTAP_BYTES + lds_off(j * 32 + l31, kk * 2 + hi));
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, w, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, a, acc[j], 0, 0, 0);   // swapped: a lane owns one frame
           }
         }
       }
@@ -112,19 +112,45 @@ __global__ __launch_bounds__(256, 2) void convpos_kernel(const ConvPosParams p) 
     }
   }
 
-  // ---- epilogue: bias + Mish (+ residual); C fragment col = lane&31 (channel), rows = frames
+  // ---- epilogue: bias + Mish (+ residual).  Swapped operands: lane -> frame f0 + 32 wave + (lane & 31), register r ->
+  // channel 32 j + (r & 3) + 8 (r >> 2) + 4 hi.  Each wave parks its 32 x 64 tile in a private LDS slab (the input slab is
+  // dead after the last barrier) and writes whole rows: 128 B (bf16) / 256 B (fp32) contiguous per frame instead of 2048
+  // scattered 2- or 4-byte stores per wave.
+  constexpr int PITCH = CG * 4 + 16;
+  char* slab = smem + wave * (32 * PITCH);
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int c = g * CG + j * 32 + l31;
-    const float bias = p.bias[c];
+  for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int f = f0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+    for (int q = 0; q < 4; ++q) {
+      const int cl = j * 32 + 8 * q + 4 * hi;
+      const float4 bias = *reinterpret_cast<const float4*>(p.bias + g * CG + cl);
+      *reinterpret_cast<float4*>(slab + l31 * PITCH + cl * 4) =
+          make_float4(mish_f(acc[j][4 * q + 0] + bias.x), mish_f(acc[j][4 * q + 1] + bias.y), mish_f(acc[j][4 * q + 2] + bias.z),
+                      mish_f(acc[j][4 * q + 3] + bias.w));
+    }
+  if (FIRST) {
+    const int rr = lane >> 3, ch = lane & 7;                 // 8 rows x 8 chunks (8 bf16 = 16 B) per pass
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int fr = it * 8 + rr, f = f0 + wave * 32 + fr;
+      const float4 a = *reinterpret_cast<const float4*>(slab + fr * PITCH + ch * 32);
+      const float4 c = *reinterpret_cast<const float4*>(slab + fr * PITCH + ch * 32 + 16);
+      bf16x8 o;
+      o[0] = (bf16_t)a.x; o[1] = (bf16_t)a.y; o[2] = (bf16_t)a.z; o[3] = (bf16_t)a.w;
+      o[4] = (bf16_t)c.x; o[5] = (bf16_t)c.y; o[6] = (bf16_t)c.z; o[7] = (bf16_t)c.w;
+      if (f < N) store_wt_b128(p.out_bf16 + ((size_t)b * p.pitch + f) * C + g * CG + ch * 8, __builtin_bit_cast(u32x4, o));
+    }
+  } else {
+    const int rr = lane >> 4, ch = lane & 15;                // 4 rows x 16 chunks (4 fp32 = 16 B) per pass
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int fr = it * 4 + rr, f = f0 + wave * 32 + fr;
       if (f < N) {
-        const size_t off = ((size_t)b * p.pitch + f) * C + c;
-        const float v = mish_f(acc[j][r] + bias);
-        if (FIRST) p.out_bf16[off] = (bf16_t)v;
-        else p.out_f32[off] = v + p.residual[off];
+        const size_t off = ((size_t)b * p.pitch + f) * C + g * CG + ch * 4;
+        const float4 a = *reinterpret_cast<const float4*>(slab + fr * PITCH + ch * 16);
+        const float4 r4 = *reinterpret_cast<const float4*>(p.residual + off);
+        const float4 o = make_float4(a.x + r4.x, a.y + r4.y, a.z + r4.z, a.w + r4.w);
+        store_wt_b128(p.out_f32 + off, __builtin_bit_cast(u32x4, o));
       }
     }
   }
