@@ -112,3 +112,49 @@ def test_edit_mask_builders_agree_on_random_spans():
         b = O.build_edit_mask(nw, spans, sr, hop)
         assert a.shape == b.shape and torch.equal(a, b), (it, nw, sr, hop, spans)
         assert a.shape[1] >= nw // hop + 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(6)))
+def test_gen_wav_multilingual_random_spans_and_rates(seed):
+    """random utterance lengths, span layouts, prompt sample rates (resampled on the way in) and loudness (rms rescale in / out)"""
+    import types
+    from lemas_tts_amd import synth
+    from lemas_tts_amd.engine import VocosEngine
+    from lemas_tts_amd.model.cfm import CFM
+    from lemas_tts_amd.model.layout import DiTArch
+    from lemas_tts_amd.scripts.speech_edit_multilingual import gen_wav_multilingual
+    rng = np.random.default_rng(40 + seed)
+    arch = DiTArch(depth=2)
+    vocab = {c: i for i, c in enumerate(" abcdefghijklmnopqrstuvwxyz.")}
+    sd = synth.synth_cfm_state_dict(arch, len(vocab), 191)
+    vsd = synth.synth_vocos_state_dict(192)
+    model = CFM(arch, len(vocab), sd, vocab_char_map=vocab, device="cuda:0")
+    tts = types.SimpleNamespace(ema_model=model, vocoder=types.SimpleNamespace(engine=VocosEngine(vsd, device="cuda:0")), frontend=None,
+                                device="cuda:0", mel_spec_type="vocos")
+    sr = int(rng.choice([24000, 16000, 44100]))
+    secs = float(rng.uniform(1.5, 5.0))
+    g = torch.Generator().manual_seed(seed)
+    audio = torch.randn(int(secs * sr), generator=g) * float(rng.choice([0.02, 0.3]))
+    k = int(rng.integers(1, 4))
+    pts = np.sort(rng.uniform(0.1, secs - 0.1, size=2 * k))
+    spans = [(float(pts[2 * i]), float(pts[2 * i + 1])) for i in range(k)]
+    rms = float(audio.pow(2).mean().sqrt())
+    a = audio[None] * (0.1 / rms) if rms < 0.1 else audio[None]
+    a24 = O.resample_sinc_hann(a, sr, 24000) if sr != 24000 else a
+    nw = a24.shape[-1]
+    F_ = nw // 256 + 1
+    y0 = torch.from_numpy(synth.synth_noise(200 + seed, F_ + 1))[None]
+    wav, mel = gen_wav_multilingual(tts, audio, sr, "some new words", spans, nfe_step=2, cfg_strength=5.0, sway_sampling_coef=3.0, y0=y0)
+    assert mel.shape == (1, 100, F_ + 1) and wav.shape == (256 * F_,)
+    cond = O.vocos_mel_spectrogram(a24).permute(0, 2, 1)
+    edit = O.build_edit_mask(nw, spans)
+    text = O.tokens_to_idx([list("some new words.")], vocab)
+    ref, _ = O.OracleCFM(sd, arch).sample(cond, text, nw // 256, y0=y0, steps=2, cfg_strength=5.0, sway_sampling_coef=3.0, edit_mask=edit)
+    keep = torch.nn.functional.pad(edit, (0, 1), value=False)[0]
+    if int((~keep).sum()):
+        mse = float(((mel.cpu().permute(0, 2, 1)[0, ~keep] - ref[0, ~keep]).double() ** 2).mean())
+        assert mse <= 1e-4, (seed, sr, secs, spans, mse)
+    gain = rms / 0.1 if rms < 0.1 else 1.0
+    wref = O.OracleVocos(vsd).decode(mel.cpu()) * gain
+    assert float((wav.cpu() - wref[0]).abs().max()) < 1e-4 * max(1.0, float(wref.abs().max()))
