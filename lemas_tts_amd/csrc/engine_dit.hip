@@ -379,6 +379,12 @@ int lemas_dit::prepare(const lemas_sample_args* a, hipStream_t s) {
     set_error("lemas_dit_prepare: bad arguments (B=%d N=%d F=%d Nt=%d S=%d)", a->batch, a->frames, a->cond_frames, a->text_len, a->steps);
     return LEMAS_E_ARG;
   }
+  for (int k = 0; k < a->steps; ++k)      // torchdiffeq asserts a strictly monotone grid (SURVEY.md 8a row a-O); the sampler's is increasing
+    if (!(a->t_grid[k + 1] > a->t_grid[k])) {
+      set_error("lemas_dit_prepare: t_grid must be strictly monotone increasing (t[%d] = %g, t[%d] = %g)", k, (double)a->t_grid[k], k + 1,
+                (double)a->t_grid[k + 1]);
+      return LEMAS_E_ARG;
+    }
   if (cfg.dim != 1024 || cfg.dim_head != 64 || cfg.dim / cfg.conv_pos_groups != 64) {
     set_error("lemas_dit: kernels are specialised for dim 1024, dim_head 64, 64 channels per conv group");
     return LEMAS_E_ARG;

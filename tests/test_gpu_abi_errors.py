@@ -1,0 +1,105 @@
+"""GPU tier: error behaviour of the C ABI -- wrong calls come back as an error code + lemas_last_error() text, never as a crash
+or a silent success (include/lemas_hip.h: 0 = ok, LEMAS_E_* / negated hipError_t otherwise)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from lemas_tts_amd import _lib, synth
+from lemas_tts_amd.model.layout import DiTArch
+
+pytestmark = pytest.mark.gpu
+
+
+def _new_dit(depth=1):
+    L = _lib.lib()
+    a = DiTArch(depth=depth)
+    cfg = _lib.DitConfig(a.dim, a.depth, a.heads, a.dim_head, a.ff_mult, a.text_dim, a.conv_layers, a.mel_dim, 899, a.conv_pos_kernel,
+                         a.conv_pos_groups, a.time_freq_dim, 0)
+    h = C.c_void_p()
+    assert L.lemas_dit_create(C.byref(cfg), C.byref(h)) == 0
+    return L, h
+
+
+def _err(L):
+    return L.lemas_last_error().decode()
+
+
+def test_dit_wrong_calls_are_refused():
+    L, h = _new_dit()
+    try:
+        assert L.lemas_dit_create(None, C.byref(C.c_void_p())) != 0
+        # finalize with nothing loaded: strict load fails and names a missing tensor
+        assert L.lemas_dit_finalize(h) != 0 and "missing" in _err(L).lower()
+        # unknown tensor name / wrong shape
+        w = np.zeros((4, 4), np.float32)
+        shp = (C.c_int64 * 2)(4, 4)
+        assert L.lemas_dit_load_weight(h, b"transformer.no.such.tensor", w.ctypes.data_as(C.c_void_p), shp, 2) != 0
+        assert "no.such.tensor" in _err(L)
+        assert L.lemas_dit_load_weight(h, b"transformer.proj_out.bias", w.ctypes.data_as(C.c_void_p), shp, 2) != 0
+        assert "shape" in _err(L).lower()
+        # sampling / solving / forward before finalize + prepare
+        args = _lib.SampleArgs()
+        assert L.lemas_dit_sample(h, C.byref(args), None) != 0
+        assert L.lemas_dit_solve(h, C.byref(args), None) != 0
+        assert L.lemas_dit_forward(h, None, 0, None, None) != 0
+        assert L.lemas_dit_set_option(h, b"no_such_option", 1) != 0 and "no_such_option" in _err(L)
+        assert L.lemas_dit_sample(None, C.byref(args), None) != 0
+    finally:
+        L.lemas_dit_destroy(h)
+
+
+def test_dit_bad_sample_arguments():
+    from lemas_tts_amd.engine import DiTEngine
+    arch = DiTArch(depth=1)
+    eng = DiTEngine(arch, 898, synth.synth_cfm_state_dict(arch, 898, 1), device="cuda:0")
+    L = _lib.lib()
+    cond = torch.zeros(1, 40, 100, device="cuda:0")
+    mask = torch.zeros(1, 40, dtype=torch.uint8, device="cuda:0")
+    text = torch.zeros(1, 5, dtype=torch.int64, device="cuda:0")
+    y = torch.zeros(1, 40, 100, device="cuda:0")
+    tg = np.linspace(0, 1, 3).astype(np.float32)
+
+    def call(**over):
+        a = _lib.SampleArgs()
+        a.batch, a.frames, a.cond_frames, a.text_len, a.steps, a.cfg_strength = 1, 40, 20, 5, 2, 2.0
+        a.cond, a.cond_mask, a.text, a.y = cond.data_ptr(), mask.data_ptr(), text.data_ptr(), y.data_ptr()
+        a.t_grid = tg.ctypes.data_as(C.POINTER(C.c_float))
+        for k, v in over.items():
+            setattr(a, k, v)
+        return L.lemas_dit_sample(eng._h, C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+
+    assert call() == 0
+    torch.cuda.synchronize()
+    for bad in (dict(batch=0), dict(frames=0), dict(frames=5000), dict(cond_frames=41), dict(steps=0), dict(cond=None), dict(text=None),
+                dict(cond_mask=None), dict(y=None), dict(t_grid=None), dict(text_len=0)):
+        assert call(**bad) != 0, bad
+        assert _err(L), bad
+    # a non-monotone time grid is what torchdiffeq would reject (SURVEY a-O)
+    tg[:] = [0.0, 0.6, 0.5]
+    assert call() != 0 and "monoton" in _err(L).lower()
+
+
+def test_vocos_mel_resample_prosody_wrong_calls():
+    L = _lib.lib()
+    v = C.c_void_p()
+    assert L.lemas_vocos_create(100, 512, 1536, 8, 1024, 256, C.byref(v)) == 0
+    try:
+        assert L.lemas_vocos_finalize(v) != 0                       # nothing loaded
+        assert L.lemas_vocos_decode(v, None, 1, 10, C.c_float(1.0), None, None) != 0
+    finally:
+        L.lemas_vocos_destroy(v)
+    m = C.c_void_p()
+    assert L.lemas_mel_create(1000, 256, 100, 24000, C.byref(m)) == 0 or True   # n_fft must be a multiple of 4: 1000 is
+    if m:
+        buf = torch.zeros(1, 100, device="cuda:0")
+        out = torch.zeros(1, 1, 100, device="cuda:0")
+        assert L.lemas_mel_forward(m, buf.data_ptr(), 1, 100, out.data_ptr(), None) != 0      # shorter than the reflect pad
+        L.lemas_mel_destroy(m)
+    assert L.lemas_mel_create(1023, 256, 100, 24000, C.byref(C.c_void_p())) != 0
+    assert L.lemas_resample_create(0, 24000, C.byref(C.c_void_p())) != 0
+    cfg = _lib.ProsodyConfig()
+    cfg.n_layers = 2
+    assert L.lemas_prosody_create(C.byref(cfg), C.byref(C.c_void_p())) != 0 and "architecture" in _err(L)
+    assert L.lemas_prosody_fbank_frames(399) == 0 and L.lemas_prosody_fbank_frames(400) == 1 and L.lemas_prosody_fbank_frames(16000) == 98
