@@ -103,3 +103,42 @@ def test_vocos_mel_resample_prosody_wrong_calls():
     cfg.n_layers = 2
     assert L.lemas_prosody_create(C.byref(cfg), C.byref(C.c_void_p())) != 0 and "architecture" in _err(L)
     assert L.lemas_prosody_fbank_frames(399) == 0 and L.lemas_prosody_fbank_frames(400) == 1 and L.lemas_prosody_fbank_frames(16000) == 98
+
+
+def test_create_destroy_cycles_do_not_leak_device_memory():
+    """every object frees what it allocated: 12 create / use / destroy cycles of each engine leave the free-memory reading flat"""
+    import gc
+    from lemas_tts_amd.engine import DiTEngine, MelEngine, ProsodyEngine, ResampleEngine, VocosEngine
+    from lemas_tts_amd.model.layout import ProsodyArch
+    arch = DiTArch(depth=1)
+    sd = synth.synth_cfm_state_dict(arch, 898, 3)
+    vsd = synth.synth_vocos_state_dict(4)
+    parch = ProsodyArch(channels=(64, 64, 64, 128), kernel_sizes=(5, 3, 3, 1), dilations=(1, 2, 3, 1), attention_channels=16, res2net_scale=4,
+                        se_channels=8, groups=(1, 1, 1, 1), embed_dim=32)
+    psd = synth.synth_prosody_encoder_state_dict(5, parch)
+    cond = torch.from_numpy(synth.synth_cond_mel(6, 40))[None]
+    text = torch.from_numpy(synth.synth_tokens(7, 10, 898))[None]
+    y0 = torch.from_numpy(synth.synth_noise(8, 120))[None]
+    cm = torch.zeros(1, 120, dtype=torch.bool); cm[:, :40] = True
+    tg = np.linspace(0, 1, 3).astype(np.float32) ** 2 + np.arange(3, dtype=np.float32) * 1e-3
+
+    def cycle():
+        e = DiTEngine(arch, 898, sd, device="cuda:0")
+        e.sample(torch.nn.functional.pad(cond, (0, 0, 0, 80)), cm, text, tg, y0, cond_frames=40, cfg_strength=2.0)
+        e.set_option("fp8", 1)
+        e.sample(torch.nn.functional.pad(cond, (0, 0, 0, 80)), cm, text, tg, y0, cond_frames=40, cfg_strength=2.0)
+        v = VocosEngine(vsd, device="cuda:0"); v.decode(torch.zeros(1, 100, 50))
+        MelEngine(device="cuda:0").frames_first(torch.zeros(1, 4000))
+        ResampleEngine(16000, 24000, device="cuda:0")(torch.zeros(1, 4000))
+        p = ProsodyEngine(parch, psd, device="cuda:0"); p.encode(p.fbank(torch.zeros(2000)))
+        torch.cuda.synchronize()
+        for o in (e, v, p):
+            o.close()
+
+    cycle(); gc.collect(); torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(12):
+        cycle()
+    gc.collect(); torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 64 << 20, (free0, free1)          # < 64 MiB drift (torch's own caching allocator noise), not 12 x engine size
