@@ -641,6 +641,10 @@ int lemas_dit::solve(const lemas_sample_args* a, hipStream_t s) {
     snprintf(key, sizeof key, "B%d_N%d_cfg%d_len%d_dual%d_f8%d", B, N, (int)use_cfg, (int)has_len, (int)dual, (int)fp8);
     auto it = graphs.find(key);
     if (it == graphs.end()) {
+      if (graphs.size() >= 32) {   // a serving process sees a new length almost every utterance: bound the cache (a capture costs ~3 ms)
+        for (auto& g : graphs) (void)hipGraphExecDestroy(g.second);
+        graphs.clear();
+      }
       hipGraph_t graph = nullptr;
       HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
       int rc = enqueue_forward(s);

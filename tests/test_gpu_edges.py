@@ -239,3 +239,21 @@ def test_randomised_conditioning_flags_vs_oracle(seed):
     assert mse <= 1e-4, (seed, prosody, B, F_, durs, use_grl, ref_ratio, no_ref, mse)
     if not no_ref:       # kept frames are the (prosody-shifted) prompt itself
         assert float((out.cpu()[:, :F_] - ref[:, :F_]).abs().max()) <= 1e-5
+
+
+def test_graph_cache_is_bounded_and_survives_many_lengths():
+    """40 different lengths through one engine (more than the 32-entry graph cache): results stay right, the first length
+    still reproduces its bits afterwards"""
+    m, o = _pair()
+    F_ = 20
+    cond = torch.from_numpy(synth.synth_cond_mel(400, F_))[None]
+    text = torch.from_numpy(synth.synth_tokens(401, 12, VOCAB))[None]
+    outs = {}
+    for i, N in enumerate(list(range(60, 100)) + [60]):
+        y0 = torch.from_numpy(synth.synth_noise(402, N))[None]
+        out, _ = m.sample(cond, text, N, y0=y0, steps=2, cfg_strength=2.0, sway_sampling_coef=5, use_acc_grl=False)
+        if N in outs:
+            np.testing.assert_array_equal(out.cpu().numpy(), outs[N])
+        outs[N] = out.cpu().numpy()
+    ref, _ = o.sample(cond, text, 99, y0=torch.from_numpy(synth.synth_noise(402, 99))[None], steps=2, cfg_strength=2.0, sway_sampling_coef=5)
+    assert _mse(torch.from_numpy(outs[99]), ref, [F_], [99]) <= 1e-4
