@@ -154,6 +154,8 @@ def main():
     model = CFM(arch, VOCAB, sd, device=device)
     model.engine.set_option("dual", a.dual)
     model.engine.set_option("fp8", a.fp8)
+    if os.environ.get("LEMAS_QKV_FUSED") is not None:
+        model.engine.set_option("qkv_fused", int(os.environ["LEMAS_QKV_FUSED"]))
     model.engine.set_option("table_cache", 0)      # hoists are redone for every utterance: nothing cached across steps
     vocoder = VocosEngine(vsd, device=device)
     cond, text, y0 = build_inputs(rank, device)

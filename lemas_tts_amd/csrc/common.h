@@ -128,6 +128,8 @@ struct GemmParams {
 // ---- internal launchers (one per .hip translation unit) ----------------------------------------
 hipError_t launch_gemm_bf16(int epi, const GemmParams& p, hipStream_t s);
 hipError_t launch_gemm_bf16_variant(int epi, const GemmParams& p, int variant, hipStream_t s);  // development: pick a kernel variant
+// one launch for a lane's QK (+RoPE) and V^T projections (same A, different W / bias / epilogue)
+hipError_t launch_gemm_qkv_fused(const GemmParams& pq, const GemmParams& pv, hipStream_t s);
 
 struct AttnParams {
   const bf16_t* q;   // [B2, H, pitch, 64]

@@ -44,6 +44,7 @@ struct lemas_dit {
   bool profile = false;
   bool table_cache = true;  // reuse the AdaLN/time tables while the t-grid is unchanged
   bool dual = true;         // run the two CFG branches as concurrent lanes (second stream / parallel graph branch)
+  bool qkv_fused = true;    // QK and V projections of a lane in one launch
   bool fp8 = false;         // block GEMMs on the MXFP8 path (BASELINE config 5); weights quantised on first use
   bool fp8_ready = false;
   hipStream_t s2 = nullptr;
@@ -545,15 +546,28 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     if (fp8) HIP_TRY(launch_ln_mod_f8(xres, h8, hmx, rows, d, tab, tab_stride, base + d, base, step, q));
     else HIP_TRY(launch_ln_mod(xres, hbf, rows, d, tab, tab_stride, base + d, base, step, q));
     RC_TRY(pend(q));
-    RC_TRY(pkernel(PC_GEMM_QK, &g.ev_start, &g.ev_stop));
-    operands(hbf, h8, hmx, w.wqkv, w.wqkv8, w.sqkv, 0, d);
-    g.bias = w.bqkv.as<float>(); g.N = 2 * in; g.K = d; g.n_valid = 2 * in;
-    g.kv_len = nullptr;
-    HIP_TRY(launch_gemm_bf16(EPI_QK_ROPE, g, q));
-    RC_TRY(pkernel(PC_GEMM_V, &g.ev_start, &g.ev_stop));
-    operands(hbf, h8, hmx, w.wqkv, w.wqkv8, w.sqkv, (size_t)2 * in, d);
-    g.bias = w.bqkv.as<float>() + 2 * in; g.N = in; g.n_valid = in;
-    HIP_TRY(launch_gemm_bf16(EPI_V_T, g, q));
+    const bool fuse_qkv = qkv_fused && !profile && lanes == 2;
+    if (fuse_qkv) {
+      GemmParams gq = g, gv = g;
+      operands(hbf, h8, hmx, w.wqkv, w.wqkv8, w.sqkv, 0, d);
+      gq.A = g.A; gq.a_mx = g.a_mx; gq.W = g.W; gq.w_scale = g.w_scale;
+      gq.bias = w.bqkv.as<float>(); gq.N = 2 * in; gq.K = d; gq.n_valid = 2 * in; gq.kv_len = nullptr;
+      operands(hbf, h8, hmx, w.wqkv, w.wqkv8, w.sqkv, (size_t)2 * in, d);
+      gv.A = g.A; gv.a_mx = g.a_mx; gv.W = g.W; gv.w_scale = g.w_scale;
+      gv.bias = w.bqkv.as<float>() + 2 * in; gv.N = in; gv.K = d; gv.n_valid = in; gv.kv_len = nullptr;
+      HIP_TRY(launch_gemm_qkv_fused(gq, gv, q));
+      g.K = d;
+    } else {
+      RC_TRY(pkernel(PC_GEMM_QK, &g.ev_start, &g.ev_stop));
+      operands(hbf, h8, hmx, w.wqkv, w.wqkv8, w.sqkv, 0, d);
+      g.bias = w.bqkv.as<float>(); g.N = 2 * in; g.K = d; g.n_valid = 2 * in;
+      g.kv_len = nullptr;
+      HIP_TRY(launch_gemm_bf16(EPI_QK_ROPE, g, q));
+      RC_TRY(pkernel(PC_GEMM_V, &g.ev_start, &g.ev_stop));
+      operands(hbf, h8, hmx, w.wqkv, w.wqkv8, w.sqkv, (size_t)2 * in, d);
+      g.bias = w.bqkv.as<float>() + 2 * in; g.N = in; g.n_valid = in;
+      HIP_TRY(launch_gemm_bf16(EPI_V_T, g, q));
+    }
     RC_TRY(pkernel(PC_ATTN, &at.ev_start, &at.ev_stop));
     at.out8 = a8; at.out_mx = amx;
     HIP_TRY(launch_attention(at, q));
@@ -704,6 +718,12 @@ int lemas_dit_set_option(lemas_dit* m, const char* key, int64_t value) {
   if (!strcmp(key, "table_cache")) { m->table_cache = value != 0; return 0; }
   if (!strcmp(key, "dual")) {
     m->dual = value != 0;
+    for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.second);
+    m->graphs.clear();
+    return 0;
+  }
+  if (!strcmp(key, "qkv_fused")) {
+    m->qkv_fused = value != 0;
     for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.second);
     m->graphs.clear();
     return 0;

@@ -47,6 +47,11 @@ __device__ __forceinline__ int xcd_tile_id() {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {   // the same bijection for a sub-range of a fused launch
+  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -782,7 +787,47 @@ hipError_t dispatch(const GemmParams& p, int variant, hipStream_t s) {
   }
 }
 
+// QK (+RoPE) and V^T projections of one lane in ONE launch: they only share their input, so instead of two launches of ~half
+// a chip each, run back to back, the first tiles_q workgroups take 256x128 QK tiles and the rest 128x128 V tiles.  Both bodies
+// are the 8-wave hand-scheduled variants (16 / 17) the separate launches would use.
+template <bool F8>
+__global__ __launch_bounds__(512) void gemm_qkv_fused_kernel(const GemmParams pq, const GemmParams pv, int tiles_q, int tiles_v) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int bid = blockIdx.x;
+  if (bid < tiles_q) {
+    const int tn = pq.N / 128, lid = xcd_remap(bid, tiles_q);
+    gemm_body<EPI_QK_ROPE, 256, 128, 3, 4, 2, 3, true, F8>(pq, smem, (lid / tn) * 256, (lid % tn) * 128);
+  } else {
+    const int tn = pv.N / 128, lid = xcd_remap(bid - tiles_q, tiles_v);
+    gemm_body<EPI_V_T, 128, 128, 3, 2, 4, 3, false, F8>(pv, smem, (lid / tn) * 128, (lid % tn) * 128);
+  }
+}
+
+template <bool F8>
+hipError_t launch_qkv(const GemmParams& pq, const GemmParams& pv, hipStream_t s) {
+  constexpr int ring_q = 3 * ((256 + 128) * 128 + (F8 ? 256 * 4 : 0)), ring_v = 3 * ((128 + 128) * 128 + (F8 ? 128 * 4 : 0));
+  constexpr int slab_q = 8 * slab_bytes<EPI_QK_ROPE, 32, 64>(), slab_v = 8 * slab_bytes<EPI_V_T, 32, 32>();
+  constexpr int lds = (ring_q > ring_v ? ring_q : ring_v) > (slab_q > slab_v ? slab_q : slab_v) ? (ring_q > ring_v ? ring_q : ring_v)
+                                                                                                  : (slab_q > slab_v ? slab_q : slab_v);
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_qkv_fused_kernel<F8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int tiles_q = ((pq.M + 255) / 256) * (pq.N / 128), tiles_v = ((pv.M + 127) / 128) * (pv.N / 128);
+  hipLaunchKernelGGL(gemm_qkv_fused_kernel<F8>, dim3(tiles_q + tiles_v), dim3(512), lds, s, pq, pv, tiles_q, tiles_v);
+  return hipGetLastError();
+}
+
 }  // namespace
+
+hipError_t launch_gemm_qkv_fused(const GemmParams& pq, const GemmParams& pv, hipStream_t s) {
+  if (pq.K % 128 != 0 || pq.N % 128 != 0 || pv.N % 128 != 0 || pq.M != pv.M || pq.f8 != pv.f8 || pq.M <= 0) return hipErrorInvalidValue;
+  if (pq.f8 && (!pq.a_mx || !pq.w_scale || !pv.w_scale)) return hipErrorInvalidValue;
+  return pq.f8 ? launch_qkv<true>(pq, pv, s) : launch_qkv<false>(pq, pv, s);
+}
 
 hipError_t launch_gemm_bf16_variant(int epi, const GemmParams& p, int variant, hipStream_t s) {
   if (p.K % BK != 0 || p.N % 128 != 0 || p.M <= 0 || p.seq_pitch <= 0) return hipErrorInvalidValue;
