@@ -134,7 +134,10 @@ def rope_apply(x: Tensor, freqs: Tensor) -> Tensor:
 
 
 def euler_solve(fn, y0: Tensor, t: Tensor) -> Tensor:
-    """torchdiffeq odeint(method='euler') on the caller's grid (call site cfm.py:456)."""
+    """torchdiffeq odeint(method='euler') on the caller's grid (call site cfm.py:456).  torchdiffeq refuses a grid that is
+    not strictly monotone -- which is what `sway_sampling_coef = -1` (the default of infer_batch_process, utils_infer.py:476)
+    produces with this sampler's power warp: t ** (1 + min(sway_max, -1)) = t ** 0 = 1 everywhere."""
+    assert bool((t[1:] > t[:-1]).all()), "t must be strictly increasing or decreasing"
     ys = [y0]
     y = y0
     for k in range(t.shape[0] - 1):
