@@ -104,30 +104,45 @@ __global__ __launch_bounds__(256) void grn_norm_kernel(const float* __restrict__
   if (rg == 0)
     gx_part[((size_t)b * GRN_SPLIT + z) * C + c] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
 }
+// a wave applies GRN_ROWS consecutive rows (of one sample: N % GRN_ROWS is not required, the sample index is re-derived per row):
+// the 16 x C/64 partial-norm loads that rebuild Nx are amortised over them instead of repeated for every row
+constexpr int GRN_ROWS = 4;
 template <int C>
 __global__ __launch_bounds__(256) void grn_apply_kernel(float* __restrict__ x, const float* __restrict__ gx,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         int M, int N) {
   constexpr int PER = C / 64;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
-  const int lane = threadIdx.x & 63, b = row / N;
-  float g[PER], s = 0.f;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * GRN_ROWS;
+  if (row0 >= M) return;
+  const int lane = threadIdx.x & 63;
+  float g[PER], gm[PER], bt[PER], denom = 0.f;
 #pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    float q = 0.f;
+  for (int i = 0; i < PER; ++i) { gm[i] = gamma[lane + 64 * i]; bt[i] = beta[lane + 64 * i]; }
+  int bcur = -1;
+  for (int r = 0; r < GRN_ROWS; ++r) {
+    const int row = row0 + r;
+    if (row >= M) break;
+    const int b = row / N;
+    if (b != bcur) {   // wave-uniform
+      bcur = b;
+      float s = 0.f;
 #pragma unroll
-    for (int z = 0; z < GRN_SPLIT; ++z) q += gx[((size_t)b * GRN_SPLIT + z) * C + lane + 64 * i];
-    g[i] = sqrtf(q);
-    s += g[i];
-  }
-  const float denom = wave_sum(s) * (1.0f / C) + 1e-6f;
-  float* xr = x + (size_t)row * C;
+      for (int i = 0; i < PER; ++i) {
+        float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    const int c = lane + 64 * i;
-    const float v = xr[c];
-    xr[c] = gamma[c] * (v * (g[i] / denom)) + beta[c] + v;
+        for (int z = 0; z < GRN_SPLIT; ++z) q += gx[((size_t)b * GRN_SPLIT + z) * C + lane + 64 * i];
+        g[i] = sqrtf(q);
+        s += g[i];
+      }
+      denom = wave_sum(s) * (1.0f / C) + 1e-6f;
+    }
+    float* xr = x + (size_t)row * C;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int c = lane + 64 * i;
+      const float v = xr[c];
+      xr[c] = gm[i] * (v * (g[i] / denom)) + bt[i] + v;
+    }
   }
 }
 
@@ -294,7 +309,7 @@ hipError_t launch_ln_affine(const float* x, const float* w, const float* b, floa
 hipError_t launch_grn(float* x, float* gx_scratch, const float* gamma, const float* beta, int B, int N, int C, hipStream_t s) {
   if (C != 1024) return hipErrorInvalidValue;
   hipLaunchKernelGGL(grn_norm_kernel, dim3(C / 64, B, GRN_SPLIT), dim3(256), 0, s, x, gx_scratch, N, C);   // gx_scratch: [B][GRN_SPLIT][C]
-  hipLaunchKernelGGL(grn_apply_kernel<1024>, dim3((B * N + 3) / 4), dim3(256), 0, s, x, gx_scratch, gamma, beta, B * N, N);
+  hipLaunchKernelGGL(grn_apply_kernel<1024>, dim3((B * N + 4 * GRN_ROWS - 1) / (4 * GRN_ROWS)), dim3(256), 0, s, x, gx_scratch, gamma, beta, B * N, N);
   return hipGetLastError();
 }
 hipError_t launch_add_rowvec(float* x, const float* vec, int BB, int B, int N, int C, int nlim, hipStream_t s) {

@@ -196,5 +196,11 @@ struct GemmF32Params {
   const float* colscale;
   const float* add;          // for F32_BIAS_ADD2: [2M, N]
   const uint8_t* rowmask;    // optional: rows with rowmask[m]!=0 are written as 0
+  // batched form (nbatch > 0): the same A against nbatch weight / bias tensors (device arrays of pointers), output z at
+  // out + z * out_bstride -- the 22 AdaLN table GEMMs of a prepare() as one launch
+  int nbatch;
+  const float* const* Wv;
+  const float* const* biasv;
+  size_t out_bstride;
 };
 hipError_t launch_gemm_f32(int epi, const GemmF32Params& p, hipStream_t s);

@@ -52,6 +52,7 @@ struct lemas_dit {
 
   std::vector<BlockW> blocks;
   DevBuf wproj_out, bproj_out;  // padded to 128 rows
+  DevBuf d_tabW, d_tabB;        // device arrays of the per-block attn_norm.linear weight / bias pointers (batched table GEMM)
   DevBuf wconv[2];              // [G][taps][64][64] bf16
 
   // --- per-shape state (valid after prepare)
@@ -82,7 +83,7 @@ struct lemas_dit {
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
     for (auto& r : prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
-    for (DevBuf* b : {&wproj_out, &bproj_out, &wconv[0], &wconv[1], &d_step, &d_dt, &d_cfg, &d_t, &d_tab, &d_rope_cos,
+    for (DevBuf* b : {&wproj_out, &bproj_out, &d_tabW, &d_tabB, &wconv[0], &wconv[1], &d_step, &d_dt, &d_cfg, &d_t, &d_tab, &d_rope_cos,
                       &d_rope_sin, &d_len, &d_sin, &d_h1, &d_temb, &d_st, &d_cond_eff, &d_step_cond, &d_pm, &d_pt, &d_te,
                       &d_rowmask, &d_t1, &d_t2, &d_t3, &d_gx, &d_ct, &d_pconst, &d_y, &d_xres, &d_hbf, &d_q, &d_k, &d_vt,
                       &d_abf, &d_ff, &d_cmid, &d_pred, &d_h8, &d_hmx, &d_a8, &d_amx, &d_ff8, &d_ffmx})
@@ -263,6 +264,18 @@ int lemas_dit::finalize() {
     HIP_TRY(launch_convpos_weight(ws.ptr(T("input_embed.conv_pos_embed.conv1d." + std::to_string(j * 2) + ".weight")),
                                   wconv[j].as<bf16_t>(), d, cg, cfg.conv_pos_kernel, s));
   }
+  {
+    std::vector<const float*> hw(cfg.depth), hb(cfg.depth);
+    for (int l = 0; l < cfg.depth; ++l) {
+      const std::string p = T("transformer_blocks." + std::to_string(l) + ".attn_norm.linear.");
+      hw[l] = ws.ptr(p + "weight");
+      hb[l] = ws.ptr(p + "bias");
+    }
+    RC_TRY(d_tabW.ensure((size_t)cfg.depth * sizeof(float*)));
+    RC_TRY(d_tabB.ensure((size_t)cfg.depth * sizeof(float*)));
+    HIP_TRY(hipMemcpy(d_tabW.p, hw.data(), (size_t)cfg.depth * sizeof(float*), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_tabB.p, hb.data(), (size_t)cfg.depth * sizeof(float*), hipMemcpyHostToDevice));
+  }
   RC_TRY(d_step.ensure(64));
   if (!s2) {
     HIP_TRY(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
@@ -312,12 +325,12 @@ int lemas_dit::build_tables(const lemas_sample_args* a, hipStream_t s) {
     HIP_TRY(launch_gemm_f32(F32_BIAS, g, s));
     HIP_TRY(launch_silu(d_temb.as<float>(), d_st.as<float>(), (size_t)Snew * d, s));
     g.A = d_st.as<float>(); g.lda = d; g.ldw = d; g.K = d; g.ldc = tab_stride;
-    for (int l = 0; l < cfg.depth; ++l) {
-      const std::string p = T("transformer_blocks." + std::to_string(l) + ".attn_norm.linear.");
-      g.W = ws.ptr(p + "weight"); g.bias = ws.ptr(p + "bias"); g.N = 6 * d;
-      g.out = d_tab.as<float>() + (size_t)l * 6 * d;
-      HIP_TRY(launch_gemm_f32(F32_BIAS, g, s));
-    }
+    // the depth attn_norm.linear GEMMs [S, d] x [6 d, d]^T as ONE launch (grid.z = block): 96 workgroups each would leave the
+    // chip mostly idle 22 times in a row
+    g.N = 6 * d; g.out = d_tab.as<float>();
+    g.nbatch = cfg.depth; g.Wv = d_tabW.as<const float*>(); g.biasv = d_tabB.as<const float*>(); g.out_bstride = (size_t)6 * d;
+    HIP_TRY(launch_gemm_f32(F32_BIAS, g, s));
+    g.nbatch = 0; g.Wv = nullptr; g.biasv = nullptr;
     g.W = ws.ptr(T("norm_out.linear.weight")); g.bias = ws.ptr(T("norm_out.linear.bias")); g.N = 2 * d;
     g.out = d_tab.as<float>() + (size_t)cfg.depth * 6 * d;
     HIP_TRY(launch_gemm_f32(F32_BIAS, g, s));

@@ -27,8 +27,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Params p) {
 
   const int lrow = tid >> 2, lk4 = (tid & 3) * 4;
   const bool a_ok = (m0 + lrow) < p.M, b_ok = (n0 + lrow) < p.N;
+  const float* Wz = p.nbatch > 0 ? p.Wv[blockIdx.z] : p.W;
+  const float* biasz = p.nbatch > 0 ? p.biasv[blockIdx.z] : p.bias;
+  float* outz = p.out + (p.nbatch > 0 ? (size_t)blockIdx.z * p.out_bstride : 0);
   const float* ap = p.A + (size_t)(a_ok ? m0 + lrow : 0) * p.lda + lk4;
-  const float* bp = p.W + (size_t)(b_ok ? n0 + lrow : 0) * p.ldw + lk4;
+  const float* bp = Wz + (size_t)(b_ok ? n0 + lrow : 0) * p.ldw + lk4;
 
   f32x4 acc[2][2];
 #pragma unroll
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Params p) {
   for (int j = 0; j < 2; ++j) {
     const int n = n0 + wn * 32 + j * 16 + l15;
     if (n >= p.N) continue;
-    const float bias = p.bias ? p.bias[n] : 0.f;
+    const float bias = biasz ? biasz[n] : 0.f;
     const float cs = (EPI == F32_BIAS_RES_SCALE && p.colscale) ? p.colscale[n] : 1.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -85,11 +88,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Params p) {
         if (EPI == F32_BIAS_SIGMOID) v = 1.0f / (1.0f + expf(-v));
         if (EPI == F32_BIAS_RES_SCALE) v = p.res[(size_t)m * p.ldres + n] + cs * v;
         if (EPI == F32_BIAS_ADD2) {
-          p.out[(size_t)m * p.ldc + n] = v + p.add[(size_t)m * p.ldc + n];
-          p.out[(size_t)(m + p.M) * p.ldc + n] = v + p.add[(size_t)(m + p.M) * p.ldc + n];
+          outz[(size_t)m * p.ldc + n] = v + p.add[(size_t)m * p.ldc + n];
+          outz[(size_t)(m + p.M) * p.ldc + n] = v + p.add[(size_t)(m + p.M) * p.ldc + n];
         } else {
           if (p.rowmask && p.rowmask[m]) v = 0.f;
-          p.out[(size_t)m * p.ldc + n] = v;
+          outz[(size_t)m * p.ldc + n] = v;
         }
       }
   }
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Params p) {
 
 template <int EPI>
 hipError_t launch(const GemmF32Params& p, hipStream_t s) {
-  dim3 grid((p.N + TN - 1) / TN, (p.M + TM - 1) / TM);
+  dim3 grid((p.N + TN - 1) / TN, (p.M + TM - 1) / TM, p.nbatch > 0 ? p.nbatch : 1);
   hipLaunchKernelGGL(gemm_f32_kernel<EPI>, grid, dim3(256), 0, s, p);
   return hipGetLastError();
 }
@@ -106,6 +109,7 @@ hipError_t launch(const GemmF32Params& p, hipStream_t s) {
 
 hipError_t launch_gemm_f32(int epi, const GemmF32Params& p, hipStream_t s) {
   if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.K & 3) || (p.lda & 3) || (p.ldw & 3)) return hipErrorInvalidValue;
+  if (p.nbatch > 0 && (!p.Wv || !p.biasv)) return hipErrorInvalidValue;
   switch (epi) {
     case F32_BIAS: return launch<F32_BIAS>(p, s);
     case F32_BIAS_GELU: return launch<F32_BIAS_GELU>(p, s);
