@@ -407,8 +407,14 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(4, 4))) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run, mx * c);
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      float m_new = fmaxf(m_run, mx * c);
+      // deferred max: while no query of the wave outgrows its running max by more than 2^8, keep the old max (P <= 256, exact
+      // after the final division by l) -- no alpha, no rescale of l and O on that tile
+      // (measured: 45.0 -> 43.2 us at N = 1875, +1.4 % end to end; on most tiles SOME query's max grows a little, so the plain
+      // "did any max grow" test rescaled almost every time)
+      const bool defer = __all(m_new - m_run <= 8.0f);
+      if (defer) m_new = m_run;
+      const float alpha = defer ? 1.0f : __builtin_amdgcn_exp2f(m_run - m_new);
       const bool grew = m_new > m_run;
       m_run = m_new;
       const f32x2 c2 = {c, c}, m2 = {m_new, m_new};
