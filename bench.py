@@ -233,8 +233,8 @@ def main():
         kname = "attn_fwd_splitkv_kernel" if dom == "attention" else f"gemm_bf16_kernel<{dom}>"
         traffic = None   # HBM-side bytes per launch from the committed PMC passes (rocprofv3 cannot run inside bench.py)
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01j_traffic.json" if lanes == 2 else "r01_traffic.json")))
-            traffic = tj[dom]["hbm_bytes_per_launch"]        # r01j: per-lane launches (one CFG branch); r01: both branches in one launch
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01o_traffic.json" if lanes == 2 else "r01_traffic.json")))
+            traffic = tj[dom]["hbm_bytes_per_launch"]        # r01o: per-lane launches (one CFG branch); r01: both branches in one launch
         except (OSError, KeyError, ValueError):
             pass
         peak = MFMA_FP8_PEAK_TFLOPS if (a.fp8 and dom != "attention") else MFMA_BF16_PEAK_TFLOPS   # attention stays bf16
