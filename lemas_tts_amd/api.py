@@ -6,7 +6,10 @@ Same constructor arguments and the same ``infer(...)`` keyword surface and retur
 * ``frontend`` is an OBJECT with ``text2phn(str) -> 'p1|p2|...'`` and ``dtype == "phone"`` (the reference builds
   ``TextNorm`` from espeak/jieba/langid, none of which exist here and all of which are out of scope); with
   ``frontend=None`` the caller passes phone-token lists directly;
-* ``ref_file`` is the reference mel ``[F, 100]`` (or an ``(audio, sr)`` pair once the wav->mel front edge lands);
+* ``frontend="phone"`` / ``"char"`` (the reference's spelling) builds the REFERENCE's own ``lemas_tts.infer.frontend.TextNorm``
+  when that package and its espeak/jieba stack are importable on the host (the text frontend stays host Python by the
+  north star) and raises otherwise;
+* ``ref_file`` is a wav path (as in the reference), a loaded ``(audio, sr)`` pair, or a ready mel ``[F, 100]``;
 * ``state_dict`` / ``vocoder_state_dict`` / ``vocab_char_map`` allow in-memory (synthetic) weights.
 """
 from __future__ import annotations
@@ -18,7 +21,33 @@ from pathlib import Path
 import numpy as np
 import torch
 
+from .infer.audio_io import save_wav
 from .infer.utils_infer import infer_process, load_arch_config, load_model, load_vocoder
+
+
+def _find_pretrained_root() -> Path:
+    """``api.py:39-75``: LEMAS_PRETRAINED_ROOT, then a /models/<id>/pretrained_models mount, then ``pretrained_models`` next
+    to an ancestor of this file or in the working directory (falling back to the latter path even when absent)."""
+    import os
+    env_root = os.environ.get("LEMAS_PRETRAINED_ROOT")
+    if env_root and Path(env_root).is_dir():
+        return Path(env_root)
+    models_dir = Path("/models")
+    if models_dir.is_dir():
+        specific = models_dir / "LEMAS-Project__LEMAS-TTS" / "pretrained_models"
+        if specific.is_dir():
+            return specific
+        for child in sorted(models_dir.iterdir()):
+            if child.is_dir() and (child / "pretrained_models").is_dir():
+                return child / "pretrained_models"
+    for parent in Path(__file__).resolve().parents:
+        if (parent / "pretrained_models").is_dir():
+            return parent / "pretrained_models"
+    return Path.cwd() / "pretrained_models"
+
+
+PRETRAINED_ROOT = _find_pretrained_root()
+CKPTS_ROOT = PRETRAINED_ROOT / "ckpts"
 
 
 def seed_everything(seed=0):
@@ -48,7 +77,16 @@ class TTS:
         is_local = vocoder_local_path is not None and Path(str(vocoder_local_path)).is_dir()
         self.vocoder = load_vocoder(self.mel_spec_type, is_local, vocoder_local_path, self.device, hf_cache_dir,
                                     state_dict=vocoder_state_dict)          # api.py:136
-        self.frontend = frontend                                            # api.py:140-151
+        if isinstance(frontend, str):                                       # api.py:140-151: TextNorm(dtype=frontend)
+            try:
+                from lemas_tts.infer.frontend import TextNorm              # the reference's host-side text frontend
+            except Exception as e:                                          # espeak / jieba / langid / phonemizer missing
+                raise ImportError(
+                    f"frontend={frontend!r} needs the reference's lemas_tts.infer.frontend.TextNorm (and its espeak/jieba/langid "
+                    f"stack) on the host: {e}.  Pass a frontend object with text2phn()/text2norm(), or frontend=None and "
+                    "phone-token lists.") from e
+            frontend = TextNorm(dtype=frontend)
+        self.frontend = frontend
         self.ema_model = load_model(None, cfg["arch"], ckpt_file, self.mel_spec_type, vocab_file, self.ode_method,
                                     self.use_ema, self.device, use_prosody_encoder=use_prosody_encoder,
                                     prosody_cfg_path=prosody_cfg_path, prosody_ckpt_path=prosody_ckpt_path,
@@ -56,14 +94,25 @@ class TTS:
         self.seed = None
 
     def export_wav(self, wav, file_wave, remove_silence=False):
-        """api.py:162-166 writes with soundfile; here a minimal 16-bit PCM writer (no soundfile in this image)."""
-        import wave
-        pcm = (np.clip(wav, -1.0, 1.0) * 32767.0).astype("<i2")
-        with wave.open(str(file_wave), "wb") as f:
-            f.setnchannels(1)
-            f.setsampwidth(2)
-            f.setframerate(self.target_sample_rate)
-            f.writeframes(pcm.tobytes())
+        """api.py:162-166: ``soundfile.write(file_wave, wav, sr)`` (16-bit PCM for .wav); silence removal (pydub) is out of scope."""
+        if remove_silence:
+            raise NotImplementedError("remove_silence needs pydub (utils_infer.py:629-640): not on the MI355X path")
+        save_wav(file_wave, wav, self.target_sample_rate, "PCM_16")
+
+    def export_spectrogram(self, spec, file_spec):
+        """api.py:168-169 renders the mel with matplotlib; without it the array itself is stored (``.npy``)."""
+        try:
+            import matplotlib
+            matplotlib.use("Agg")
+            import matplotlib.pyplot as plt
+        except ImportError:
+            np.save(str(file_spec) if str(file_spec).endswith(".npy") else str(file_spec) + ".npy", np.asarray(spec))
+            return
+        plt.figure(figsize=(12, 4))
+        plt.imshow(spec, origin="lower", aspect="auto")
+        plt.colorbar()
+        plt.savefig(file_spec)
+        plt.close()
 
     def infer(self, ref_file, ref_text, gen_text, show_info=print, progress=None, target_rms=0.1,
               cross_fade_duration=0.15, use_acc_grl=False, ref_ratio=None, no_ref_audio=False, cfg_strength=2,
@@ -97,6 +146,8 @@ class TTS:
         # every line draws its noise from the generator seed_everything() just seeded, in order
         if file_wave is not None:
             self.export_wav(wav, file_wave)
+        if file_spec is not None:
+            self.export_spectrogram(spec, file_spec)
         return wav, sr, spec
 
     def process_phone_list(self, parts):

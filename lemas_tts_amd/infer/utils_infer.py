@@ -158,7 +158,11 @@ def infer_process(ref_audio, ref_text, gen_text, model_obj, vocoder, mel_spec_ty
                   cfg_strength=cfg_strength, sway_sampling_coef=sway_sampling_coef, use_acc_grl=True,
                   use_prosody_encoder=True, ref_ratio=None, no_ref_audio=False, speed=speed, fix_duration=fix_duration,
                   device=device, **extra):
-    """:399-458.  ``ref_audio`` is the loaded ``(audio, sr)`` pair or a mel (see module docstring)."""
+    """:399-458.  ``ref_audio`` is a wav path (``torchaudio.load`` at :425 -> ``audio_io.load_wav``), the loaded
+    ``(audio, sr)`` pair, or a mel (see module docstring)."""
+    if isinstance(ref_audio, (str, os.PathLike)):
+        from .audio_io import load_wav
+        ref_audio = load_wav(ref_audio)
     if isinstance(ref_text, str):
         raise NotImplementedError("str ref_text needs chunk_text/convert_char_to_pinyin (frontend, out of scope); pass phone lists")
     gen_text_batches = gen_text

@@ -158,3 +158,68 @@ def test_gen_wav_multilingual_random_spans_and_rates(seed):
     gain = rms / 0.1 if rms < 0.1 else 1.0
     wref = O.OracleVocos(vsd).decode(mel.cpu()) * gain
     assert float((wav.cpu() - wref[0]).abs().max()) < 1e-4 * max(1.0, float(wref.abs().max()))
+
+
+# ---------------------------------------------------------------- file-level entry point (run_edit_for_pair / main, :210-466)
+def _alignment():
+    return {"interval": [0.5, 4.5], "display_text": "the quick brown fox jumps", "modified_text": ["brown fox", "red cat"],
+            "modified_index": [2, 4],
+            "words": [{"interval": [0.6, 0.9]}, {"interval": [1.0, 1.5]}, {"interval": [1.7, 2.2]}, {"interval": [2.3, 2.9]},
+                      {"interval": [3.1, 3.9]}]}
+
+
+def test_edit_request_from_alignment_and_pairs(tmp_path):
+    from lemas_tts_amd.scripts.speech_edit_multilingual import build_parser, collect_pairs, edit_request_from_alignment
+    (utt0, utt1), spans, text = edit_request_from_alignment(_alignment())
+    assert (utt0, utt1) == (0.5, 4.5) and text == "the quick red cat jumps"
+    assert spans == [(pytest.approx(1.7 - 0.5 - 0.1), pytest.approx(2.9 - 0.5))]           # :246-247
+    d = _alignment()
+    d["modified_index"] = [-3, 99]                                                          # clipped to the word list (:238-239)
+    d["words"][0]["interval"][0] = 0.52                                                     # start - 0.1 s would be negative
+    _, spans, _ = edit_request_from_alignment(d)
+    assert spans == [(0.0, pytest.approx(3.9 - 0.5))]
+    d["modified_index"] = [3, 3]
+    with pytest.raises(AssertionError, match="empty"):
+        edit_request_from_alignment(d)
+    for n in ("b.wav", "a.WAV", "c.txt", "d.mp3"):
+        (tmp_path / n).write_bytes(b"")
+    pairs = collect_pairs(None, str(tmp_path), "/al", "/out")
+    assert pairs == [(str(tmp_path / "a.WAV"), "/al/a.json", "/out/a.wav"), (str(tmp_path / "b.wav"), "/al/b.json", "/out/b.wav")]
+    assert collect_pairs("/x/y.wav", "ignored", "/al", "/out") == [("/x/y.wav", "/al/y.json", "/out/y.wav")]
+    a = build_parser().parse_args([])
+    assert (a.model, a.frontend, a.nfe_step, a.cfg_strength, a.sway_sampling_coef, a.ref_ratio, a.seed) == ("multilingual", "phone", 64, 5.0, 3.0, 1.0, -1)
+
+
+@pytest.mark.gpu
+def test_speech_edit_main_files_in_files_out(tmp_path):
+    """wav (stereo, 16 kHz) + alignment json in, edited 24 kHz wav out; equals the in-memory routine on the same segment"""
+    import json
+    import types
+    from lemas_tts_amd import synth
+    from lemas_tts_amd.engine import VocosEngine
+    from lemas_tts_amd.infer.audio_io import load_wav, save_wav
+    from lemas_tts_amd.model.cfm import CFM
+    from lemas_tts_amd.model.layout import DiTArch
+    import lemas_tts_amd.scripts.speech_edit_multilingual as M
+    arch = DiTArch(depth=2)
+    vocab = {c: i for i, c in enumerate(" abcdefghijklmnopqrstuvwxyz.")}
+    model = CFM(arch, len(vocab), synth.synth_cfm_state_dict(arch, len(vocab), 101), vocab_char_map=vocab, device="cuda:0")
+    voc = types.SimpleNamespace(engine=VocosEngine(synth.synth_vocos_state_dict(102), device="cuda:0"))
+    tts = types.SimpleNamespace(ema_model=model, vocoder=voc, frontend=None, device="cuda:0", mel_spec_type="vocos", target_sample_rate=24000)
+    rng = np.random.default_rng(103)
+    x = 0.05 * rng.standard_normal((5 * 16000, 2))
+    (tmp_path / "in").mkdir(); (tmp_path / "al").mkdir()
+    save_wav(tmp_path / "in" / "utt.wav", x, 16000, "PCM_16")
+    (tmp_path / "al" / "utt.json").write_text(json.dumps(_alignment()))
+    save_wav(tmp_path / "in" / "orphan.wav", x[:100], 16000, "PCM_16")            # no alignment: warned about and skipped
+    rc = M.main(["--wav_dir", str(tmp_path / "in"), "--align_dir", str(tmp_path / "al"), "--save_dir", str(tmp_path / "out"),
+                 "--nfe_step", "2", "--seed", "77", "--frontend", "none"], tts=tts)
+    assert rc == 0 and not (tmp_path / "out" / "orphan.wav").exists()
+    got, sr = load_wav(tmp_path / "out" / "utt.wav")
+    wav, sr_in = M.load_wav_mono(str(tmp_path / "in" / "utt.wav"), 24000)
+    assert sr == 24000 and sr_in == 24000 and wav.ndim == 1 and abs(wav.numel() - 5 * 24000) <= 1 and float(wav.abs().max()) <= 0.999
+    seg = wav[int(round(0.5 * 24000)):int(round(4.5 * 24000))]
+    (_, _), spans, text = M.edit_request_from_alignment(_alignment())
+    ref, mel = M.gen_wav_multilingual(tts, seg, 24000, text, spans, nfe_step=2, cfg_strength=5.0, sway_sampling_coef=3.0, seed=77)
+    assert got.shape == (1, ref.numel()) and mel.shape[2] == seg.numel() // 256 + 2   # F = nw // hop + 1 prompt frames, +1 (cfm.py:300-302)
+    np.testing.assert_array_equal(got.numpy()[0], ref.reshape(-1).cpu().numpy())   # 32-bit float WAV: bit-exact
