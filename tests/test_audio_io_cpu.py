@@ -128,3 +128,37 @@ def test_pretrained_root_env_override(tmp_path, monkeypatch):
     assert A._find_pretrained_root() == tmp_path
     monkeypatch.setenv("LEMAS_PRETRAINED_ROOT", str(tmp_path / "missing"))
     assert A._find_pretrained_root().name == "pretrained_models"
+
+
+def test_against_scipy_wavfile(tmp_path):
+    """an independent RIFF implementation on both sides: scipy writes -> load_wav reads, save_wav writes -> scipy reads"""
+    from scipy.io import wavfile
+    rng = np.random.default_rng(5)
+    for dtype, scale in ((np.int16, 32768.0), (np.int32, 2147483648.0), (np.uint8, None), (np.float32, 1.0), (np.float64, 1.0)):
+        if dtype == np.uint8:
+            x = rng.integers(0, 256, size=(501, 2), dtype=np.uint8)
+            want = (x.astype(np.float32) - 128.0) / 128.0
+        elif np.issubdtype(dtype, np.integer):
+            info = np.iinfo(dtype)
+            x = rng.integers(info.min, info.max, size=(501, 2), dtype=dtype)
+            want = (x.astype(np.float64) / scale).astype(np.float32)
+        else:
+            x = rng.uniform(-1, 1, size=(501, 2)).astype(dtype)
+            want = x.astype(np.float32)
+        p = tmp_path / f"s_{np.dtype(dtype).name}.wav"
+        wavfile.write(str(p), 44100, x)
+        y, sr = load_wav(p)
+        assert sr == 44100 and y.shape == (2, 501)
+        np.testing.assert_array_equal(y.numpy(), want.T)
+    z = rng.uniform(-1, 1, size=(333, 2))
+    save_wav(tmp_path / "p16.wav", z, 24000, "PCM_16")
+    sr, got = wavfile.read(str(tmp_path / "p16.wav"))
+    assert sr == 24000 and got.dtype == np.int16
+    np.testing.assert_array_equal(got, np.clip(np.rint(z * 32768.0), -32768, 32767).astype(np.int16))
+    save_wav(tmp_path / "pf.wav", z, 24000, "FLOAT")
+    sr, got = wavfile.read(str(tmp_path / "pf.wav"))
+    assert got.dtype == np.float32
+    np.testing.assert_array_equal(got, z.astype(np.float32))
+    save_wav(tmp_path / "p24.wav", z, 24000, "PCM_24")
+    sr, got = wavfile.read(str(tmp_path / "p24.wav"))             # scipy returns 24-bit data left-justified in int32
+    np.testing.assert_array_equal(got >> 8, np.clip(np.rint(z * 8388608.0), -8388608, 8388607).astype(np.int32))
