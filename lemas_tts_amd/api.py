@@ -6,9 +6,9 @@ Same constructor arguments and the same ``infer(...)`` keyword surface and retur
 * ``frontend`` is an OBJECT with ``text2phn(str) -> 'p1|p2|...'`` and ``dtype == "phone"`` (the reference builds
   ``TextNorm`` from espeak/jieba/langid, none of which exist here and all of which are out of scope); with
   ``frontend=None`` the caller passes phone-token lists directly;
-* ``frontend="phone"`` / ``"char"`` (the reference's spelling) builds the REFERENCE's own ``lemas_tts.infer.frontend.TextNorm``
-  when that package and its espeak/jieba stack are importable on the host (the text frontend stays host Python by the
-  north star) and raises otherwise;
+* ``frontend="phone"`` / ``"char"`` (the reference's spelling) asks the factory registered with
+  :func:`set_frontend_factory` for the object (the integrator registers ``lambda d: TextNorm(dtype=d)``; the product itself
+  never imports the reference package) and raises ``TypeError`` when none is registered;
 * ``ref_file`` is a wav path (as in the reference), a loaded ``(audio, sr)`` pair, or a ready mel ``[F, 100]``;
 * ``state_dict`` / ``vocoder_state_dict`` / ``vocab_char_map`` allow in-memory (synthetic) weights.
 """
@@ -58,6 +58,16 @@ def seed_everything(seed=0):
         torch.cuda.manual_seed_all(seed)
 
 
+FRONTEND_FACTORY = None
+
+
+def set_frontend_factory(factory) -> None:
+    """``factory(dtype: str) -> frontend object`` for ``TTS(frontend="phone" | "char")`` (what api.py:140-151 does with the
+    reference's ``TextNorm``).  The text frontend stays host Python outside this package (north star); this is the seam."""
+    global FRONTEND_FACTORY
+    FRONTEND_FACTORY = factory
+
+
 class TTS:
     def __init__(self, model="multilingual_grl", ckpt_file="", vocab_file="", ode_method="euler", use_ema=False,
                  vocoder_local_path=None, use_prosody_encoder=False, prosody_cfg_path="", prosody_ckpt_path="",
@@ -77,15 +87,15 @@ class TTS:
         is_local = vocoder_local_path is not None and Path(str(vocoder_local_path)).is_dir()
         self.vocoder = load_vocoder(self.mel_spec_type, is_local, vocoder_local_path, self.device, hf_cache_dir,
                                     state_dict=vocoder_state_dict)          # api.py:136
-        if isinstance(frontend, str):                                       # api.py:140-151: TextNorm(dtype=frontend)
-            try:
-                from lemas_tts.infer.frontend import TextNorm              # the reference's host-side text frontend
-            except Exception as e:                                          # espeak / jieba / langid / phonemizer missing
-                raise ImportError(
-                    f"frontend={frontend!r} needs the reference's lemas_tts.infer.frontend.TextNorm (and its espeak/jieba/langid "
-                    f"stack) on the host: {e}.  Pass a frontend object with text2phn()/text2norm(), or frontend=None and "
-                    "phone-token lists.") from e
-            frontend = TextNorm(dtype=frontend)
+        if isinstance(frontend, str):
+            # api.py:140-151 builds TextNorm(dtype=frontend) from the reference's own host-side frontend package (espeak / jieba /
+            # langid).  The text frontend is out of this build's scope and the product does not import the reference package:
+            # the integrator registers a factory once, or hands the OBJECT over.
+            if FRONTEND_FACTORY is None:
+                raise TypeError(f"frontend={frontend!r}: no text frontend is registered.  Call lemas_tts_amd.api.set_frontend_factory("
+                                "lambda dtype: TextNorm(dtype=dtype)) once, or pass a frontend OBJECT with text2phn() / text2norm() "
+                                "and a .dtype of 'phone' or 'char', or frontend=None with phone-token lists")
+            frontend = FRONTEND_FACTORY(frontend)
         self.frontend = frontend
         self.ema_model = load_model(None, cfg["arch"], ckpt_file, self.mel_spec_type, vocab_file, self.ode_method,
                                     self.use_ema, self.device, use_prosody_encoder=use_prosody_encoder,

@@ -14,7 +14,7 @@ inline int grid_for(size_t n, int block = 256) {
 // ---- TextEmbedding front (backbones/dit.py:51-70): token+1, truncate/pad to N, pad-mask BEFORE the cfg drop,
 // embedding lookup + sinusoid position table, masked_fill(0).  Rows [0,B*N) = text branch, [B*N,2B*N) = dropped text.
 __global__ void text_gather_kernel(const int64_t* __restrict__ text, int B, int Nt, int N, int td, int branches,
-                                   const float* __restrict__ table, const float* __restrict__ freqs_cis, int max_pos,
+                                   const float* __restrict__ table, int vocab_rows, const float* __restrict__ freqs_cis, int max_pos,
                                    float* __restrict__ out, uint8_t* __restrict__ rowmask) {
   const size_t total = (size_t)branches * B * N * td;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -25,6 +25,9 @@ __global__ void text_gather_kernel(const int64_t* __restrict__ text, int B, int 
     const int b = bb % B, branch = bb / B;
     int tok = 0;
     if (n < Nt) tok = (int)text[(size_t)b * Nt + n] + 1;
+    // ids outside [-1, vocab) raise in the reference's nn.Embedding; the Python mirror checks them on the host
+    // (model/cfm.py), here they are clamped so that a raw C-ABI caller cannot read outside the table
+    tok = tok < 0 ? 0 : (tok >= vocab_rows ? vocab_rows - 1 : tok);
     const bool pad = tok == 0;
     if (branch == 1) tok = 0;
     const int pos = n < max_pos ? n : max_pos - 1;
@@ -293,9 +296,9 @@ __global__ void scale_kernel(float* __restrict__ x, float s, size_t n) {
   hipLaunchKernelGGL(kern, dim3(grid_for(total)), dim3(256), 0, s, __VA_ARGS__); \
   return hipGetLastError();
 
-hipError_t launch_text_gather(const int64_t* text, int B, int Nt, int N, int td, int branches, const float* table,
+hipError_t launch_text_gather(const int64_t* text, int B, int Nt, int N, int td, int branches, const float* table, int vocab_rows,
                               const float* freqs_cis, int max_pos, float* out, uint8_t* rowmask, hipStream_t s) {
-  LAUNCH(text_gather_kernel, (size_t)branches * B * N * td, text, B, Nt, N, td, branches, table, freqs_cis, max_pos, out, rowmask)
+  LAUNCH(text_gather_kernel, (size_t)branches * B * N * td, text, B, Nt, N, td, branches, table, vocab_rows, freqs_cis, max_pos, out, rowmask)
 }
 hipError_t launch_dwconv7(const float* x, const float* w, const float* bias, float* out, int B, int N, int C, hipStream_t s) {
   LAUNCH(dwconv7_kernel, (size_t)B * N * C, x, w, bias, out, B, N, C)

@@ -29,12 +29,23 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
     if (_rc != 0) return _rc; \
   } while (0)
 
-// Growable device allocation.  `generation` bumps on every (re)allocation so cached hipGraphs that baked the old
-// address can be invalidated.
+// Zero-fill that is COMPLETE when it returns.  hipMemset on device memory only enqueues the fill on the NULL stream
+// (measured on MI355X / ROCm 7.2: the call returns in 3 us for 2 GiB) and the NULL stream does not order against the
+// engines' non-blocking streams, so a plain hipMemset after hipMalloc can land AFTER the first kernels that write the
+// buffer (tools/exp/memset_race_probe.hip: 191 of 200 trials lose the kernel's data).  That was the round-1 "box-dependent"
+// config3 failure: tables and workspaces partly re-zeroed under load.  Allocation is rare, so waiting here is free.
+inline hipError_t zero_fill_sync(void* p, size_t n) {
+  hipError_t e = hipMemsetAsync(p, 0, n, nullptr);
+  if (e != hipSuccess) return e;
+  return hipStreamSynchronize(nullptr);
+}
+
+// Growable device allocation.  `*moved` (the owning engine's counter, if set) bumps on every (re)allocation so that the
+// owner's cached hipGraphs, which baked the old address, can be invalidated -- per engine, not process-wide.
 struct DevBuf {
   void* p = nullptr;
   size_t bytes = 0;
-  static unsigned long long generation;
+  unsigned long long* moved = nullptr;
   int ensure(size_t n) {
     if (n <= bytes) return 0;
     if (p) HIP_TRY(hipFree(p));
@@ -42,9 +53,9 @@ struct DevBuf {
     bytes = 0;
     n = (n + 255) & ~(size_t)255;
     HIP_TRY(hipMalloc(&p, n));
-    HIP_TRY(hipMemset(p, 0, n));  // pad regions must stay finite (attention v^T tail)
+    HIP_TRY(zero_fill_sync(p, n));  // pad regions must stay finite (attention v^T tail)
     bytes = n;
-    ++generation;
+    if (moved) ++*moved;
     return 0;
   }
   void release() {

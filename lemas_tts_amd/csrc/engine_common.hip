@@ -6,7 +6,6 @@
 namespace lemas {
 
 static thread_local char g_err[512] = "";
-unsigned long long DevBuf::generation = 1;
 
 void set_error(const char* fmt, ...) {
   va_list ap;
@@ -43,7 +42,7 @@ int WeightStore::load(const char* name, const float* host, const int64_t* shape,
   x.dev = nullptr;
   // +64 floats of slack: the fp32 GEMM reads whole float4 groups of offset sub-matrices (input_embed.proj columns)
   HIP_TRY(hipMalloc((void**)&x.dev, (numel + 64) * sizeof(float)));
-  HIP_TRY(hipMemset(x.dev, 0, (numel + 64) * sizeof(float)));
+  HIP_TRY(zero_fill_sync(x.dev, (numel + 64) * sizeof(float)));
   HIP_TRY(hipMemcpy(x.dev, host, numel * sizeof(float), hipMemcpyHostToDevice));
   x.shape.assign(shape, shape + ndim);
   x.numel = numel;

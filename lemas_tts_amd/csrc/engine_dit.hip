@@ -72,25 +72,40 @@ struct lemas_dit {
   int tab_stride = 0;
 
   std::map<std::string, hipGraphExec_t> graphs;
-  unsigned long long graph_generation = 0;
+  unsigned long long moved = 1;             // bumped by this engine's DevBufs when one of them is (re)allocated
+  unsigned long long graph_generation = 0;  // value of `moved` the cached graphs were captured under
 
   struct ProfRec { hipEvent_t a, b; int cls; };
   std::vector<ProfRec> prof;
 
-  ~lemas_dit() {
+  std::vector<DevBuf*> own_bufs() {
+    return {&wproj_out, &bproj_out, &d_tabW, &d_tabB, &wconv[0], &wconv[1], &d_step, &d_dt, &d_cfg, &d_t, &d_tab, &d_rope_cos,
+            &d_rope_sin, &d_len, &d_sin, &d_h1, &d_temb, &d_st, &d_cond_eff, &d_step_cond, &d_pm, &d_pt, &d_te,
+            &d_rowmask, &d_t1, &d_t2, &d_t3, &d_gx, &d_ct, &d_pconst, &d_y, &d_xres, &d_hbf, &d_q, &d_k, &d_vt,
+            &d_abf, &d_ff, &d_cmid, &d_pred, &d_h8, &d_hmx, &d_a8, &d_amx, &d_ff8, &d_ffmx};
+  }
+  static std::vector<DevBuf*> block_bufs(BlockW& b) {
+    return {&b.wqkv, &b.wo, &b.w1, &b.w2, &b.bqkv, &b.wqkv8, &b.wo8, &b.w18, &b.w28, &b.sqkv, &b.so, &b.s1, &b.s2};
+  }
+  void drop_graphs() {
     for (auto& g : graphs) (void)hipGraphExecDestroy(g.second);
+    graphs.clear();
+  }
+  lemas_dit() {
+    for (DevBuf* b : own_bufs()) b->moved = &moved;
+  }
+  lemas_dit(const lemas_dit&) = delete;
+  lemas_dit& operator=(const lemas_dit&) = delete;
+  ~lemas_dit() {
+    (void)hipDeviceSynchronize();   // nothing of this engine may still be running when its graphs and buffers go
+    drop_graphs();
     if (s2) (void)hipStreamDestroy(s2);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
     for (auto& r : prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
-    for (DevBuf* b : {&wproj_out, &bproj_out, &d_tabW, &d_tabB, &wconv[0], &wconv[1], &d_step, &d_dt, &d_cfg, &d_t, &d_tab, &d_rope_cos,
-                      &d_rope_sin, &d_len, &d_sin, &d_h1, &d_temb, &d_st, &d_cond_eff, &d_step_cond, &d_pm, &d_pt, &d_te,
-                      &d_rowmask, &d_t1, &d_t2, &d_t3, &d_gx, &d_ct, &d_pconst, &d_y, &d_xres, &d_hbf, &d_q, &d_k, &d_vt,
-                      &d_abf, &d_ff, &d_cmid, &d_pred, &d_h8, &d_hmx, &d_a8, &d_amx, &d_ff8, &d_ffmx})
-      b->release();
-    for (auto& b : blocks) {
-      for (DevBuf* w : {&b.wqkv, &b.wo, &b.w1, &b.w2, &b.bqkv, &b.wqkv8, &b.wo8, &b.w18, &b.w28, &b.sqkv, &b.so, &b.s1, &b.s2}) w->release();
-    }
+    for (DevBuf* b : own_bufs()) b->release();
+    for (auto& b : blocks)
+      for (DevBuf* w : block_bufs(b)) w->release();
     ws.release();
   }
 
@@ -229,7 +244,15 @@ int lemas_dit::finalize() {
   RC_TRY(ws.check_complete());
   const int d = cfg.dim, in = inner(), ffd = cfg.ff_mult * d;
   hipStream_t s = nullptr;
+  drop_graphs();   // weights may have been reloaded: every cached graph baked the old tensors' addresses
+  prepared = false;
+  tgrid_cached.clear();
+  for (auto& b : blocks)
+    for (DevBuf* w : block_bufs(b)) w->release();
+  blocks.clear();
   blocks.resize(cfg.depth);
+  for (auto& b : blocks)
+    for (DevBuf* w : block_bufs(b)) w->moved = &moved;
   fp8_ready = false;
   for (int i = 0; i < cfg.depth; ++i) {
     const std::string p = T("transformer_blocks." + std::to_string(i) + ".");
@@ -351,7 +374,7 @@ int lemas_dit::text_embed(const lemas_sample_args* a, hipStream_t s) {
   const int td = cfg.text_dim, rows = BB * N, branches = BB / B;
   RC_TRY(d_te.ensure((size_t)rows * td * 4));
   RC_TRY(d_rowmask.ensure((size_t)rows));
-  HIP_TRY(launch_text_gather(a->text, B, Nt, N, td, branches, ws.ptr(T("text_embed.text_embed.weight")),
+  HIP_TRY(launch_text_gather(a->text, B, Nt, N, td, branches, ws.ptr(T("text_embed.text_embed.weight")), cfg.vocab_rows,
                              ws.ptr(T("text_embed.freqs_cis")), 4096, d_te.as<float>(), d_rowmask.as<uint8_t>(), s));
   if (cfg.conv_layers > 0) {
     RC_TRY(d_t1.ensure((size_t)rows * td * 4));
@@ -651,7 +674,7 @@ int lemas_dit::enqueue_update(float* traj, hipStream_t s) {
 }
 
 int lemas_dit::solve(const lemas_sample_args* a, hipStream_t s) {
-  if (!prepared) { set_error("lemas_dit_solve: prepare() has not run"); return LEMAS_E_STATE; }
+  if (!finalized || !prepared) { set_error("lemas_dit_solve: prepare() has not run on the finalized weights"); return LEMAS_E_STATE; }
   if (a->batch != B || a->frames != N || a->steps != S || !a->y) { set_error("lemas_dit_solve: arguments differ from prepare()"); return LEMAS_E_ARG; }
   const size_t ybytes = (size_t)B * N * cfg.mel_dim * 4;
   const size_t yw = (size_t)N * cfg.mel_dim * 4, ypitch = (size_t)pitch * cfg.mel_dim * 4;
@@ -662,19 +685,15 @@ int lemas_dit::solve(const lemas_sample_args* a, hipStream_t s) {
 
   const bool graph_ok = use_graph && !profile && !a->trajectory && s != nullptr;  // the legacy NULL stream cannot be captured
   if (graph_ok) {
-    if (graph_generation != DevBuf::generation) {  // some buffer moved: every captured address is suspect
-      for (auto& g : graphs) (void)hipGraphExecDestroy(g.second);
-      graphs.clear();
-      graph_generation = DevBuf::generation;
+    if (graph_generation != moved) {  // one of THIS engine's buffers moved: every captured address is suspect
+      drop_graphs();
+      graph_generation = moved;
     }
     char key[96];
     snprintf(key, sizeof key, "B%d_N%d_cfg%d_len%d_dual%d_f8%d", B, N, (int)use_cfg, (int)has_len, (int)dual, (int)fp8);
     auto it = graphs.find(key);
     if (it == graphs.end()) {
-      if (graphs.size() >= 32) {   // a serving process sees a new length almost every utterance: bound the cache (a capture costs ~3 ms)
-        for (auto& g : graphs) (void)hipGraphExecDestroy(g.second);
-        graphs.clear();
-      }
+      if (graphs.size() >= 32) drop_graphs();   // a serving process sees a new length almost every utterance: bound the cache (a capture costs ~3 ms)
       hipGraph_t graph = nullptr;
       HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
       int rc = enqueue_forward(s);
@@ -723,7 +742,10 @@ int lemas_dit_load_weight(lemas_dit* m, const char* name, const float* host, con
   if (!m || !name || !host) { set_error("lemas_dit_load_weight: null argument"); return LEMAS_E_ARG; }
   // loaded-but-unused tensors of the reference checkpoint (cfm.py:171 accent classifier) are accepted and dropped
   if (strncmp(name, "accent_classifier.", 18) == 0) return 0;
+  // a (re)loaded tensor lives at a new address: nothing prepared or captured on the old weights may be replayed
   m->finalized = false;
+  m->prepared = false;
+  m->drop_graphs();
   return m->ws.load(name, host, shape, ndim);
 }
 int lemas_dit_finalize(lemas_dit* m) { return m ? m->finalize() : LEMAS_E_ARG; }
@@ -734,14 +756,12 @@ int lemas_dit_set_option(lemas_dit* m, const char* key, int64_t value) {
   if (!strcmp(key, "table_cache")) { m->table_cache = value != 0; return 0; }
   if (!strcmp(key, "dual")) {
     m->dual = value != 0;
-    for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.second);
-    m->graphs.clear();
+    m->drop_graphs();
     return 0;
   }
   if (!strcmp(key, "qkv_fused")) {
     m->qkv_fused = value != 0;
-    for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.second);
-    m->graphs.clear();
+    m->drop_graphs();
     return 0;
   }
   if (!strcmp(key, "fp8")) {      // block GEMMs on the MXFP8 path; takes effect at the next prepare()
@@ -775,7 +795,7 @@ int lemas_dit_sample(lemas_dit* m, const lemas_sample_args* a, void* stream) {
 
 int lemas_dit_forward(lemas_dit* m, const float* x, int32_t step_index, float* pred, void* stream) {
   if (!m || !x || !pred) return LEMAS_E_ARG;
-  if (!m->prepared) { set_error("lemas_dit_forward: prepare() has not run"); return LEMAS_E_STATE; }
+  if (!m->finalized || !m->prepared) { set_error("lemas_dit_forward: prepare() has not run on the finalized weights"); return LEMAS_E_STATE; }
   if (step_index < 0 || step_index >= m->S) { set_error("lemas_dit_forward: step index out of range"); return LEMAS_E_ARG; }
   hipStream_t s = (hipStream_t)stream;
   const size_t w = (size_t)m->N * m->cfg.mel_dim * 4, wp = (size_t)m->pitch * m->cfg.mel_dim * 4;

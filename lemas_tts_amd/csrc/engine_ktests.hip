@@ -19,7 +19,7 @@ struct Scratch {
   T* get(size_t n) {
     void* p = nullptr;
     if (hipMalloc(&p, n * sizeof(T) + 256) != hipSuccess) return nullptr;
-    (void)hipMemset(p, 0, n * sizeof(T) + 256);
+    if (zero_fill_sync(p, n * sizeof(T) + 256) != hipSuccess) { (void)hipFree(p); return nullptr; }
     ptrs.push_back(p);
     return reinterpret_cast<T*>(p);
   }

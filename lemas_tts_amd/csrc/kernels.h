@@ -8,7 +8,7 @@ hipError_t launch_f32_to_bf16(const float* src, bf16_t* dst, size_t n, hipStream
 hipError_t launch_convpos_weight(const float* src, bf16_t* dst, int C, int cg, int taps, hipStream_t s);
 hipError_t launch_select_rows(float* out, const float* a, const float* b_padded, const uint8_t* mask, int B, int N, int pitch, int cols, hipStream_t s);
 
-hipError_t launch_text_gather(const int64_t* text, int B, int Nt, int N, int td, int branches, const float* table,
+hipError_t launch_text_gather(const int64_t* text, int B, int Nt, int N, int td, int branches, const float* table, int vocab_rows,
                               const float* freqs_cis, int max_pos, float* out, uint8_t* rowmask, hipStream_t s);
 hipError_t launch_dwconv7(const float* x, const float* w, const float* bias, float* out, int B, int N, int C, hipStream_t s);
 hipError_t launch_ln_affine(const float* x, const float* w, const float* b, float* out, int M, int D, hipStream_t s);

@@ -301,6 +301,19 @@ class ResampleEngine(_Streamed):
         return out
 
 
+_RESAMPLERS: dict = {}
+
+
+def resampler(orig_freq: int, new_freq: int = 24000, device="cuda:0") -> "ResampleEngine":
+    """One ResampleEngine per (orig, new, device): building one costs a fp64 kernel bank on the host, a hipMalloc and an
+    H2D copy, which does not belong on the per-utterance latency path."""
+    key = (int(orig_freq), int(new_freq), str(torch.device(device)))
+    eng = _RESAMPLERS.get(key)
+    if eng is None:
+        eng = _RESAMPLERS[key] = ResampleEngine(orig_freq, new_freq, device=device)
+    return eng
+
+
 class ProsodyEngine(_Streamed):
     """Owns one ``lemas_prosody`` (ECAPA-TDNN weights + workspaces + the kaldi-fbank constants) on one device."""
 

@@ -8,7 +8,7 @@ Differences that are stated rather than hidden:
 * compute dtype: the reference picks fp16 on "cuda" (:205-213); this build uses bf16 MFMA operands with fp32
   accumulation / residual stream / ODE state (BASELINE.json), whatever ``dtype`` says;
 * reference audio arrives as a ``(tensor[channels, samples], sample_rate)`` pair (what ``torchaudio.load`` returns
-  at :422; 24 kHz only, resampling is not built) or as a ready mel ``[F, 100]``;
+  at :422; any sample rate: it is resampled to 24 kHz on the device, :494-496) or as a ready mel ``[F, 100]``;
 * ``ref_text`` / ``gen_text`` are phone-token lists (the text frontend stays host Python and is out of scope);
   the ``str`` branch (:509-515) needs ``convert_char_to_pinyin`` and raises ``NotImplementedError``.
 """
@@ -138,9 +138,20 @@ def load_model(model_cls, model_cfg, ckpt_path, mel_spec_type=mel_spec_type, voc
         vocab_size = len(vocab_char_map)
     args = dict(arch=arch, vocab_size=vocab_size, vocab_char_map=vocab_char_map, use_prosody_encoder=use_prosody_encoder,
                 num_channels=n_mel_channels, odeint_kwargs=dict(method=ode_method))
-    if use_prosody_encoder and prosody_ckpt_path:                      # cfm.py:139-145: the Pretssel ECAPA encoder next to the CFM
-        from ..model.prosody_encoder import ProsodyEncoder
-        args["prosody_encoder"] = ProsodyEncoder(prosody_cfg_path or None, prosody_ckpt_path, device=_cuda(device))
+    if use_prosody_encoder:                                            # cfm.py:139-145: the Pretssel ECAPA encoder next to the CFM
+        from ..api import CKPTS_ROOT
+        if not prosody_cfg_path:                                       # :276-280: default assets under CKPTS_ROOT/prosody_encoder
+            prosody_cfg_path = str(CKPTS_ROOT / "prosody_encoder" / "pretssel_cfg.json")
+        if not prosody_ckpt_path:
+            prosody_ckpt_path = str(CKPTS_ROOT / "prosody_encoder" / "prosody_encoder_UnitY2.pt")
+        have = os.path.exists(prosody_cfg_path) and os.path.exists(prosody_ckpt_path)
+        if have:
+            from ..model.prosody_encoder import ProsodyEncoder
+            args["prosody_encoder"] = ProsodyEncoder(prosody_cfg_path, prosody_ckpt_path, device=_cuda(device))
+        elif state_dict is None:
+            # a real checkpoint load: the reference would fail opening these files (prosody_encoder.py:390-424)
+            raise FileNotFoundError(f"use_prosody_encoder needs {prosody_cfg_path} and {prosody_ckpt_path}")
+        # synthetic-weights bypass without encoder assets: CFM.sample then requires explicit prosody_embeds for raw audio
     if state_dict is not None:
         return CFM(state_dict=state_dict, device=_cuda(device), **args)
     return load_checkpoint(args, ckpt_path, device, use_ema=use_ema)
@@ -209,8 +220,8 @@ def infer_batch_process(ref_audio, ref_text, gen_text_batches, model_obj, vocode
         if rms < target_rms:
             audio = audio * target_rms / rms                                    # :492-493
         if sr != target_sample_rate:                                            # :494-496
-            from ..engine import ResampleEngine
-            audio = ResampleEngine(int(sr), target_sample_rate, device=getattr(model_obj, "device", device) or "cuda:0")(audio).cpu()
+            from ..engine import resampler
+            audio = resampler(int(sr), target_sample_rate, device=getattr(model_obj, "device", device) or "cuda:0")(audio).cpu()
         cond = audio
         ref_audio_len = audio.shape[-1] // hop_length                           # :520
     else:

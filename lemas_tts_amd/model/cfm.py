@@ -125,7 +125,12 @@ class CFM:
         dev = self.device
         if cond.ndim == 2:
             raw_audio = cond
-            if prosody_embeds is None and self.prosody_encoder is not None and use_prosody_encoder and self.use_prosody_encoder:
+            if prosody_embeds is None and use_prosody_encoder and self.use_prosody_encoder:
+                if self.prosody_encoder is None:
+                    # the reference's model always owns its encoder when built with use_prosody_encoder (cfm.py:139-145, default
+                    # assets utils_infer.py:276-280): skipping the conditioning here would diverge from it without a word
+                    raise RuntimeError("use_prosody_encoder is set and raw audio was given, but this model has no prosody encoder "
+                                       "(pass prosody_ckpt_path to load_model, or prosody_embeds=...)")
                 prosody_embeds = self.prosody_encoder.embed_prompt(raw_audio, self.mel_spec.target_sample_rate)   # cfm.py:248-262
             cond = self.mel_spec(cond).permute(0, 2, 1)              # cfm.py:232-236
         assert cond.shape[-1] == self.num_channels
@@ -148,6 +153,9 @@ class CFM:
             text = list_str_to_idx(text, self.vocab_char_map) if self.vocab_char_map is not None else list_str_to_tensor(text)
             assert text.shape[0] == batch
         text = text.to("cpu", torch.long)
+        if text.numel() and (int(text.min()) < -1 or int(text.max()) >= self.engine.vocab_size):
+            # nn.Embedding(vocab + 1, ...) on text + 1 (dit.py:37,53-61) raises for these ids
+            raise IndexError("index out of range in self")
 
         cond_mask = lens_to_mask(lens)
         if edit_mask is not None:

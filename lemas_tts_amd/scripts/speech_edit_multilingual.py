@@ -2,7 +2,7 @@
 SURVEY.md 3.2 / 8a row a-E): same function names, arguments, defaults and return values; the sampler and the vocoder
 behind it are the MI355X engines, the wav files go through ``infer/audio_io.py`` (no torchaudio / soundfile here) and the
 prompt resampling through the HIP polyphase resampler.  The text frontend stays host Python (north_star): ``--frontend
-phone|char`` builds the reference's own ``TextNorm`` when it is importable, ``--frontend none`` feeds characters.
+phone|char`` asks the factory registered with ``lemas_tts_amd.api.set_frontend_factory``, ``--frontend none`` feeds characters.
 
     python -m lemas_tts_amd.scripts.speech_edit_multilingual --wav_dir in/ --align_dir align/ --save_dir out/ --ckpt_file ... --vocab_file ...
 """
@@ -26,8 +26,8 @@ def load_wav_mono(path: str, target_sr: int, device="cuda:0") -> Tuple[torch.Ten
     if wav.dim() > 1 and wav.shape[0] > 1:
         wav = wav.mean(dim=0, keepdim=True)
     if sr != target_sr:
-        from ..engine import ResampleEngine
-        wav = ResampleEngine(int(sr), int(target_sr), device=device)(wav).cpu()
+        from ..engine import resampler
+        wav = resampler(int(sr), int(target_sr), device=device)(wav).cpu()
         sr = target_sr
     return torch.clip(wav, -0.999, 0.999).squeeze(0), sr
 
@@ -97,8 +97,8 @@ def gen_wav_multilingual(tts, segment_audio: torch.Tensor, sr: int, target_text,
     if rms < target_rms:
         audio = audio * target_rms / rms
     if sr != target_sr:                                                       # :118-120
-        from ..engine import ResampleEngine
-        audio = ResampleEngine(int(sr), target_sr, device=model.device)(audio).cpu()
+        from ..engine import resampler
+        audio = resampler(int(sr), target_sr, device=model.device)(audio).cpu()
     edit_mask = build_edit_mask(parts_to_edit, audio.shape[-1], target_sr, hop)
     duration = audio.shape[-1] // hop                                         # :161 (the sampler raises it to frames + 1)
     tokens = [list(target_text)] if isinstance(target_text, (list, tuple)) else build_tokens_from_text(tts, target_text)

@@ -11,7 +11,7 @@ What differs from the reference script, and why:
   beforehand and pass the result as ``--ref_audio``.
 * there is no CPU retry (``:332-336``): this build has no CPU path, a missing GPU is an error;
 * checkpoints resolve locally only (``:89-119`` falls back to a Hugging Face download; no network here);
-* the text frontend is the reference's own host-side ``TextNorm`` when it is importable; ``--ref_phones`` / ``--phones``
+* the text frontend comes from the factory registered with ``lemas_tts_amd.api.set_frontend_factory``; ``--ref_phones`` / ``--phones``
   (an extension) take text that is ALREADY phonemised -- ``p1|p2|...``, one generated line per ``\\n`` -- and skip the
   frontend, which is how the entry point is exercised on a box without espeak.
 """

@@ -74,12 +74,25 @@ def test_cli_writes_the_wave_tts_infer_returns(tmp_path, monkeypatch):
     np.testing.assert_array_equal(wav, wav2)
 
 
-def test_string_frontend_needs_the_reference_frontend(tmp_path, monkeypatch):
-    """api.py:140-151 builds TextNorm(dtype=frontend); that host-side package is not part of this tree: loud ImportError."""
+def test_string_frontend_needs_a_registered_factory(tmp_path, monkeypatch):
+    """api.py:140-151 builds TextNorm(dtype=frontend) from the reference's frontend package; the product does not import that
+    package: a string frontend asks the registered factory, and without one it is a loud TypeError."""
     import lemas_tts_amd.api as A
     real_cfg = A.load_arch_config
     monkeypatch.setattr(A, "load_arch_config", lambda m: {**real_cfg(m), "arch": {**real_cfg(m)["arch"], "depth": 1}})
     vocab = {f"p{i}": i for i in range(40)}
-    with pytest.raises(ImportError, match="TextNorm"):
-        A.TTS(model="multilingual_grl", device="cuda:0", state_dict=synth.synth_cfm_state_dict(DiTArch(depth=1), 40, 5),
+    kw = dict(model="multilingual_grl", device="cuda:0", state_dict=synth.synth_cfm_state_dict(DiTArch(depth=1), 40, 5),
               vocoder_state_dict=synth.synth_vocos_state_dict(6), vocab_char_map=vocab, frontend="phone")
+    monkeypatch.setattr(A, "FRONTEND_FACTORY", None)
+    with pytest.raises(TypeError, match="set_frontend_factory"):
+        A.TTS(**kw)
+
+    class _FE:
+        def __init__(self, dtype):
+            self.dtype = dtype
+    A.set_frontend_factory(_FE)
+    try:
+        tts = A.TTS(**kw)
+        assert isinstance(tts.frontend, _FE) and tts.frontend.dtype == "phone"
+    finally:
+        A.set_frontend_factory(None)
