@@ -17,7 +17,8 @@
  *   lemas_resample_create/forward           <- torchaudio Resample call, lemas_tts/infer/utils_infer.py:494-496
  *   lemas_prosody_*                         <- lemas_tts/model/backbones/prosody_encoder.py ProsodyEncoder / extract_fbank_16k,
  *                                              called per sample at lemas_tts/model/cfm.py:248-262
- *   lemas_k_*                               <- single-kernel entry points used by the parity tests
+ * Single-kernel entry points for the parity tests and micro-benchmarks (lemas_k_*) are declared in lemas_hip_test.h; they
+ * are exported by the same library but are not part of the drop-in surface.
  *
  * Conventions: plain pointers and sizes only.  "device" pointers are HIP device addresses on the current device
  * (e.g. torch.Tensor.data_ptr()); "host" pointers are ordinary memory.  `stream` is a hipStream_t passed as void*
@@ -134,15 +135,6 @@ void lemas_resample_destroy(lemas_resample* r);
 int64_t lemas_resample_out_len(const lemas_resample* r, int64_t samples);   /* ceil(new * samples / orig) */
 int lemas_resample_forward(lemas_resample* r, const float* wav, int32_t batch, int32_t samples, float* out, void* stream);
 
-/* ---- single-kernel entry points (parity tests) ---- all pointers device fp32 unless noted */
-/* out[M,N] = act(A[M,K] . W[N,K]^T + bias) through the bf16 MFMA GEMM (inputs rounded to bf16); act: 0 none, 1 gelu-tanh.
- * K % 64 == 0; N % 4 == 0 (act 0) / N % 8 == 0 (act 1): the epilogues store whole 16-byte chunks; anything else is refused. */
-int lemas_k_linear_bf16(const float* A, const float* W, const float* bias, float* out, int32_t M, int32_t N, int32_t K,
-                        int32_t act, void* stream);
-/* out[M,N] = A . W^T + bias through the exact-fp32 MFMA GEMM; act: 0 none, 1 gelu-erf, 2 silu */
-int lemas_k_linear_f32(const float* A, const float* W, const float* bias, float* out, int32_t M, int32_t N, int32_t K,
-                       int32_t act, void* stream);
-/* q,k,v [B,H,N,64] (already rotated) -> out [B,N,H*64]; seq_len device int32 [B] or NULL */
 /* ---- prosody encoder (ECAPA-TDNN), the prompt's global prosody embedding ----
  * Architecture numbers = the reference's pretssel_cfg.json "model.prosody_*" keys (prosody_encoder.py:390-403). */
 typedef struct lemas_prosody_config {
@@ -163,36 +155,6 @@ int64_t lemas_prosody_fbank_frames(int64_t samples_16k);      /* 1 + (samples - 
 int lemas_prosody_fbank(lemas_prosody* p, const float* wav16k, int32_t samples, float* fbank, void* stream);
 /* one sample, padding_mask=None (how cfm.py:259 calls it): fbank device [frames, input_dim] -> emb device [embed_dim], L2-normalised */
 int lemas_prosody_encode(lemas_prosody* p, const float* fbank, int32_t frames, float* emb, void* stream);
-
-/* fp8 (MXFP8) path of the GEMMs -- BASELINE config 5 "fp8 MFMA weights".  Activations: e4m3 bytes + one E8M0 scale per
- * 32 consecutive K (OCP MX); weights: e4m3 + one fp32 scale per output channel.  All pointers device. */
-int lemas_k_mx_quant(const float* x, int32_t M, int32_t K, uint8_t* out8, uint8_t* mx, void* stream);
-int lemas_k_w_quant_f8(const float* w, int32_t N, int32_t K, uint8_t* out8, float* scale, void* stream);
-int lemas_k_ln_mod_f8(const float* x, const float* scale, const float* shift, uint8_t* out8, uint8_t* mx, int32_t M, int32_t D,
-                      void* stream);
-/* out = act(MXFP8(A) . FP8(W)^T + bias); act 0 none (fp32 out), 1 GELU-tanh (bf16-rounded out), 2 GELU-tanh written as
- * MXFP8 into out8 [M,N] / outmx [M,N/32] (out unused) */
-int lemas_k_linear_f8(const float* A, const float* W, const float* bias, float* out, int32_t M, int32_t N, int32_t K, int32_t act,
-                      uint8_t* out8, uint8_t* outmx, void* stream);
-int lemas_k_attention(const float* q, const float* k, const float* v, const int32_t* seq_len, float* out, int32_t B,
-                      int32_t H, int32_t N, void* stream);
-/* selects the attention kernel used by lemas_k_attention: 0 auto (by grid size), 1 four-wave, 2 split-KV eight-wave */
-int lemas_k_set_attention_variant(int32_t variant);
-/* out = LayerNorm(x; eps 1e-6) * (1 + scale) + shift, rows of 1024; result rounded to bf16 then widened */
-int lemas_k_ln_mod(const float* x, const float* scale, const float* shift, float* out, int32_t M, int32_t D, void* stream);
-/* out = conv_pos_embed(x) + x for x [B,N,C]; w1,w2 [C, C/groups, taps], b1,b2 [C] */
-int lemas_k_convpos(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* out,
-                    int32_t B, int32_t N, int32_t C, int32_t groups, int32_t taps, void* stream);
-
-/* micro-benchmark of one step-loop kernel on synthetic operands: what = "gemm_gelu" | "gemm_gate" | "gemm_qk" | "gemm_v" |
- * "gemm_f32out" (M,N,K = GEMM shape) or "attention" (M = frames, N = batch*heads); returns the average launch
- * duration in microseconds over `iters` back-to-back launches (HIP events).  `variant` selects a kernel variant
- * (0 = production choice). */
-int lemas_k_bench(const char* what, int32_t M, int32_t N, int32_t K, int32_t iters, int32_t variant, double* avg_us);
-
-/* development experiment: one lane's attention beside the other lane's five GEMMs, serial (mode 0) or on two streams
- * (mode 1); returns microseconds per group */
-int lemas_k_bench_overlap(int32_t mode, int32_t iters, int32_t gemm_variant_wide, int32_t gemm_variant_narrow, double* avg_us);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,65 @@
+/* liblemas_hip.so -- test and measurement entry points (lemas_k_*).
+ *
+ * NOT part of the drop-in surface (include/lemas_hip.h): thin drivers that feed fp32 device arrays through ONE production
+ * kernel so that the parity tests can localise a failure, plus a micro-benchmark.  They allocate scratch with hipMalloc
+ * and synchronise the stream before returning.  Conventions as in lemas_hip.h: all pointers are device fp32 unless noted,
+ * `stream` is a hipStream_t, return 0 or a negative code.
+ */
+#ifndef LEMAS_HIP_TEST_H
+#define LEMAS_HIP_TEST_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- single-kernel entry points (parity tests) ---- all pointers device fp32 unless noted */
+/* out[M,N] = act(A[M,K] . W[N,K]^T + bias) through the bf16 MFMA GEMM (inputs rounded to bf16); act: 0 none, 1 gelu-tanh.
+ * K % 64 == 0; N % 4 == 0 (act 0) / N % 8 == 0 (act 1): the epilogues store whole 16-byte chunks; anything else is refused. */
+int lemas_k_linear_bf16(const float* A, const float* W, const float* bias, float* out, int32_t M, int32_t N, int32_t K,
+                        int32_t act, void* stream);
+/* out[M,N] = A . W^T + bias through the exact-fp32 MFMA GEMM; act: 0 none, 1 gelu-erf, 2 silu */
+int lemas_k_linear_f32(const float* A, const float* W, const float* bias, float* out, int32_t M, int32_t N, int32_t K,
+                       int32_t act, void* stream);
+/* fp8 (MXFP8) path of the GEMMs -- BASELINE config 5 "fp8 MFMA weights".  Activations: e4m3 bytes + one E8M0 scale per
+ * 32 consecutive K (OCP MX); weights: e4m3 + one fp32 scale per output channel.  All pointers device. */
+int lemas_k_mx_quant(const float* x, int32_t M, int32_t K, uint8_t* out8, uint8_t* mx, void* stream);
+int lemas_k_w_quant_f8(const float* w, int32_t N, int32_t K, uint8_t* out8, float* scale, void* stream);
+int lemas_k_ln_mod_f8(const float* x, const float* scale, const float* shift, uint8_t* out8, uint8_t* mx, int32_t M, int32_t D,
+                      void* stream);
+/* out = act(MXFP8(A) . FP8(W)^T + bias); act 0 none (fp32 out), 1 GELU-tanh (bf16-rounded out), 2 GELU-tanh written as
+ * MXFP8 into out8 [M,N] / outmx [M,N/32] (out unused) */
+int lemas_k_linear_f8(const float* A, const float* W, const float* bias, float* out, int32_t M, int32_t N, int32_t K, int32_t act,
+                      uint8_t* out8, uint8_t* outmx, void* stream);
+/* q,k,v [B,H,N,64] (already rotated) -> out [B,N,H*64]; seq_len device int32 [B] or NULL (modules.py:483-491) */
+int lemas_k_attention(const float* q, const float* k, const float* v, const int32_t* seq_len, float* out, int32_t B,
+                      int32_t H, int32_t N, void* stream);
+/* out = LayerNorm(x; eps 1e-6) * (1 + scale) + shift, rows of 1024; result rounded to bf16 then widened */
+int lemas_k_ln_mod(const float* x, const float* scale, const float* shift, float* out, int32_t M, int32_t D, void* stream);
+/* out = conv_pos_embed(x) + x for x [B,N,C]; w1,w2 [C, C/groups, taps], b1,b2 [C] */
+int lemas_k_convpos(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* out,
+                    int32_t B, int32_t N, int32_t C, int32_t groups, int32_t taps, void* stream);
+
+/* one production bf16 GEMM launch with an explicit tile and epilogue in the engine's row space: rows = batch x pitch
+ * (pitch % 128 == 0), `frames` valid rows per sample.  A [batch*pitch, K], W [N, K], bias [N] fp32 (rounded to bf16 inside).
+ *   tile: 0 production choice | 16 = 256x128 | 17 = 128x128 | 18 = 128x64 | 22 = 256x256
+ *   epi 0: out[M,N] = bf16(acc + bias)        1: out = bf16(gelu_tanh(acc + bias))       2: out = acc + bias (fp32)
+ *   epi 3: out[M,N] += aux[n] * (acc + bias) for rows with pos < frames (and pos < seq_len[b] when given); aux = gate [N]
+ *   epi 4: N = 2*H*64: +bias, RoPE with aux = [cos | sin] ([frames][32] each) -> out = q then k, each [batch][H][pitch][64]
+ *   epi 5: N = H*64:   +bias -> out = v^T [batch][H][64][pitch]
+ * (modules.py:452-461,470-480,495,635,349-350) */
+int lemas_k_gemm_epi(int32_t epi, int32_t tile, const float* A, const float* W, const float* bias, const float* aux,
+                     const int32_t* seq_len, float* out, int32_t batch, int32_t pitch, int32_t frames, int32_t N, int32_t K, void* stream);
+
+/* micro-benchmark of one step-loop kernel on synthetic operands: what = "gemm_gelu" | "gemm_gate" | "gemm_qk" | "gemm_v" |
+ * "gemm_f32out" (M,N,K = GEMM shape; prefix "f8_" for the MXFP8 path) or "attention" (M = frames, N = batch*heads); returns
+ * the average launch duration in microseconds over `iters` back-to-back launches (HIP events).  `variant` = GEMM tile as
+ * in lemas_k_gemm_epi (0 = production choice). */
+int lemas_k_bench(const char* what, int32_t M, int32_t N, int32_t K, int32_t iters, int32_t variant, double* avg_us);
+
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LEMAS_HIP_TEST_H */

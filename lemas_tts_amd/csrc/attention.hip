@@ -8,9 +8,9 @@
 // row pitch of the activation row space (a multiple of 128).  Rows / columns past N inside the pitch hold finite
 // stale values and are masked, so tiles are loaded without clamping.
 //
-// Work split: one workgroup = 128 queries of one (batch, head) = 4 waves x 32 queries.  K and V^T tiles of 64 keys
-// stream L2 -> LDS by LDS-DMA (global_load_lds_dwordx4, wave-uniform base + per-lane 32-bit offset) into a 4-stage
-// ring: one s_barrier per tile, counted s_waitcnt vmcnt keeps the tile after next in flight across the barrier.
+// Work split: one workgroup = 128 queries of one (batch, head), 8 waves = 2 key-parity groups x 4 query sub-blocks of 32
+// (see the kernel).  K and V^T tiles of 64 keys stream L2 -> LDS by LDS-DMA (global_load_lds_dwordx4, wave-uniform base +
+// per-lane 32-bit offset) into a 2-stage ring of tile PAIRS: one s_barrier per pair.
 //
 // Both matmuls are computed TRANSPOSED so that everything the softmax needs is lane-local:
 //   S^T[key, q] = K . Q^T   (A = K rows from LDS, B = Q fragment held in registers)
@@ -23,11 +23,9 @@
 // leaves registers and V^T is read with one ds_read_b128 per MFMA.
 //
 // This kernel is VALU-bound, not MFMA-bound (PMC: at head_dim 64 the softmax costs 2x the matrix-pipe time), so the
-// structure minimises VALU instructions per key: the tile loop is unrolled by the ring depth (every LDS address is
-// base register + immediate, no per-tile address arithmetic), S^T ping-pongs between two register sets (no copies),
-// the exponent argument and the row sum use packed fp32 math (v_pk_fma_f32 / v_pk_add_f32), v_exp_f32 is issued
-// directly, and the O rescale is skipped whenever no query of the wave raised its running max (alpha == 1 exactly).
-// S^T of tile j+1 is issued to the matrix pipe BEFORE the softmax of tile j so the two pipes overlap inside a wave.
+// structure minimises VALU instructions per key: the pair loop is unrolled by the ring depth (every LDS address is base
+// register + immediate), the exponent argument and the row sum use packed fp32 math (v_pk_fma_f32 / v_pk_add_f32),
+// v_exp_f32 is issued directly, and l / O are only rescaled when some query's running max grew by more than 2^8.
 #include <type_traits>
 
 #include "common.h"
@@ -39,9 +37,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int QB = 128;            // queries per workgroup
 constexpr int KB = 64;             // keys per tile
 constexpr int TILE = KB * 64 * 2;  // 8 KiB per operand tile
-constexpr int STAGE = 2 * TILE;    // K | V^T
-constexpr int NST = 4;             // ring depth
-constexpr int PW = 4;              // DMA pieces per wave per tile (2 K + 2 V^T)
 
 // XCD-aware block order: workgroups are dispatched round-robin over the 8 XCDs (private L2s).  Consecutive LOGICAL ids
 // are mapped onto one XCD so that all query blocks of a (batch, head) share that XCD's L2 copy of K and V^T; with the
@@ -74,227 +69,10 @@ __device__ __forceinline__ void wait_lgkm_frags(u32x4& a, u32x4& b) {
   asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
 }
 
-struct Ctx {
-  char* smem;
-  const char* kg;   // K of this (b, h), bytes
-  const char* vg;   // V^T of this (b, h), bytes
-  unsigned koff[2], voff[2];   // per-lane DMA source offsets (bytes) of this wave's two K / two V^T pieces
-  int kbase, vbase;            // per-lane LDS byte offsets of the A-operand rows (swizzle folded in), stage 0
-  int kx[4], vx[4];            // per-lane swizzled chunk offsets for the 4 k-steps of S^T / the 4 (t, ss) steps of PV
-  int wave, hi;
-  int kvlen, ntiles;
-  float c;
-};
-
-__device__ __forceinline__ void issue_tile(const Ctx& x, int stage, int j) {
-  char* base = x.smem + stage * STAGE + x.wave * 1024;
-  const char* kt = x.kg + (size_t)j * (KB * 64 * 2);
-  const char* vt = x.vg + (size_t)j * (KB * 2);
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kt + x.koff[i]),
-                                     (__attribute__((address_space(3))) void*)(base + i * 4096), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vt + x.voff[i]),
-                                     (__attribute__((address_space(3))) void*)(base + TILE + i * 4096), 16, 0, 0);
-  }
-}
-
-template <int ST>
-__device__ __forceinline__ void qk_tile(const Ctx& x, const bf16x8 (&qf)[4], f32x16 (&s)[2]) {
-  const char* sK = x.smem + ST * STAGE + x.kbase;
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
-  // the two 32-key sub-tiles are independent accumulators: alternate them so no MFMA waits on its predecessor
-#pragma unroll
-  for (int kk = 0; kk < 4; ++kk) {
-    bf16x8 a[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) a[t] = *reinterpret_cast<const bf16x8*>(sK + t * 4096 + x.kx[kk]);
-#pragma unroll
-    for (int t = 0; t < 2; ++t) s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t], qf[kk], s[t], 0, 0, 0);
-  }
-}
-
-// softmax of tile j held in `s`, then O^T += V^T . P^T from ring stage ST
-template <int ST>
-__device__ __forceinline__ void softmax_pv(const Ctx& x, int j, f32x16 (&s)[2], f32x16 (&o)[2], float& m_run, float& l_run) {
-  // lane's register r of sub-tile t is key  j*64 + 32 t + 16 (r>>3) + 8 hi + (r&7)
-  if ((j + 1) * KB > x.kvlen) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = j * KB + 32 * t + 16 * (r >> 3) + 8 * x.hi + (r & 7);
-        if (key >= x.kvlen) s[t][r] = -INFINITY;
-      }
-  }
-  float mx = s[0][0];
-#pragma unroll
-  for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
-  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));   // partner lane holds the other 32 keys of the tile
-  const float m_new = fmaxf(m_run, mx * x.c);
-  // v_exp_f32 directly: exp2f() wraps it in a 6-instruction denormal-range fix-up softmax does not need
-  const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // first tile: exp2(-inf) = 0
-  const bool grew = m_new > m_run;
-  m_run = m_new;
-  const f32x2 c2 = {x.c, x.c}, m2 = {m_new, m_new};
-  f32x2 ps = {0.f, 0.f};
-  bf16x8 pb[2][2];
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; r += 2) {
-      f32x2 e = {s[t][r], s[t][r + 1]};
-      e = e * c2 - m2;                                  // v_pk_fma_f32
-      f32x2 pv = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
-      ps += pv;                                         // v_pk_add_f32
-      pb[t][r >> 3][r & 7] = (bf16_t)pv[0];
-      pb[t][r >> 3][(r & 7) + 1] = (bf16_t)pv[1];
-    }
-  l_run = l_run * alpha + (ps[0] + ps[1]);
-  if (__any(grew)) {   // wave-uniform: when no query of this wave raised its running max, alpha == 1 exactly
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
-  }
-  const char* sV = x.smem + ST * STAGE + TILE + x.vbase;
-  __builtin_amdgcn_s_setprio(1);
-  // the two 32-row halves of O^T are independent accumulators: alternate them (no back-to-back dependent MFMAs)
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int ss = 0; ss < 2; ++ss) {
-      bf16x8 a[2];
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt) a[dt] = *reinterpret_cast<const bf16x8*>(sV + dt * 4096 + x.vx[t * 2 + ss]);
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[dt], pb[t][ss], o[dt], 0, 0, 0);
-    }
-  __builtin_amdgcn_s_setprio(0);
-}
-
-// one ring position of the 4x-unrolled tile loop: tile j lives in stage ST, its S^T in `s_cur`; S^T of tile j+1 goes
-// to `s_nxt` (stage ST+1) before the softmax of tile j
-template <int ST>
-__device__ __forceinline__ void step(const Ctx& x, int j, const bf16x8 (&qf)[4], f32x16 (&s_cur)[2], f32x16 (&s_nxt)[2],
-                                     f32x16 (&o)[2], float& m_run, float& l_run) {
-  // tile j+1 must have landed; tile j+2 may stay in flight across the barrier
-  if (j + 2 < x.ntiles) wait_vmcnt<PW>();
-  else wait_vmcnt<0>();
-  __builtin_amdgcn_s_barrier();
-  // all waves are past tile j-1: its stage (ST+3 mod 4) is free for tile j+3
-  if (j + NST - 1 < x.ntiles) issue_tile(x, (ST + NST - 1) % NST, j + NST - 1);
-  if (j + 1 < x.ntiles) qk_tile<(ST + 1) % NST>(x, qf, s_nxt);
-  softmax_pv<ST>(x, j, s_cur, o, m_run, l_run);
-}
-
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
-  __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int l31 = lane & 31, hi = lane >> 5;
-  const int nqb = (p.n + QB - 1) / QB;
-  const int lid = xcd_block_id();
-  const int bh = lid / nqb, qblk = lid - bh * nqb;
-  const int b2 = bh / p.heads, h = bh - b2 * p.heads;
-  const int N = p.n;
-
-  Ctx x;
-  x.smem = smem;
-  x.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  x.hi = hi;
-  x.kvlen = p.kv_len ? p.kv_len[b2 % p.batch] : N;
-  x.ntiles = (x.kvlen + KB - 1) / KB;
-  x.c = p.scale * 1.4426950408889634f;  // softmax in base 2
-  x.kg = reinterpret_cast<const char*>(p.k + (size_t)bh * p.pitch * 64);
-  x.vg = reinterpret_cast<const char*>(p.vt + (size_t)bh * 64 * p.npad);
-  const int q_base = qblk * QB + x.wave * 32;
-
-  // DMA: a tile is 8 + 8 one-KiB pieces (8 rows of 128 B each); wave w owns pieces {w, w+4} of K and of V^T.
-  // lane -> (row, physical chunk); the swizzle sits in the SOURCE address (the LDS image is lane-linear).
-  {
-    const int lr = lane >> 3, lp = lane & 7;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = 8 * (x.wave + 4 * i) + lr;
-      const int c = (lp ^ ((r >> 1) & 7)) << 3;   // elements
-      x.koff[i] = (unsigned)((r * 64 + c) * 2);
-      x.voff[i] = (unsigned)((r * p.npad + c) * 2);
-    }
-  }
-  // A-operand rows: S^T reads K row kappa(l31) (bits 2,3 of the MFMA row index swapped), PV reads V^T row l31 (= d).
-  // lds_off(row, chunk) = row*128 + ((chunk ^ ((row>>1)&7)) << 4); +32 rows leaves the swizzle unchanged (+4096 B).
-  {
-    const int krow = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
-    x.kbase = krow * 128;
-    x.vbase = l31 * 128;
-    const int ksw = (krow >> 1) & 7, vsw = (l31 >> 1) & 7;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) x.kx[kk] = ((kk * 2 + hi) ^ ksw) << 4;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) x.vx[e] = ((2 * e + hi) ^ vsw) << 4;   // chunk = 4 t + 2 ss + hi, e = 2 t + ss
-  }
-
-  // Q fragment (B operand of S^T = K.Q^T): lane (q = l31, hi) holds Q[q][kk*16 + hi*8 .. +7]
-  bf16x8 qf[4];
-  {
-    const bf16_t* Qg = p.q + (size_t)bh * p.pitch * 64;
-    int qrow = q_base + l31;
-    qrow = qrow < N ? qrow : N - 1;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
-      qf[kk] = *reinterpret_cast<const bf16x8*>(Qg + (size_t)qrow * 64 + kk * 16 + hi * 8);
-  }
-
-  f32x16 o[2];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
-  float m_run = -INFINITY, l_run = 0.f;
-
-  // prologue: tiles 0..2 in flight, S^T of tile 0 computed
-#pragma unroll
-  for (int s = 0; s < NST - 1; ++s)
-    if (s < x.ntiles) issue_tile(x, s, s);
-  if (x.ntiles > 2) wait_vmcnt<2 * PW>();
-  else if (x.ntiles > 1) wait_vmcnt<PW>();
-  else wait_vmcnt<0>();
-  __builtin_amdgcn_s_barrier();
-  f32x16 sa[2], sb[2];
-  qk_tile<0>(x, qf, sa);
-
-  for (int j = 0; j < x.ntiles; j += NST) {
-    step<0>(x, j, qf, sa, sb, o, m_run, l_run);
-    if (j + 1 < x.ntiles) step<1>(x, j + 1, qf, sb, sa, o, m_run, l_run);
-    if (j + 2 < x.ntiles) step<2>(x, j + 2, qf, sa, sb, o, m_run, l_run);
-    if (j + 3 < x.ntiles) step<3>(x, j + 3, qf, sb, sa, o, m_run, l_run);
-  }
-
-  // ---- normalise and store: lane owns query q_base + l31; rows of O^T are d = 32 dt + (r&3) + 8 (r>>2) + 4 hi
-  const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32, 64));
-  const int q = q_base + l31;
-  if (q < N) {
-    bf16_t* dst = p.out + ((size_t)b2 * p.pitch + q) * (p.heads * 64) + h * 64;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        bf16x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(o[dt][g * 4 + e] * inv);
-        *reinterpret_cast<bf16x4*>(dst + dt * 32 + 8 * g + 4 * hi) = v;
-      }
-  }
-}
-
-
-// ================================================================================================================
-// Split-KV variant for small problems (B = 1: only ~7 waves of work per CU).  A workgroup still owns 128 queries but
-// runs 8 waves: waves 0-3 take the even key tiles, waves 4-7 the odd ones (same queries), and the two partial results
-// (m, l, O^T) are merged through LDS at the end.  Twice the waves per SIMD (4 instead of 2, <= 128 VGPRs each) hide the
-// long per-tile dependency chain (LDS read -> MFMA -> row max -> exchange -> exp -> MFMA) that bounds the 4-wave kernel.
+// Split-KV: a workgroup owns 128 queries of one (batch, head) and runs 8 waves: waves 0-3 take the even key tiles, waves
+// 4-7 the odd ones (same queries), and the two partial results (m, l, O^T) are merged through LDS at the end.  Four waves
+// per SIMD (<= 128 VGPRs each) hide the long per-tile dependency chain (LDS read -> MFMA -> row max -> exchange -> exp ->
+// MFMA); a 4-wave one-group kernel measured slower at every size (B=1: 53 vs 47 us; BH=256: 154 vs 136 us) and was removed.
 // Ring: 2 stages of [K0 | V0^T | K1 | V1^T] (32 KiB each), one barrier per tile pair.
 constexpr int STAGE2 = 4 * TILE;
 
@@ -365,7 +143,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     constexpr int SG = decltype(stage_c)::value;
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
-    if (i + 1 < nsup && !(p.variant == 3 && i > 0)) issue(SG ^ 1, i + 1);   // variant 3: timing experiment without DMA
+    if (i + 1 < nsup) issue(SG ^ 1, i + 1);
     const int j = 2 * i + grp;
     if (j < ntiles) {
       // K fragment schedule (2 x ds_read_b128 per k-step, double-buffered in fk[2][2]): the reads of step kk+1 are in flight
@@ -532,14 +310,9 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(4, 4))) 
 hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
   // K rows are loaded up to the next multiple of 64 without clamping: the row pitch must cover them
   if (p.npad % 64 != 0 || p.n <= 0 || p.pitch < ((p.n + 63) & ~63) || p.npad < ((p.n + 63) & ~63)) return hipErrorInvalidValue;
+  if (p.out8 && !p.out_mx) return hipErrorInvalidValue;
   dim3 grid(((p.n + QB - 1) / QB) * p.b2 * p.heads);
-  // measured (tools/kbench_attn.py): the split-KV kernel wins at every size tried (B=1: 47 vs 53 us; BH=256: 136 vs 154 us)
-  const bool split = p.variant != 1;
-  if (p.out8 && (!split || !p.out_mx)) return hipErrorInvalidValue;   // the MXFP8 epilogue lives in the split-KV kernel
-  if (p.ev_start) {
-    if (split) hipExtLaunchKernelGGL(attn_fwd_splitkv_kernel, grid, dim3(512), 0, s, p.ev_start, p.ev_stop, 0, p);
-    else hipExtLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, s, p.ev_start, p.ev_stop, 0, p);
-  } else if (split) hipLaunchKernelGGL(attn_fwd_splitkv_kernel, grid, dim3(512), 0, s, p);
-  else hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, s, p);
+  if (p.ev_start) hipExtLaunchKernelGGL(attn_fwd_splitkv_kernel, grid, dim3(512), 0, s, p.ev_start, p.ev_stop, 0, p);
+  else hipLaunchKernelGGL(attn_fwd_splitkv_kernel, grid, dim3(512), 0, s, p);
   return hipGetLastError();
 }

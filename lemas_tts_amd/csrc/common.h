@@ -80,7 +80,6 @@ enum GemmEpi : int {
   EPI_GATE_RES = 3,        // res_f32[m][n] += gate[n] * (acc + bias)   (rows past kv_len contribute 0)
   EPI_QK_ROPE = 4,         // N = 2*inner: +bias, RoPE, scatter to q / k [B2,H,pitch,64]
   EPI_V_T = 5,             // N = inner:   +bias, scatter to v^T [B2,H,64,npad]
-  EPI_NONE = 6,            // benchmarking only: K loop without an epilogue (one guarded store keeps the MFMAs live)
   EPI_BIAS_GELU_F8 = 7,    // out_f8 / out_mx = MXFP8(gelu_tanh(acc + bias))   (fp8 path only)
 };
 
@@ -127,7 +126,10 @@ struct GemmParams {
 
 // ---- internal launchers (one per .hip translation unit) ----------------------------------------
 hipError_t launch_gemm_bf16(int epi, const GemmParams& p, hipStream_t s);
-hipError_t launch_gemm_bf16_variant(int epi, const GemmParams& p, int variant, hipStream_t s);  // development: pick a kernel variant
+// explicit tile shape (16 = 256x128, 17 = 128x128, 18 = 128x64, 22 = 256x256; 0 = the production choice): unit tests and kbench
+hipError_t launch_gemm_bf16_tile(int epi, const GemmParams& p, int tile, hipStream_t s);
+// one-time > 64 KB dynamic-LDS opt-in of every GEMM instantiation (called from lemas_kernels_init, never on a launch path)
+hipError_t gemm_bf16_init();
 // one launch for a lane's QK (+RoPE) and V^T projections (same A, different W / bias / epilogue)
 hipError_t launch_gemm_qkv_fused(const GemmParams& pq, const GemmParams& pv, hipStream_t s);
 
@@ -139,7 +141,6 @@ struct AttnParams {
   const int* kv_len; // [B] or nullptr
   int b2, batch, heads, n, npad;
   int pitch;         // rows per sample of q / k / out (>= n)
-  int variant;       // 0 = auto, 1 = 4-wave kernel, 2 = split-KV 8-wave kernel
   float scale;
   uint8_t* out8;     // fp8 path: when set, the output is written as MXFP8 here ([B2*pitch, H*64] e4m3) instead of `out`
   uint8_t* out_mx;   //           [B2*pitch, H*2] E8M0

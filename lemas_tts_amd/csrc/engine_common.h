@@ -15,6 +15,9 @@
 namespace lemas {
 
 void set_error(const char* fmt, ...);
+// once per process: kernel attributes (dynamic-LDS opt-ins) that must not be set on a launch path.  Every *_create and
+// every lemas_k_* entry point calls it; returns 0 or a negative HIP code.
+int kernels_init();
 int hip_fail(hipError_t e, const char* what, const char* file, int line);
 
 #define HIP_TRY(expr)                                                        \

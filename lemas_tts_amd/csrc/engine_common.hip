@@ -2,6 +2,7 @@
 #include "engine_common.h"
 
 #include <cstring>
+#include <mutex>
 
 namespace lemas {
 
@@ -18,6 +19,14 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line) {
   set_error("HIP error %d (%s) at %s:%d in %s", (int)e, hipGetErrorString(e), file, line, what);
   (void)hipGetLastError();
   return -(int)e;
+}
+
+int kernels_init() {
+  static std::once_flag once;
+  static hipError_t err = hipSuccess;
+  std::call_once(once, [] { err = gemm_bf16_init(); });
+  if (err != hipSuccess) return hip_fail(err, "gemm_bf16_init()", __FILE__, __LINE__);
+  return 0;
 }
 
 int WeightStore::load(const char* name, const float* host, const int64_t* shape, int ndim) {

@@ -730,6 +730,7 @@ int lemas_dit_create(const lemas_dit_config* cfg, lemas_dit** out) {
     set_error("lemas_dit_create: no HIP device (this library has no CPU path)");
     return e != hipSuccess ? -(int)e : LEMAS_E_STATE;
   }
+  RC_TRY(kernels_init());
   lemas_dit* m = new lemas_dit();
   m->cfg = *cfg;
   m->declare_schema();

@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "engine_common.h"
+#include "../../include/lemas_hip_test.h"
 
 using namespace lemas;
 
@@ -70,15 +71,12 @@ __global__ void fill_pattern_kernel(bf16_t* p, size_t n, unsigned seed) {
 
 }  // namespace
 
-static int g_attn_variant = 0;
-
 extern "C" {
-
-int lemas_k_set_attention_variant(int32_t v) { g_attn_variant = v; return 0; }
 
 int lemas_k_linear_bf16(const float* A, const float* W, const float* bias, float* out, int32_t M, int32_t N, int32_t K,
                         int32_t act, void* stream) {
   hipStream_t s = (hipStream_t)stream;
+  RC_TRY(kernels_init());
   if (K % 64 != 0) { set_error("lemas_k_linear_bf16: K must be a multiple of 64"); return LEMAS_E_ARG; }
   Scratch sc;
   const int Np = (N + 127) & ~127;
@@ -100,6 +98,64 @@ int lemas_k_linear_bf16(const float* A, const float* W, const float* bias, float
     p.out_f32 = out;
     HIP_TRY(launch_gemm_bf16(EPI_BIAS_F32, p, s));
   }
+  HIP_TRY(hipStreamSynchronize(s));
+  return 0;
+}
+
+// One production GEMM launch with an explicit tile shape and epilogue in the engine's row space ([batch][pitch] rows, `frames`
+// valid per sample), so that every (tile, epilogue) pair the sampler can pick is reachable from a unit test.
+int lemas_k_gemm_epi(int32_t epi, int32_t tile, const float* A, const float* W, const float* bias, const float* aux,
+                     const int32_t* seq_len, float* out, int32_t batch, int32_t pitch, int32_t frames, int32_t N, int32_t K, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  RC_TRY(kernels_init());
+  if (batch <= 0 || pitch % 128 != 0 || frames <= 0 || frames > pitch || K % 64 != 0 || N % 128 != 0) {
+    set_error("lemas_k_gemm_epi: need pitch %% 128 == 0, frames <= pitch, K %% 64 == 0, N %% 128 == 0");
+    return LEMAS_E_ARG;
+  }
+  const int M = batch * pitch;
+  Scratch sc;
+  bf16_t* a = sc.get<bf16_t>((size_t)M * K);
+  bf16_t* w = sc.get<bf16_t>((size_t)N * K);
+  int* step = sc.get<int>(16);
+  if (!a || !w || !step) { set_error("lemas_k_gemm_epi: out of memory"); return LEMAS_E_STATE; }
+  HIP_TRY(launch_f32_to_bf16(A, a, (size_t)M * K, s));
+  HIP_TRY(launch_f32_to_bf16(W, w, (size_t)N * K, s));
+  GemmParams p{};
+  p.A = a; p.W = w; p.bias = bias; p.M = M; p.N = N; p.K = K; p.n_valid = N; p.ldc = N;
+  p.seq_pitch = pitch; p.seq_valid = frames; p.batch = batch; p.step_idx = step;
+  if (epi == EPI_BIAS_F32) {
+    p.out_f32 = out;
+    HIP_TRY(launch_gemm_bf16_tile(epi, p, tile, s));
+  } else if (epi == EPI_BIAS_BF16 || epi == EPI_BIAS_GELU_BF16) {
+    bf16_t* ob = sc.get<bf16_t>((size_t)M * N);
+    if (!ob) { set_error("lemas_k_gemm_epi: out of memory"); return LEMAS_E_STATE; }
+    p.out_bf16 = ob;
+    HIP_TRY(launch_gemm_bf16_tile(epi, p, tile, s));
+    hipLaunchKernelGGL(widen_kernel, dim3(2048), dim3(256), 0, s, ob, out, (size_t)M * N);
+  } else if (epi == EPI_GATE_RES) {     // out is the residual stream (in/out); aux = gate[N]
+    p.out_f32 = out; p.tab = aux; p.tab_stride = 0; p.gate_off = 0; p.kv_len = seq_len;
+    HIP_TRY(launch_gemm_bf16_tile(epi, p, tile, s));
+  } else if (epi == EPI_QK_ROPE) {      // aux = [cos | sin], each [frames][32]; out = q then k, each [batch][H][pitch][64]
+    const int heads = N / 128;
+    const size_t per = (size_t)M * heads * 64;
+    bf16_t* qk = sc.get<bf16_t>(2 * per);
+    if (!qk) { set_error("lemas_k_gemm_epi: out of memory"); return LEMAS_E_STATE; }
+    p.q = qk; p.k = qk + per; p.heads = heads; p.npad = pitch; p.rope_cos = aux; p.rope_sin = aux + (size_t)frames * 32;
+    HIP_TRY(launch_gemm_bf16_tile(epi, p, tile, s));
+    hipLaunchKernelGGL(widen_kernel, dim3(2048), dim3(256), 0, s, qk, out, 2 * per);
+  } else if (epi == EPI_V_T) {          // out = v^T [batch][H][64][pitch]
+    const int heads = N / 64;
+    const size_t per = (size_t)M * heads * 64;
+    bf16_t* vt = sc.get<bf16_t>(per);
+    if (!vt) { set_error("lemas_k_gemm_epi: out of memory"); return LEMAS_E_STATE; }
+    p.vt = vt; p.heads = heads; p.npad = pitch;
+    HIP_TRY(launch_gemm_bf16_tile(epi, p, tile, s));
+    hipLaunchKernelGGL(widen_kernel, dim3(2048), dim3(256), 0, s, vt, out, per);
+  } else {
+    set_error("lemas_k_gemm_epi: unknown epilogue %d", epi);
+    return LEMAS_E_ARG;
+  }
+  HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(s));
   return 0;
 }
@@ -144,6 +200,7 @@ int lemas_k_ln_mod_f8(const float* x, const float* scale, const float* shift, ui
 int lemas_k_linear_f8(const float* A, const float* W, const float* bias, float* out, int32_t M, int32_t N, int32_t K, int32_t act,
                       uint8_t* out8, uint8_t* outmx, void* stream) {
   hipStream_t s = (hipStream_t)stream;
+  RC_TRY(kernels_init());
   if (K % 128 != 0) { set_error("lemas_k_linear_f8: K must be a multiple of 128"); return LEMAS_E_ARG; }
   if (act == 2 && (N % 128 != 0 || !out8 || !outmx)) { set_error("lemas_k_linear_f8: act 2 needs N %% 128 == 0 and out8/outmx"); return LEMAS_E_ARG; }
   Scratch sc;
@@ -192,7 +249,7 @@ int lemas_k_attention(const float* q, const float* k, const float* v, const int3
   hipLaunchKernelGGL(pad_rows_kernel, dim3(2048), dim3(256), 0, s, k, kb, B * H, N, pitch);
   hipLaunchKernelGGL(transpose_v_kernel, dim3(2048), dim3(256), 0, s, v, vt, B * H, N, npad);
   AttnParams p{};
-  p.q = qb; p.k = kb; p.vt = vt; p.out = ob; p.kv_len = seq_len; p.b2 = B; p.batch = B; p.heads = H; p.n = N; p.npad = npad; p.pitch = pitch; p.variant = g_attn_variant;
+  p.q = qb; p.k = kb; p.vt = vt; p.out = ob; p.kv_len = seq_len; p.b2 = B; p.batch = B; p.heads = H; p.n = N; p.npad = npad; p.pitch = pitch;
   p.scale = 0.125f;
   HIP_TRY(launch_attention(p, s));
   hipLaunchKernelGGL(unpad_widen_kernel, dim3(2048), dim3(256), 0, s, ob, out, B, N, pitch, H * 64);
@@ -239,6 +296,7 @@ int lemas_k_convpos(const float* x, const float* w1, const float* b1, const floa
 
 // ---- micro-benchmarks of the step-loop kernels at arbitrary shapes (development aid + bench.py roofline cross-check)
 extern "C" int lemas_k_bench(const char* what, int32_t M, int32_t N, int32_t K, int32_t iters, int32_t variant, double* avg_us) {
+  RC_TRY(kernels_init());
   hipStream_t s = nullptr;
   hipStream_t own = nullptr;
   HIP_TRY(hipStreamCreate(&own));
@@ -261,7 +319,7 @@ extern "C" int lemas_k_bench(const char* what, int32_t M, int32_t N, int32_t K, 
     HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
     return 0;
   };
-  if (w == "gemm_gelu" || w == "gemm_gelu8" || w == "gemm_gate" || w == "gemm_qk" || w == "gemm_v" || w == "gemm_f32out" || w == "gemm_none" || w == "gemm_nodma") {
+  if (w == "gemm_gelu" || w == "gemm_gelu8" || w == "gemm_gate" || w == "gemm_qk" || w == "gemm_v" || w == "gemm_f32out") {
     const int Np = (N + 127) & ~127;
     bf16_t* a = sc.get<bf16_t>((size_t)M * K);
     bf16_t* wt = sc.get<bf16_t>((size_t)Np * K);
@@ -293,10 +351,9 @@ extern "C" int lemas_k_bench(const char* what, int32_t M, int32_t N, int32_t K, 
       HIP_TRY(hipMemsetAsync(amx, 127, (size_t)M * (K / 32), s));
       p.f8 = 1; p.a_mx = amx; p.w_scale = wsc; p.out_f8 = o8; p.out_mx = omx;
     }
-    const int epi = w == "gemm_gelu8" ? EPI_BIAS_GELU_F8 : w == "gemm_gelu" ? EPI_BIAS_GELU_BF16 : w == "gemm_gate" ? EPI_GATE_RES : w == "gemm_qk" ? EPI_QK_ROPE : w == "gemm_v" ? EPI_V_T : (w == "gemm_none" || w == "gemm_nodma") ? EPI_NONE : EPI_BIAS_F32;
-    if (w == "gemm_nodma") p.n_valid = -1;
+    const int epi = w == "gemm_gelu8" ? EPI_BIAS_GELU_F8 : w == "gemm_gelu" ? EPI_BIAS_GELU_BF16 : w == "gemm_gate" ? EPI_GATE_RES : w == "gemm_qk" ? EPI_QK_ROPE : w == "gemm_v" ? EPI_V_T : EPI_BIAS_F32;
     if ((epi == EPI_QK_ROPE && N != 2048) || (epi == EPI_V_T && N != 1024)) { set_error("bench: gemm_qk needs N = 2048, gemm_v N = 1024"); return LEMAS_E_ARG; }
-    rc = time_it([&]() { return launch_gemm_bf16_variant(epi, p, variant, s); });
+    rc = time_it([&]() { return launch_gemm_bf16_tile(epi, p, variant, s); });
   } else if (w == "attention") {
     // M = sequence length, N = batch*heads
     const int n = M, bh = N, npad = (n + 127) & ~127, pitch = npad;
@@ -309,7 +366,7 @@ extern "C" int lemas_k_bench(const char* what, int32_t M, int32_t N, int32_t K, 
     hipLaunchKernelGGL(fill_pattern_kernel, dim3(1024), dim3(256), 0, s, k, (size_t)bh * pitch * 64, 4u);
     hipLaunchKernelGGL(fill_pattern_kernel, dim3(1024), dim3(256), 0, s, vt, (size_t)bh * 64 * npad, 5u);
     AttnParams p{};
-    p.q = q; p.k = k; p.vt = vt; p.out = o; p.kv_len = nullptr; p.b2 = bh / 16; p.batch = bh / 16; p.heads = 16; p.n = n; p.npad = npad; p.pitch = pitch; p.variant = variant;
+    p.q = q; p.k = k; p.vt = vt; p.out = o; p.kv_len = nullptr; p.b2 = bh / 16; p.batch = bh / 16; p.heads = 16; p.n = n; p.npad = npad; p.pitch = pitch;
     p.scale = 0.125f;
     rc = time_it([&]() { return launch_attention(p, s); });
   } else {
@@ -323,72 +380,3 @@ extern "C" int lemas_k_bench(const char* what, int32_t M, int32_t N, int32_t K, 
   return rc;
 }
 
-// ---- experiment: how well does the VALU-bound attention kernel overlap with the MFMA-bound GEMMs of the OTHER CFG lane
-// when they run concurrently on two streams?  mode 0 = serial on one stream, 1 = concurrent.  Returns us per (attention +
-// 5 GEMMs) group.
-extern "C" int lemas_k_bench_overlap(int32_t mode, int32_t iters, int32_t gemm_variant_wide, int32_t gemm_variant_narrow, double* avg_us) {
-  hipStream_t sa = nullptr, sb = nullptr;
-  HIP_TRY(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
-  HIP_TRY(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
-  Scratch sc;
-  const int M = 1920, n = 1875, bh = 16, pitch = 1920;
-  bf16_t* a = sc.get<bf16_t>((size_t)M * 2048);
-  bf16_t* wt = sc.get<bf16_t>((size_t)2048 * 2048);
-  float* b = sc.get<float>(2048);
-  bf16_t* ob = sc.get<bf16_t>((size_t)M * 2048);
-  float* of = sc.get<float>((size_t)M * 2048);
-  float* tab = sc.get<float>(2048);
-  int* step = sc.get<int>(16);
-  bf16_t* q = sc.get<bf16_t>((size_t)bh * pitch * 64);
-  bf16_t* k = sc.get<bf16_t>((size_t)bh * pitch * 64);
-  bf16_t* vt = sc.get<bf16_t>((size_t)bh * 64 * pitch);
-  bf16_t* o = sc.get<bf16_t>((size_t)bh * pitch * 64);
-  bf16_t* q2 = sc.get<bf16_t>((size_t)bh * pitch * 64);
-  bf16_t* k2 = sc.get<bf16_t>((size_t)bh * pitch * 64);
-  bf16_t* vt2 = sc.get<bf16_t>((size_t)bh * 64 * pitch);
-  float* rc_ = sc.get<float>((size_t)M * 32);
-  float* rs_ = sc.get<float>((size_t)M * 32);
-  if (!a || !wt || !b || !ob || !of || !tab || !step || !q || !k || !vt || !o || !q2 || !k2 || !vt2 || !rc_ || !rs_) { set_error("bench: out of memory"); return LEMAS_E_STATE; }
-  hipLaunchKernelGGL(fill_pattern_kernel, dim3(1024), dim3(256), 0, sa, a, (size_t)M * 2048, 1u);
-  hipLaunchKernelGGL(fill_pattern_kernel, dim3(1024), dim3(256), 0, sa, wt, (size_t)2048 * 2048, 2u);
-  hipLaunchKernelGGL(fill_pattern_kernel, dim3(1024), dim3(256), 0, sa, q, (size_t)bh * pitch * 64, 3u);
-  hipLaunchKernelGGL(fill_pattern_kernel, dim3(1024), dim3(256), 0, sa, k, (size_t)bh * pitch * 64, 4u);
-  hipLaunchKernelGGL(fill_pattern_kernel, dim3(1024), dim3(256), 0, sa, vt, (size_t)bh * 64 * pitch, 5u);
-  HIP_TRY(hipStreamSynchronize(sa));
-  AttnParams at{};
-  at.q = q; at.k = k; at.vt = vt; at.out = o; at.b2 = 1; at.batch = 1; at.heads = 16; at.n = n; at.npad = pitch; at.pitch = pitch; at.scale = 0.125f;
-  GemmParams g{};
-  g.A = a; g.W = wt; g.bias = b; g.M = M; g.tab = tab; g.step_idx = step; g.seq_pitch = pitch; g.seq_valid = n; g.batch = 1; g.heads = 16; g.npad = pitch;
-  g.q = q2; g.k = k2; g.vt = vt2; g.rope_cos = rc_; g.rope_sin = rs_; g.out_bf16 = ob; g.out_f32 = of;
-  auto gemms = [&](hipStream_t s) {
-    g.N = 2048; g.K = 1024; g.n_valid = 2048; g.ldc = 2048; (void)launch_gemm_bf16_variant(EPI_QK_ROPE, g, gemm_variant_wide, s);
-    g.N = 1024; g.n_valid = 1024; (void)launch_gemm_bf16_variant(EPI_V_T, g, gemm_variant_narrow, s);
-    g.ldc = 1024; (void)launch_gemm_bf16_variant(EPI_GATE_RES, g, gemm_variant_narrow, s);
-    g.N = 2048; g.n_valid = 2048; g.ldc = 2048; (void)launch_gemm_bf16_variant(EPI_BIAS_GELU_BF16, g, gemm_variant_wide, s);
-    g.N = 1024; g.K = 2048; g.n_valid = 1024; g.ldc = 1024; (void)launch_gemm_bf16_variant(EPI_GATE_RES, g, gemm_variant_narrow, s);
-  };
-  hipEvent_t e0, e1, ej;
-  HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventCreateWithFlags(&ej, hipEventDisableTiming));
-  for (int w = 0; w < 2; ++w) { (void)launch_attention(at, sa); gemms(mode ? sb : sa); }
-  HIP_TRY(hipStreamSynchronize(sa)); HIP_TRY(hipStreamSynchronize(sb));
-  HIP_TRY(hipEventRecord(e0, sa));
-  if (mode == 1 || mode == 2) { HIP_TRY(hipStreamWaitEvent(sb, e0, 0)); }
-  for (int i = 0; i < iters; ++i) {
-    if (mode >= 2) {   // control experiment: the SAME half-size attention on both streams (mode 2) or twice on one (mode 3)
-      (void)launch_attention(at, sa);
-      (void)launch_attention(at, mode == 2 ? sb : sa);
-      continue;
-    }
-    (void)launch_attention(at, sa);
-    gemms(mode ? sb : sa);
-  }
-  if (mode == 1 || mode == 2) { HIP_TRY(hipEventRecord(ej, sb)); HIP_TRY(hipStreamWaitEvent(sa, ej, 0)); }
-  HIP_TRY(hipEventRecord(e1, sa));
-  HIP_TRY(hipEventSynchronize(e1));
-  float ms = 0.f;
-  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-  if (avg_us) *avg_us = 1e3 * ms / iters;
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(ej);
-  (void)hipStreamDestroy(sa); (void)hipStreamDestroy(sb);
-  return 0;
-}

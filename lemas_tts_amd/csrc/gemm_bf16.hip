@@ -7,7 +7,7 @@
 // Reference semantics: lemas_tts/model/modules.py:452-461,470-480 (QKV + RoPE), :495,:635 (out-proj + gated
 // residual), :349-350,:638-639 (FF), backbones/dit.py:252 (proj_out).
 //
-// Structure: BM x BN x 64 block tile, 4 waves as 2(M) x 2(N); operand tiles stream HBM/L2 -> LDS with
+// Structure: BM x BN x 64 block tile, 4 or 8 waves as NWM(M) x NWN(N); operand tiles stream HBM/L2 -> LDS with
 // global_load_lds_dwordx4 (LDS-DMA: no VGPR round trip, no ds_write pass) into an NSTAGE ring, one s_barrier per
 // K-tile, counted s_waitcnt vmcnt so that NSTAGE-2 tiles stay in flight across the barrier.  LDS rows are 128 B
 // with the 16-B chunk index XOR-swizzled by (row>>1)&7: conflict-free ds_read_b128 for the 32x32x16 fragments
@@ -25,18 +25,13 @@
 // Row space: activations are laid out as [sample][seq_pitch rows][...] with seq_pitch a multiple of 128, so a
 // 128-row tile never straddles two samples and v^T stores are 8-B aligned; rows >= seq_valid are padding
 // (computed, never stored where it matters).
-#include <cstdlib>
+#include <mutex>
 
 #include "common.h"
-
-#ifndef LEMAS_GEMM_PRIO
-#define LEMAS_GEMM_PRIO 0
-#endif
 
 namespace {
 
 constexpr int BK = 64;
-constexpr bool PRIO = LEMAS_GEMM_PRIO;
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
@@ -337,7 +332,7 @@ template <> struct FragT<true> { using type = i32x8; };
 // per row, brought in by one extra 4-B-per-lane LDS-DMA per wave and tile.  Operand layout of the instruction
 // (probed on the hardware, tools/exp/mx_probe.hip): lane (i = l&31, h = l>>5) holds row i; registers 0-3 are K
 // 16h..16h+15 and registers 4-7 are K 32+16h..; the scale of K-block beta (32 K) comes from lane i + 32 beta.
-template <int EPI, int TBM, int TBN, int NSTAGE, int NWM, int NWN, int SPREAD, bool SWAP, bool F8>
+template <int EPI, int TBM, int TBN, int NSTAGE, int NWM, int NWN, bool SWAP, bool F8>
 __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, int m0, int n0) {
   using frag_t = typename FragT<F8>::type;
   constexpr int NW = NWM * NWN;                       // waves per workgroup
@@ -348,7 +343,6 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, int m
   constexpr int PW = A_PW + B_PW + (F8 ? 1 : 0);           // + the scale piece
   constexpr int KS = F8 ? 2 : 4;                           // MFMA k-steps per 128-B K tile
   static_assert((TBM / 8) % NW == 0 && (TBN / 8) % NW == 0, "DMA pieces must divide over the waves");
-  static_assert(!F8 || SPREAD != 2, "the mid-barrier loop is bf16 only");
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -411,19 +405,6 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, int m
   for (int s = 0; s < NSTAGE - 1; ++s)
     if (s < nk) issue(s, s);
 
-  auto ldfrag = [&](const char* sX, int row, int kk) -> frag_t {
-    if constexpr (F8) {
-      const u32x4 lo = *reinterpret_cast<const u32x4*>(sX + lds_off(row, kk * 4 + hi));
-      const u32x4 up = *reinterpret_cast<const u32x4*>(sX + lds_off(row, kk * 4 + 2 + hi));
-      i32x8 f;
-      f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = up[0]; f[5] = up[1]; f[6] = up[2]; f[7] = up[3];
-      return f;
-    } else {
-      return *reinterpret_cast<const bf16x8*>(sX + lds_off(row, kk * 2 + hi));
-    }
-  };
-  auto frag_a = [&](const char* sA, int kk, int t) { return ldfrag(sA, wm * WTM + t * 32 + l31, kk); };
-  auto frag_b = [&](const char* sB, int kk, int t) { return ldfrag(sB, wn * WTN + t * 32 + l31, kk); };
   // one MFMA of k-step kk; asc = this lane's scale dword for the A row-fragment, already shifted by 8 hi
   auto mfma1 = [&](const frag_t& fa, const frag_t& fb, f32x16& c, int kk, int asc) {
     if constexpr (F8) {
@@ -435,93 +416,12 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, int m
       c = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb, fa, c, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, c, 0, 0, 0);
     }
   };
-  if constexpr (SPREAD == 2 && !F8) {
-    // Mid-iteration barrier: the wait + barrier that publishes tile kt+1 sits between k-steps 1 and 2 of tile kt, so the
-    // first fragments of tile kt+1 are read under the last MFMAs of tile kt and no iteration opens with every wave
-    // waiting on LDS at once (with the barrier at the top, all 8 waves issue their reads together and the matrix pipe
-    // idles ~300 cycles per K-tile).  Tile kt+NSTAGE-1 is issued in the second half, after the barrier.
-    bf16x8 f0a[TI], f0b[TJ], f1a[TI], f1b[TJ];
-    if (nk >= NSTAGE - 1) wait_vmcnt<PW * (NSTAGE - 2)>();   // prologue issued NSTAGE-1 tiles: tile 0 is the oldest
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int t = 0; t < TI; ++t) f0a[t] = frag_a(smem, 0, t);
-#pragma unroll
-    for (int t = 0; t < TJ; ++t) f0b[t] = frag_b(smem + A_BYTES, 0, t);
-    auto mma = [&](const bf16x8 (&fa)[TI], const bf16x8 (&fb)[TJ]) {
-#pragma unroll
-      for (int i = 0; i < TI; ++i)
-#pragma unroll
-        for (int j = 0; j < TJ; ++j)
-          acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0)
-                           : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-    };
-    int stage = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-      const char* sA = smem + stage * STAGE;
-      const char* sB = sA + A_BYTES;
-      int s1 = stage + 1;
-      s1 = s1 == NSTAGE ? 0 : s1;
-      const int nt = kt + NSTAGE - 1;
-      int ns = stage + NSTAGE - 1;
-      ns = ns >= NSTAGE ? ns - NSTAGE : ns;
-      // k-step 0
-#pragma unroll
-      for (int t = 0; t < TI; ++t) f1a[t] = frag_a(sA, 1, t);
-#pragma unroll
-      for (int t = 0; t < TJ; ++t) f1b[t] = frag_b(sB, 1, t);
-      __builtin_amdgcn_sched_barrier(0);
-      mma(f0a, f0b);
-      __builtin_amdgcn_sched_barrier(0);
-      // k-step 1
-#pragma unroll
-      for (int t = 0; t < TI; ++t) f0a[t] = frag_a(sA, 2, t);
-#pragma unroll
-      for (int t = 0; t < TJ; ++t) f0b[t] = frag_b(sB, 2, t);
-      __builtin_amdgcn_sched_barrier(0);
-      mma(f1a, f1b);
-      __builtin_amdgcn_sched_barrier(0);
-      // publish tile kt+1 (its DMA was issued one iteration ago); younger tiles stay in flight
-      if (kt + 1 < nk) {
-        if (kt + NSTAGE - 2 < nk) wait_vmcnt<PW * (NSTAGE - 3 > 0 ? NSTAGE - 3 : 0)>();
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-      }
-      const bool refill = nt < nk;
-      // k-step 2 (+ first half of the refill DMA: the stage of tile kt-1 is free now)
-#pragma unroll
-      for (int t = 0; t < TI; ++t) f1a[t] = frag_a(sA, 3, t);
-#pragma unroll
-      for (int t = 0; t < TJ; ++t) f1b[t] = frag_b(sB, 3, t);
-      if (refill) {
-#pragma unroll
-        for (int x = 0; x < PW / 2; ++x) issue_piece(ns, nt, x);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      mma(f0a, f0b);
-      __builtin_amdgcn_sched_barrier(0);
-      // k-step 3 (+ second half of the DMA, + first fragments of tile kt+1)
-      if (kt + 1 < nk) {
-        const char* nA = smem + s1 * STAGE;
-#pragma unroll
-        for (int t = 0; t < TI; ++t) f0a[t] = frag_a(nA, 0, t);
-#pragma unroll
-        for (int t = 0; t < TJ; ++t) f0b[t] = frag_b(nA + A_BYTES, 0, t);
-      }
-      if (refill) {
-#pragma unroll
-        for (int x = PW / 2; x < PW; ++x) issue_piece(ns, nt, x);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      mma(f1a, f1b);
-      __builtin_amdgcn_sched_barrier(0);
-      stage = s1;
-    }
-  } else if constexpr (SPREAD == 3) {
-    // Hand-scheduled variant of the loop below.  The compiler's waitcnt pass cannot count past the LDS-DMA / branch
-    // structure and drops an s_waitcnt lgkmcnt(0) in front of every MFMA group, i.e. it also waits for the fragment reads
-    // of the NEXT k-step that were issued a few instructions earlier (measured: matrix pipe 52 % busy while resident).
-    // Here the fragment reads are asm (untracked) and each k-step waits with an exact count: only for its own operands.
+  {
+    // Hand-scheduled K loop.  Left to the compiler, the waitcnt pass cannot count past the LDS-DMA / branch structure and
+    // drops an s_waitcnt lgkmcnt(0) in front of every MFMA group, i.e. it also waits for the fragment reads of the NEXT
+    // k-step that were issued a few instructions earlier (measured: matrix pipe 52 % busy while resident).  Here the
+    // fragment reads are asm (untracked) and each k-step waits with an exact count: only for its own operands.  The refill
+    // DMA of tile kt+NSTAGE-1 is spread over the k-steps so that its issue slots hide behind the MFMAs.
     constexpr int RPF = F8 ? 2 : 1;                 // ds_read_b128 per fragment
     constexpr int NR = (TI + TJ) * RPF;             // LDS reads per k-step (F8: + TI scale dwords in step 0, all older)
     static_assert(NR + (F8 ? TI : 0) <= 15, "lgkmcnt is a 4-bit counter");
@@ -555,7 +455,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, int m
       const int nt = kt + NSTAGE - 1;
       int ns = stage + NSTAGE - 1;
       ns = ns >= NSTAGE ? ns - NSTAGE : ns;
-      const bool refill = nt < nk && !(EPI == EPI_NONE && p.n_valid == -1);
+      const bool refill = nt < nk;
       const unsigned sb = lds_base + stage * STAGE;
       if constexpr (F8) ReadScales<0, TI>::run(asc, sb + aS);
       ReadFrags<0, TI, RPF>::run(fa[0], aA[0], sb);
@@ -586,66 +486,6 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, int m
       }
       stage = stage + 1 == NSTAGE ? 0 : stage + 1;
     }
-  } else {
-    int stage = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-      // tile kt must have landed; in steady state the NSTAGE-2 younger tiles stay in flight across the barrier
-      if (kt + NSTAGE - 2 < nk) wait_vmcnt<PW * (NSTAGE - 2)>();
-      else wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();
-      // every wave is past its reads of the stage consumed in iteration kt-1: refill it with tile kt+NSTAGE-1
-      const int nt = kt + NSTAGE - 1;
-      int ns = stage + NSTAGE - 1;
-      ns = ns >= NSTAGE ? ns - NSTAGE : ns;
-      const bool refill = nt < nk && !(EPI == EPI_NONE && p.n_valid == -1);   // n_valid == -1: timing experiment without DMA
-      if (!SPREAD && refill) issue(ns, nt);
-      const char* sA = smem + stage * STAGE;
-      const char* sB = sA + A_BYTES;
-      // fragments are double-buffered in registers: the ds_read_b128 of k-step kk+1 are in flight under the MFMAs of kk;
-      // sched_barrier pins that order (the scheduler otherwise sinks the reads next to their consumers)
-      frag_t af[2][TI], bf[2][TJ];
-      int asc[TI];
-  #pragma unroll
-      for (int t = 0; t < TI; ++t) {
-        af[0][t] = frag_a(sA, 0, t);
-        asc[t] = F8 ? (*reinterpret_cast<const int*>(sA + SC_OFF + (wm * WTM + t * 32 + l31) * 4) >> (8 * hi)) : 0;
-      }
-  #pragma unroll
-      for (int t = 0; t < TJ; ++t) bf[0][t] = frag_b(sB, 0, t);
-  #pragma unroll
-      for (int kk = 0; kk < KS; ++kk) {
-        if (kk < KS - 1) {
-  #pragma unroll
-          for (int t = 0; t < TI; ++t) af[(kk + 1) & 1][t] = frag_a(sA, kk + 1, t);
-  #pragma unroll
-          for (int t = 0; t < TJ; ++t) bf[(kk + 1) & 1][t] = frag_b(sB, kk + 1, t);
-        }
-        if (SPREAD && refill) {   // DMA issue slots hidden behind the MFMAs instead of a burst after the barrier
-  #pragma unroll
-          for (int x = (PW * kk) / KS; x < (PW * (kk + 1)) / KS; ++x) issue_piece(ns, nt, x);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
-  #pragma unroll
-        for (int i = 0; i < TI; ++i)
-  #pragma unroll
-          for (int j = 0; j < TJ; ++j) mfma1(af[kk & 1][i], bf[kk & 1][j], acc[i][j], kk, asc[i]);
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      stage = stage + 1 == NSTAGE ? 0 : stage + 1;
-    }
-  }
-  if (EPI == EPI_NONE) {
-    float t = 0.f;
-#pragma unroll
-    for (int i = 0; i < TI; ++i)
-#pragma unroll
-      for (int j = 0; j < TJ; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) t += acc[i][j][r];
-    if (t == 123.456f) p.out_f32[0] = t;
-    return;
   }
   if constexpr (F8) {   // per-output-channel weight scale
     const float* ws = p.w_scale + n0 + wn * WTN;
@@ -683,168 +523,149 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, int m
   }
 }
 
-template <int EPI, int TBM, int TBN, int NSTAGE, int NWM, int NWN, int SPREAD, bool F8 = false>
+template <int EPI, int TBM, int TBN, int NSTAGE, int NWM, int NWN, bool F8>
 __global__ __launch_bounds__(64 * NWM * NWN) void gemm_bf16_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tiles_n = p.N / TBN;
   const int lid = xcd_tile_id();
   const int m0 = (lid / tiles_n) * TBM, n0 = (lid % tiles_n) * TBN;
-  gemm_body<EPI, TBM, TBN, NSTAGE, NWM, NWN, SPREAD, EPI != EPI_V_T, F8>(p, smem, m0, n0);
+  gemm_body<EPI, TBM, TBN, NSTAGE, NWM, NWN, EPI != EPI_V_T, F8>(p, smem, m0, n0);
 }
 
-template <int EPI, int TBM, int TBN, int NSTAGE, int NWM, int NWN, int SPREAD, bool F8 = false>
-hipError_t launch_cfg(const GemmParams& p, hipStream_t s) {
-  if (p.N % TBN != 0) return hipErrorInvalidValue;
-  constexpr int ring = NSTAGE * ((TBM + TBN) * 128 + (F8 ? TBM * 4 : 0));
-  constexpr int slabs = NWM * NWN * slab_bytes<EPI, 32, TBN / NWN>();
-  constexpr int lds = ring > slabs ? ring : slabs;
+// The tile shapes in use.  All run the hand-scheduled loop above.
+//   T256x128: 8 waves (4 x 2), 3-stage ring, 147 KB LDS -- N >= 2048 GEMMs at batch 1
+//   T128x128: 8 waves (2 x 4), 3-stage ring,  96 KB      -- N = 1024 GEMMs at batch 1
+//   T128x64 : 4 waves (2 x 2), 3-stage ring,  72 KB      -- short utterances
+//   T256x256: 8 waves (2 x 4), 2-stage ring, 128 KB      -- batched shapes (several rounds of tiles per CU): 33 % fewer operand
+//             bytes per flop, measured 8-13 % faster per tile area at M = 30720 (bf16 only)
+enum GemmTile : int { T256x128 = 16, T128x128 = 17, T128x64 = 18, T256x256 = 22 };
+
+template <int TILE> struct TileCfg;
+template <> struct TileCfg<T256x128> { static constexpr int BM = 256, BN = 128, ST = 3, WM = 4, WN = 2; };
+template <> struct TileCfg<T128x128> { static constexpr int BM = 128, BN = 128, ST = 3, WM = 2, WN = 4; };
+template <> struct TileCfg<T128x64>  { static constexpr int BM = 128, BN = 64,  ST = 3, WM = 2, WN = 2; };
+template <> struct TileCfg<T256x256> { static constexpr int BM = 256, BN = 256, ST = 2, WM = 2, WN = 4; };
+
+template <int EPI, int TILE, bool F8>
+struct Launch {
+  using C = TileCfg<TILE>;
+  static constexpr int ring = C::ST * ((C::BM + C::BN) * 128 + (F8 ? C::BM * 4 : 0));
+  static constexpr int slabs = C::WM * C::WN * slab_bytes<EPI, 32, C::BN / C::WN>();
+  static constexpr int lds = ring > slabs ? ring : slabs;
   static_assert(lds <= 160 * 1024, "LDS budget");
-  static bool attr_set = false;
-  if (lds > 65536 && !attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<EPI, TBM, TBN, NSTAGE, NWM, NWN, SPREAD, F8>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
+  static const void* fn() { return reinterpret_cast<const void*>(gemm_bf16_kernel<EPI, C::BM, C::BN, C::ST, C::WM, C::WN, F8>); }
+  // the > 64 KB dynamic-LDS opt-in; done once from lemas_kernels_init(), never on a launch path (a launch may sit inside a
+  // stream capture)
+  static hipError_t init() { return hipFuncSetAttribute(fn(), hipFuncAttributeMaxDynamicSharedMemorySize, lds); }
+  static hipError_t run(const GemmParams& p, hipStream_t s) {
+    if (p.N % C::BN != 0) return hipErrorInvalidValue;
+    const int tiles_m = (p.M + C::BM - 1) / C::BM, tiles_n = p.N / C::BN;
+    const dim3 grid(tiles_m * tiles_n), block(64 * C::WM * C::WN);
+    if (p.ev_start)
+      hipExtLaunchKernelGGL((gemm_bf16_kernel<EPI, C::BM, C::BN, C::ST, C::WM, C::WN, F8>), grid, block, lds, s, p.ev_start, p.ev_stop, 0, p);
+    else
+      hipLaunchKernelGGL((gemm_bf16_kernel<EPI, C::BM, C::BN, C::ST, C::WM, C::WN, F8>), grid, block, lds, s, p);
+    return hipGetLastError();
   }
-  const int tiles_m = (p.M + TBM - 1) / TBM, tiles_n = p.N / TBN;
-  if (p.ev_start)
-    hipExtLaunchKernelGGL((gemm_bf16_kernel<EPI, TBM, TBN, NSTAGE, NWM, NWN, SPREAD, F8>), dim3(tiles_m * tiles_n),
-                          dim3(64 * NWM * NWN), lds, s, p.ev_start, p.ev_stop, 0, p);
-  else
-    hipLaunchKernelGGL((gemm_bf16_kernel<EPI, TBM, TBN, NSTAGE, NWM, NWN, SPREAD, F8>), dim3(tiles_m * tiles_n),
-                       dim3(64 * NWM * NWN), lds, s, p);
-  return hipGetLastError();
+};
+
+// Largest tile that still yields about one workgroup per CU (measured at M = 1920 / 3840 / 18432 with tools/kbench.py).
+// With two CFG lanes in flight each launch only needs half the chip (p.concurrency = 2: +1.8 % end to end for the larger tiles).
+int pick_tile(const GemmParams& p) {
+  const long conc = p.concurrency > 1 ? p.concurrency : 1;
+  const long t256 = (long)((p.M + 255) / 256) * (p.N / 128), t128 = (long)((p.M + 127) / 128) * (p.N / 128);
+  const long want = 200 / conc;
+  int tile = t256 >= want ? T256x128 : t128 >= want ? T128x128 : T128x64;
+  if (!p.f8 && tile == T256x128 && p.N % 256 == 0) {
+    // batched workloads: 256x256 when at least two full rounds of them exist and the whole-round count favours them
+    const long cus = 256 / conc, tbig = (long)((p.M + 255) / 256) * (p.N / 256);
+    const double cost_big = (double)((tbig + cus - 1) / cus) * (2.0 / 1.10), cost_std = (double)((t256 + cus - 1) / cus);
+    if (tbig >= 2 * cus && cost_big < cost_std) tile = T256x256;
+  }
+  return tile;
 }
 
-template <int EPI>
-hipError_t dispatch_f8(const GemmParams& p, int variant, hipStream_t s) {
-  if (variant == 0) {
-    static const int force = getenv("LEMAS_GEMM_F8") ? atoi(getenv("LEMAS_GEMM_F8")) : 0;   // development A/B switch
-    const long t256 = (long)((p.M + 255) / 256) * (p.N / 128), t128 = (long)((p.M + 127) / 128) * (p.N / 128);
-    const long want = 200 / (p.concurrency > 1 ? p.concurrency : 1);
-    variant = t256 >= want ? 16 : t128 >= want ? 17 : 18;
-    if (force) variant = force;
-  }
-  switch (variant) {
-    case 4: return launch_cfg<EPI, 128, 64, 3, 2, 2, 1, true>(p, s);
-    case 6: return launch_cfg<EPI, 256, 128, 3, 4, 2, 1, true>(p, s);
-    case 10: return launch_cfg<EPI, 128, 128, 3, 2, 4, 1, true>(p, s);
-    case 11: return launch_cfg<EPI, 128, 128, 4, 2, 4, 1, true>(p, s);
-    case 16: return launch_cfg<EPI, 256, 128, 3, 4, 2, 3, true>(p, s);
-    case 17: return launch_cfg<EPI, 128, 128, 3, 2, 4, 3, true>(p, s);
-    case 18: return launch_cfg<EPI, 128, 64, 3, 2, 2, 3, true>(p, s);
+template <int EPI, bool F8>
+hipError_t dispatch(const GemmParams& p, int tile, hipStream_t s) {
+  if (tile == 0) tile = pick_tile(p);
+  switch (tile) {
+    case T256x128: return Launch<EPI, T256x128, F8>::run(p, s);
+    case T128x128: return Launch<EPI, T128x128, F8>::run(p, s);
+    case T128x64: return Launch<EPI, T128x64, F8>::run(p, s);
+    case T256x256:
+      if constexpr (!F8) return Launch<EPI, T256x256, false>::run(p, s);
+      else return hipErrorInvalidValue;
     default: return hipErrorInvalidValue;
   }
 }
 
-template <int EPI>
-hipError_t dispatch(const GemmParams& p, int variant, hipStream_t s) {
-  if (variant == 0) {
-    // Largest tile that still yields about one workgroup per CU (measured with tools/kbench.py at M = 1920 / 3840 /
-    // 18432): 256x128 (8 waves, 3-stage ring) -> 128x128 (8 waves, 3-stage) -> 128x64 (4 waves, 3-stage), each in its
-    // hand-scheduled form (exact lgkmcnt waits; 2-7 % faster than the compiler-scheduled 6 / 10 / 4).
-    static const int force_wide = getenv("LEMAS_GEMM_WIDE") ? atoi(getenv("LEMAS_GEMM_WIDE")) : 0;       // development A/B switches
-    static const int force_narrow = getenv("LEMAS_GEMM_NARROW") ? atoi(getenv("LEMAS_GEMM_NARROW")) : 0;
-    const long t256 = (long)((p.M + 255) / 256) * (p.N / 128), t128 = (long)((p.M + 127) / 128) * (p.N / 128);
-    // with two CFG lanes in flight each launch only needs half the chip: measured +1.8 % end to end for the larger tiles
-    const long want = 200 / (p.concurrency > 1 ? p.concurrency : 1);
-    variant = t256 >= want ? 16 : t128 >= want ? 17 : 18;
-    // batched workloads (several rounds of tiles per CU): 256x256 tiles move 33 % fewer operand bytes per flop and measure
-    // 8-13 % faster per tile-area (M = 30720: 806-930 vs 643-854 TFLOP/s); taken when the whole-round count still favours them
-    if (p.N % 256 == 0) {
-      const long cus = 256 / (p.concurrency > 1 ? p.concurrency : 1);
-      const long tbig = (long)((p.M + 255) / 256) * (p.N / 256);
-      const double cost_big = (double)((tbig + cus - 1) / cus) * (2.0 / 1.10), cost_std = (double)((t256 + cus - 1) / cus);
-      if (variant == 16 && tbig >= 2 * cus && cost_big < cost_std) variant = 22;
-    }
-    const int chosen = variant;
-    if (p.N >= 2048 && force_wide) variant = force_wide;
-    if (p.N < 2048 && force_narrow) variant = force_narrow;
-    if ((variant == 21 || variant == 22) && p.N % 256 != 0) variant = chosen;   // a forced 256-wide tile must divide N
+template <int EPI, bool F8>
+hipError_t init_epi() {
+  hipError_t e;
+  if ((e = Launch<EPI, T256x128, F8>::init()) != hipSuccess) return e;
+  if ((e = Launch<EPI, T128x128, F8>::init()) != hipSuccess) return e;
+  if ((e = Launch<EPI, T128x64, F8>::init()) != hipSuccess) return e;
+  if constexpr (!F8) {
+    if ((e = Launch<EPI, T256x256, false>::init()) != hipSuccess) return e;
   }
-  switch (variant) {
-    //                              BM   BN  ST WM WN spread
-    case 2: return launch_cfg<EPI, 128, 128, 2, 2, 2, false>(p, s);
-    case 3: return launch_cfg<EPI, 128, 128, 3, 2, 2, true>(p, s);
-    case 4: return launch_cfg<EPI, 128, 64, 3, 2, 2, true>(p, s);
-    case 5: return launch_cfg<EPI, 128, 64, 2, 2, 2, false>(p, s);
-    case 6: return launch_cfg<EPI, 256, 128, 3, 4, 2, true>(p, s);
-    case 7: return launch_cfg<EPI, 256, 128, 2, 4, 2, false>(p, s);
-    case 10: return launch_cfg<EPI, 128, 128, 3, 2, 4, true>(p, s);
-    case 11: return launch_cfg<EPI, 128, 128, 3, 2, 2, false>(p, s);
-    case 12: return launch_cfg<EPI, 256, 128, 3, 4, 2, false>(p, s);
-    case 13: return launch_cfg<EPI, 256, 128, 3, 4, 2, 2>(p, s);
-    case 14: return launch_cfg<EPI, 128, 128, 3, 2, 4, 2>(p, s);
-    case 15: return launch_cfg<EPI, 128, 128, 4, 2, 4, 2>(p, s);
-    case 16: return launch_cfg<EPI, 256, 128, 3, 4, 2, 3>(p, s);   // hand-scheduled LDS reads (exact lgkmcnt)
-    case 17: return launch_cfg<EPI, 128, 128, 3, 2, 4, 3>(p, s);
-    case 18: return launch_cfg<EPI, 128, 64, 3, 2, 2, 3>(p, s);
-    case 19: return launch_cfg<EPI, 256, 128, 3, 2, 2, 3>(p, s);   // 4 waves of 128x64: one wave per SIMD, 0.75 LDS reads per MFMA
-    case 20: return launch_cfg<EPI, 128, 128, 3, 2, 2, 3>(p, s);
-    case 21: return launch_cfg<EPI, 256, 256, 2, 4, 2, 3>(p, s);   // large-M experiments: 33 % fewer operand bytes per flop
-    case 22: return launch_cfg<EPI, 256, 256, 2, 2, 4, 3>(p, s);
-    default: return hipErrorInvalidValue;
-  }
+  return hipSuccess;
 }
 
 // QK (+RoPE) and V^T projections of one lane in ONE launch: they only share their input, so instead of two launches of ~half
-// a chip each, run back to back, the first tiles_q workgroups take 256x128 QK tiles and the rest 128x128 V tiles.  Both bodies
-// are 8-wave hand-scheduled variants (16 for QK; 16 or 17 for V).
-template <bool F8, int VBM = 128>
+// a chip each, run back to back, the first tiles_q workgroups take 256x128 QK tiles and the remaining ones 256x128 V tiles
+// (128 + 64 workgroups at configs[1]; measured 0.6 % faster end to end than 128x128 V tiles).
+template <bool F8>
 __global__ __launch_bounds__(512) void gemm_qkv_fused_kernel(const GemmParams pq, const GemmParams pv, int tiles_q, int tiles_v) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int bid = blockIdx.x;
   if (bid < tiles_q) {
     const int tn = pq.N / 128, lid = xcd_remap(bid, tiles_q);
-    gemm_body<EPI_QK_ROPE, 256, 128, 3, 4, 2, 3, true, F8>(pq, smem, (lid / tn) * 256, (lid % tn) * 128);
+    gemm_body<EPI_QK_ROPE, 256, 128, 3, 4, 2, true, F8>(pq, smem, (lid / tn) * 256, (lid % tn) * 128);
   } else {
     const int tn = pv.N / 128, lid = xcd_remap(bid - tiles_q, tiles_v);
-    if constexpr (VBM == 128) gemm_body<EPI_V_T, 128, 128, 3, 2, 4, 3, false, F8>(pv, smem, (lid / tn) * 128, (lid % tn) * 128);
-    else gemm_body<EPI_V_T, 256, 128, 3, 4, 2, 3, false, F8>(pv, smem, (lid / tn) * 256, (lid % tn) * 128);
+    gemm_body<EPI_V_T, 256, 128, 3, 4, 2, false, F8>(pv, smem, (lid / tn) * 256, (lid % tn) * 128);
   }
 }
 
 template <bool F8>
-hipError_t launch_qkv(const GemmParams& pq, const GemmParams& pv, hipStream_t s) {
-  constexpr int ring_q = 3 * ((256 + 128) * 128 + (F8 ? 256 * 4 : 0)), ring_v = 3 * ((128 + 128) * 128 + (F8 ? 128 * 4 : 0));
-  constexpr int slab_q = 8 * slab_bytes<EPI_QK_ROPE, 32, 64>(), slab_v = 8 * slab_bytes<EPI_V_T, 32, 64>();
-  constexpr int lds = (ring_q > ring_v ? ring_q : ring_v) > (slab_q > slab_v ? slab_q : slab_v) ? (ring_q > ring_v ? ring_q : ring_v)
-                                                                                                  : (slab_q > slab_v ? slab_q : slab_v);
+struct LaunchQkv {
+  static constexpr int ring = 3 * ((256 + 128) * 128 + (F8 ? 256 * 4 : 0));
+  static constexpr int slab_q = 8 * slab_bytes<EPI_QK_ROPE, 32, 64>(), slab_v = 8 * slab_bytes<EPI_V_T, 32, 64>();
+  static constexpr int slab = slab_q > slab_v ? slab_q : slab_v;
+  static constexpr int lds = ring > slab ? ring : slab;
   static_assert(lds <= 160 * 1024, "LDS budget");
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_qkv_fused_kernel<F8, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
+  static hipError_t init() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_qkv_fused_kernel<F8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   }
-  // V tiles: 256x128 (64 tiles: 192 workgroups in all, measured 0.6 % faster end to end) or 128x128 (120 tiles)
-  static const int vbig = getenv("LEMAS_QKV_VBIG") ? atoi(getenv("LEMAS_QKV_VBIG")) : 1;
-  const int tiles_q = ((pq.M + 255) / 256) * (pq.N / 128);
-  if (vbig) {
-    static bool attr2 = false;
-    if (!attr2) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_qkv_fused_kernel<F8, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      if (e != hipSuccess) return e;
-      attr2 = true;
-    }
-    const int tiles_v = ((pv.M + 255) / 256) * (pv.N / 128);
-    hipLaunchKernelGGL((gemm_qkv_fused_kernel<F8, 256>), dim3(tiles_q + tiles_v), dim3(512), lds, s, pq, pv, tiles_q, tiles_v);
+  static hipError_t run(const GemmParams& pq, const GemmParams& pv, hipStream_t s) {
+    const int tiles_q = ((pq.M + 255) / 256) * (pq.N / 128), tiles_v = ((pv.M + 255) / 256) * (pv.N / 128);
+    hipLaunchKernelGGL((gemm_qkv_fused_kernel<F8>), dim3(tiles_q + tiles_v), dim3(512), lds, s, pq, pv, tiles_q, tiles_v);
     return hipGetLastError();
   }
-  const int tiles_v = ((pv.M + 127) / 128) * (pv.N / 128);
-  hipLaunchKernelGGL((gemm_qkv_fused_kernel<F8, 128>), dim3(tiles_q + tiles_v), dim3(512), lds, s, pq, pv, tiles_q, tiles_v);
-  return hipGetLastError();
-}
+};
 
 }  // namespace
+
+hipError_t gemm_bf16_init() {
+  hipError_t e;
+#define LEMAS_INIT(EPI)                                                   \
+  if ((e = init_epi<EPI, false>()) != hipSuccess) return e;               \
+  if ((e = init_epi<EPI, true>()) != hipSuccess) return e;
+  LEMAS_INIT(EPI_BIAS_BF16) LEMAS_INIT(EPI_BIAS_GELU_BF16) LEMAS_INIT(EPI_BIAS_F32) LEMAS_INIT(EPI_GATE_RES) LEMAS_INIT(EPI_QK_ROPE)
+  LEMAS_INIT(EPI_V_T)
+#undef LEMAS_INIT
+  if ((e = init_epi<EPI_BIAS_GELU_F8, true>()) != hipSuccess) return e;
+  if ((e = LaunchQkv<false>::init()) != hipSuccess) return e;
+  return LaunchQkv<true>::init();
+}
 
 hipError_t launch_gemm_qkv_fused(const GemmParams& pq, const GemmParams& pv, hipStream_t s) {
   if (pq.K % 128 != 0 || pq.N % 128 != 0 || pv.N % 128 != 0 || pq.M != pv.M || pq.f8 != pv.f8 || pq.M <= 0) return hipErrorInvalidValue;
   if (pq.f8 && (!pq.a_mx || !pq.w_scale || !pv.w_scale)) return hipErrorInvalidValue;
-  return pq.f8 ? launch_qkv<true>(pq, pv, s) : launch_qkv<false>(pq, pv, s);
+  return pq.f8 ? LaunchQkv<true>::run(pq, pv, s) : LaunchQkv<false>::run(pq, pv, s);
 }
 
-hipError_t launch_gemm_bf16_variant(int epi, const GemmParams& p, int variant, hipStream_t s) {
+hipError_t launch_gemm_bf16_tile(int epi, const GemmParams& p, int tile, hipStream_t s) {
   if (p.K % BK != 0 || p.N % 128 != 0 || p.M <= 0 || p.seq_pitch <= 0) return hipErrorInvalidValue;
   // the row-wise epilogues store whole 16-B chunks: 4 fp32 / 8 bf16 / 16 e4m3 columns, so the stored width and the row
   // pitch must be multiples of that (every shape of the path is: 100, 1024, 2048)
@@ -854,26 +675,24 @@ hipError_t launch_gemm_bf16_variant(int epi, const GemmParams& p, int variant, h
   if (p.f8) {
     if (p.K % 128 != 0 || !p.a_mx || !p.w_scale) return hipErrorInvalidValue;
     switch (epi) {
-      case EPI_BIAS_GELU_BF16: return dispatch_f8<EPI_BIAS_GELU_BF16>(p, variant, s);
-      case EPI_BIAS_GELU_F8: return dispatch_f8<EPI_BIAS_GELU_F8>(p, variant, s);
-      case EPI_BIAS_F32: return dispatch_f8<EPI_BIAS_F32>(p, variant, s);
-      case EPI_GATE_RES: return dispatch_f8<EPI_GATE_RES>(p, variant, s);
-      case EPI_QK_ROPE: return dispatch_f8<EPI_QK_ROPE>(p, variant, s);
-      case EPI_V_T: return dispatch_f8<EPI_V_T>(p, variant, s);
-      case EPI_NONE: return dispatch_f8<EPI_NONE>(p, variant, s);
+      case EPI_BIAS_GELU_BF16: return dispatch<EPI_BIAS_GELU_BF16, true>(p, tile, s);
+      case EPI_BIAS_GELU_F8: return dispatch<EPI_BIAS_GELU_F8, true>(p, tile, s);
+      case EPI_BIAS_F32: return dispatch<EPI_BIAS_F32, true>(p, tile, s);
+      case EPI_GATE_RES: return dispatch<EPI_GATE_RES, true>(p, tile, s);
+      case EPI_QK_ROPE: return dispatch<EPI_QK_ROPE, true>(p, tile, s);
+      case EPI_V_T: return dispatch<EPI_V_T, true>(p, tile, s);
     }
     return hipErrorInvalidValue;
   }
   switch (epi) {
-    case EPI_BIAS_BF16: return dispatch<EPI_BIAS_BF16>(p, variant, s);
-    case EPI_BIAS_GELU_BF16: return dispatch<EPI_BIAS_GELU_BF16>(p, variant, s);
-    case EPI_BIAS_F32: return dispatch<EPI_BIAS_F32>(p, variant, s);
-    case EPI_GATE_RES: return dispatch<EPI_GATE_RES>(p, variant, s);
-    case EPI_QK_ROPE: return dispatch<EPI_QK_ROPE>(p, variant, s);
-    case EPI_V_T: return dispatch<EPI_V_T>(p, variant, s);
-    case EPI_NONE: return dispatch<EPI_NONE>(p, variant, s);
+    case EPI_BIAS_BF16: return dispatch<EPI_BIAS_BF16, false>(p, tile, s);
+    case EPI_BIAS_GELU_BF16: return dispatch<EPI_BIAS_GELU_BF16, false>(p, tile, s);
+    case EPI_BIAS_F32: return dispatch<EPI_BIAS_F32, false>(p, tile, s);
+    case EPI_GATE_RES: return dispatch<EPI_GATE_RES, false>(p, tile, s);
+    case EPI_QK_ROPE: return dispatch<EPI_QK_ROPE, false>(p, tile, s);
+    case EPI_V_T: return dispatch<EPI_V_T, false>(p, tile, s);
   }
   return hipErrorInvalidValue;
 }
 
-hipError_t launch_gemm_bf16(int epi, const GemmParams& p, hipStream_t s) { return launch_gemm_bf16_variant(epi, p, 0, s); }
+hipError_t launch_gemm_bf16(int epi, const GemmParams& p, hipStream_t s) { return launch_gemm_bf16_tile(epi, p, 0, s); }

@@ -152,7 +152,7 @@ def test_fp8_sampler_vs_emulation_and_reference_golden(golden_dir, name):
     steps (dt 0.3 / 0.6) carry the ~1 % e4m3 flow error almost undamped (the emulation itself sits at 3.6e-4 from the
     reference), so it gets 1e-3 here and the NFE-32 case below is the one the stated tolerance applies to."""
     from oracle import lemas_oracle as O
-    import test_gpu_sample as T
+    import test_gpu_00_sample as T
     fx, arch, sd = T._load(golden_dir, name)
     m = _fp8_model(arch, int(fx["vocab"]), sd, bool(fx["prosody"]))
     args, kw = _golden_args(fx)
@@ -187,7 +187,7 @@ def test_fp8_full_depth_nfe32_within_reference_tolerance():
 
 
 def test_fp8_graph_eager_dual_bit_identical(golden_dir):
-    import test_gpu_sample as T
+    import test_gpu_00_sample as T
     fx, arch, sd = T._load(golden_dir, "mini_plain")
     m = _fp8_model(arch, int(fx["vocab"]), sd)
     outs = []
@@ -204,7 +204,7 @@ def test_fp8_graph_eager_dual_bit_identical(golden_dir):
 
 def test_fp8_switch_is_reversible_and_changes_the_numbers(golden_dir):
     """option "fp8" really switches the GEMM path (outputs differ from bf16) and switching back restores the bf16 bits"""
-    import test_gpu_sample as T
+    import test_gpu_00_sample as T
     from lemas_tts_amd.model.cfm import CFM
     fx, arch, sd = T._load(golden_dir, "mini_plain")
     m = CFM(arch, int(fx["vocab"]), sd, device=DEV)
@@ -225,7 +225,7 @@ def test_config5_fp8_speech_edit_30s_three_spans():
     from oracle import lemas_oracle as O
     from lemas_tts_amd import synth
     from lemas_tts_amd.model.layout import DiTArch
-    import test_gpu_configs as Cf
+    import test_gpu_06_configs as Cf
     arch = DiTArch(depth=2)
     sd = synth.synth_cfm_state_dict(arch, Cf.VOCAB, 71)
     nw = 720000
@@ -251,7 +251,7 @@ def test_fp8_flow_error_full_size():
     from oracle import lemas_oracle as O
     from lemas_tts_amd import synth
     from lemas_tts_amd.model.layout import DiTArch
-    import test_gpu_configs as Cf
+    import test_gpu_06_configs as Cf
     arch = DiTArch()
     sd = synth.synth_cfm_state_dict(arch, Cf.VOCAB, 1234)
     F_, N = 938, 1875

@@ -82,7 +82,7 @@ def test_config4_batch8_equal_length():
 def test_config5_speech_edit_30s_three_spans():
     """configs[4]: 30 s source, 3 edit spans, the LAST two steps of the NFE-48 grid (the first steps of a sway-warped
     grid have dt ~ 1e-7 and would make any comparison vacuous), whole utterance vocoded.  bf16 operands here; the fp8-weights
-    variant of the same case is tests/test_gpu_fp8.py::test_config5_fp8_speech_edit_30s_three_spans."""
+    variant of the same case is tests/test_gpu_02_fp8.py::test_config5_fp8_speech_edit_30s_three_spans."""
     from lemas_tts_amd.engine import VocosEngine
     from lemas_tts_amd.model.cfm import CFM
     from oracle import lemas_oracle as O

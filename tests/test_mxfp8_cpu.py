@@ -1,5 +1,5 @@
 """CPU tier: the MXFP8 quantisation scheme of the fp8 GEMM variant as the oracle restates it (oracle/mxfp8.py).
-The GPU tier checks the HIP quantisers bit-for-bit against these functions (tests/test_gpu_fp8.py)."""
+The GPU tier checks the HIP quantisers bit-for-bit against these functions (tests/test_gpu_02_fp8.py)."""
 import numpy as np
 import torch
 

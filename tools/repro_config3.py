@@ -1,4 +1,4 @@
-"""Reproducer for the round-1 driver failure (tests/test_gpu_configs.py::test_config3..., mel-MSE 0.109 on a fresh box).
+"""Reproducer for the round-1 driver failure (tests/test_gpu_06_configs.py::test_config3..., mel-MSE 0.109 on a fresh box).
 
 Runs the config3 shape (B = 8 ragged, prosody, sway, depth 2, 3 steps) several times in ONE process under different engine
 options and compares the results bit for bit against the eager single-stream run; --oracle also checks that run against the
