@@ -90,6 +90,10 @@ void lemas_dit_destroy(lemas_dit* m);
  *   "transformer.text_embed.freqs_cis" [4096, text_dim]  (modules.py:196-207)
  *   "transformer.time_embed.freqs"     [time_freq_dim/2] (modules.py:157-158) */
 int lemas_dit_load_weight(lemas_dit* m, const char* name, const float* host_data, const int64_t* shape, int32_t ndim);
+/* the same with the tensor already in DEVICE memory on the current device (fp32, contiguous; complete on entry): the form the
+ * data-parallel launcher uses after the RCCL weight broadcast, so that non-source ranks never stage weights through the host
+ * (precedent for per-GPU workers: uvr5/multiprocess_cuda_infer.py:404-420) */
+int lemas_dit_load_weight_device(lemas_dit* m, const char* name, const float* device_data, const int64_t* shape, int32_t ndim);
 int lemas_dit_finalize(lemas_dit* m);
 /* options: "graph" (1 = replay one captured hipGraph per ODE step, default 1), "profile" (1 = per-kernel events),
  * "table_cache" (1 = keep the time/AdaLN tables while the t-grid is unchanged, default 1),
@@ -115,6 +119,7 @@ int lemas_vocos_create(int32_t input_channels, int32_t dim, int32_t intermediate
                        int32_t hop_length, lemas_vocos** out);
 void lemas_vocos_destroy(lemas_vocos* v);
 int lemas_vocos_load_weight(lemas_vocos* v, const char* name, const float* host_data, const int64_t* shape, int32_t ndim);
+int lemas_vocos_load_weight_device(lemas_vocos* v, const char* name, const float* device_data, const int64_t* shape, int32_t ndim);
 int lemas_vocos_finalize(lemas_vocos* v);
 /* mel device [B, C, L] fp32 -> wav device [B, hop*(L-1)] fp32; `gain` multiplies the waveform (rms rescale,
  * utils_infer.py:552-553; pass 1.0 for none) */

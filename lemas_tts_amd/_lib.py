@@ -57,6 +57,7 @@ def lib():
         "lemas_dit_create": (C.c_int, [C.POINTER(DitConfig), C.POINTER(vp)]),
         "lemas_dit_destroy": (None, [vp]),
         "lemas_dit_load_weight": (C.c_int, [vp, C.c_char_p, vp, C.POINTER(i64), i32]),
+        "lemas_dit_load_weight_device": (C.c_int, [vp, C.c_char_p, vp, C.POINTER(i64), i32]),
         "lemas_dit_finalize": (C.c_int, [vp]),
         "lemas_dit_set_option": (C.c_int, [vp, C.c_char_p, i64]),
         "lemas_dit_sample": (C.c_int, [vp, C.POINTER(SampleArgs), vp]),
@@ -67,6 +68,7 @@ def lib():
         "lemas_vocos_create": (C.c_int, [i32, i32, i32, i32, i32, i32, C.POINTER(vp)]),
         "lemas_vocos_destroy": (None, [vp]),
         "lemas_vocos_load_weight": (C.c_int, [vp, C.c_char_p, vp, C.POINTER(i64), i32]),
+        "lemas_vocos_load_weight_device": (C.c_int, [vp, C.c_char_p, vp, C.POINTER(i64), i32]),
         "lemas_vocos_finalize": (C.c_int, [vp]),
         "lemas_vocos_decode": (C.c_int, [vp, vp, i32, i32, f32, vp, vp]),
         "lemas_mel_create": (C.c_int, [i32, i32, i32, i32, C.POINTER(vp)]),
@@ -104,7 +106,7 @@ def lib():
 
 
 EXPORTED = [
-    "lemas_last_error", "lemas_version", "lemas_dit_create", "lemas_dit_destroy", "lemas_dit_load_weight",
+    "lemas_last_error", "lemas_version", "lemas_dit_create", "lemas_dit_destroy", "lemas_dit_load_weight", "lemas_dit_load_weight_device", "lemas_vocos_load_weight_device",
     "lemas_dit_finalize", "lemas_dit_set_option", "lemas_dit_sample", "lemas_dit_prepare", "lemas_dit_solve",
     "lemas_dit_forward", "lemas_dit_profile_read", "lemas_vocos_create", "lemas_vocos_destroy",
     "lemas_vocos_load_weight", "lemas_vocos_finalize", "lemas_vocos_decode", "lemas_mel_create", "lemas_mel_destroy",

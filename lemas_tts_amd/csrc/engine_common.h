@@ -81,7 +81,9 @@ struct WeightStore {
   std::map<std::string, std::vector<int64_t>> schema;
   std::map<std::string, Tensor> t;
   void declare(const std::string& name, std::vector<int64_t> shape) { schema[name] = std::move(shape); }
-  int load(const char* name, const float* host, const int64_t* shape, int ndim);
+  // `src` is host memory, or (on_device) a device address on the current device, e.g. a view of the flat buffer that arrived
+  // by RCCL broadcast (parallel.py): then the tensor never touches the host
+  int load(const char* name, const float* src, const int64_t* shape, int ndim, bool on_device = false);
   int check_complete() const;
   const Tensor* find(const std::string& name) const {
     auto it = t.find(name);

@@ -29,7 +29,7 @@ int kernels_init() {
   return 0;
 }
 
-int WeightStore::load(const char* name, const float* host, const int64_t* shape, int ndim) {
+int WeightStore::load(const char* name, const float* src, const int64_t* shape, int ndim, bool on_device) {
   auto it = schema.find(name);
   if (it == schema.end()) {
     set_error("unexpected tensor '%s' (strict load)", name);
@@ -52,7 +52,9 @@ int WeightStore::load(const char* name, const float* host, const int64_t* shape,
   // +64 floats of slack: the fp32 GEMM reads whole float4 groups of offset sub-matrices (input_embed.proj columns)
   HIP_TRY(hipMalloc((void**)&x.dev, (numel + 64) * sizeof(float)));
   HIP_TRY(zero_fill_sync(x.dev, (numel + 64) * sizeof(float)));
-  HIP_TRY(hipMemcpy(x.dev, host, numel * sizeof(float), hipMemcpyHostToDevice));
+  // synchronous on the NULL stream in both cases; a device source written on another stream must be complete before the call
+  HIP_TRY(hipMemcpy(x.dev, src, numel * sizeof(float), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+  if (on_device) HIP_TRY(hipStreamSynchronize(nullptr));
   x.shape.assign(shape, shape + ndim);
   x.numel = numel;
   return 0;

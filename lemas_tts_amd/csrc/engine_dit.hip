@@ -19,9 +19,9 @@
 
 namespace lemas {
 
-enum ProfClass { PC_INPROJ, PC_CONVPOS, PC_LN, PC_GEMM_QK, PC_GEMM_V, PC_ATTN, PC_GEMM_OUT, PC_GEMM_FF1, PC_GEMM_FF2, PC_GEMM_FINAL,
+enum ProfClass { PC_INPROJ, PC_CONVPOS, PC_LN, PC_GEMM_QKV, PC_GEMM_QK, PC_GEMM_V, PC_ATTN, PC_GEMM_OUT, PC_GEMM_FF1, PC_GEMM_FF2, PC_GEMM_FINAL,
                  PC_CFG_EULER, PC_COUNT };
-static const char* kProfNames[PC_COUNT] = {"inproj_f32", "convpos", "ln_mod", "gemm_qk_rope", "gemm_v_t", "attention", "gemm_attn_out",
+static const char* kProfNames[PC_COUNT] = {"inproj_f32", "convpos", "ln_mod", "gemm_qkv_fused", "gemm_qk_rope", "gemm_v_t", "attention", "gemm_attn_out",
                                            "gemm_ff1_gelu", "gemm_ff2", "gemm_proj_out", "cfg_euler"};
 
 struct BlockW {
@@ -585,9 +585,10 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     // one launch for QK and V only while all of its workgroups fit the chip in one round (128 + 64 at configs[1]); beyond that two
     // separately tiled launches pack better (measured: -5 % at N = 2814 and at batch 8 when fused regardless)
     const long qkv_wgs = (long)((rows + 255) / 256) * (3 * in / 128);
-    const bool fuse_qkv = qkv_fused && !profile && lanes == 2 && qkv_wgs <= 250;
+    const bool fuse_qkv = qkv_fused && lanes == 2 && qkv_wgs <= 250;
     if (fuse_qkv) {
       GemmParams gq = g, gv = g;
+      RC_TRY(pkernel(PC_GEMM_QKV, &gq.ev_start, &gq.ev_stop));
       operands(hbf, h8, hmx, w.wqkv, w.wqkv8, w.sqkv, 0, d);
       gq.A = g.A; gq.a_mx = g.a_mx; gq.W = g.W; gq.w_scale = g.w_scale;
       gq.bias = w.bqkv.as<float>(); gq.N = 2 * in; gq.K = d; gq.n_valid = 2 * in; gq.kv_len = nullptr;
@@ -739,15 +740,21 @@ int lemas_dit_create(const lemas_dit_config* cfg, lemas_dit** out) {
 }
 void lemas_dit_destroy(lemas_dit* m) { delete m; }
 
-int lemas_dit_load_weight(lemas_dit* m, const char* name, const float* host, const int64_t* shape, int32_t ndim) {
-  if (!m || !name || !host) { set_error("lemas_dit_load_weight: null argument"); return LEMAS_E_ARG; }
+static int dit_load(lemas_dit* m, const char* name, const float* src, const int64_t* shape, int32_t ndim, bool on_device) {
+  if (!m || !name || !src) { set_error("lemas_dit_load_weight: null argument"); return LEMAS_E_ARG; }
   // loaded-but-unused tensors of the reference checkpoint (cfm.py:171 accent classifier) are accepted and dropped
   if (strncmp(name, "accent_classifier.", 18) == 0) return 0;
   // a (re)loaded tensor lives at a new address: nothing prepared or captured on the old weights may be replayed
   m->finalized = false;
   m->prepared = false;
   m->drop_graphs();
-  return m->ws.load(name, host, shape, ndim);
+  return m->ws.load(name, src, shape, ndim, on_device);
+}
+int lemas_dit_load_weight(lemas_dit* m, const char* name, const float* host, const int64_t* shape, int32_t ndim) {
+  return dit_load(m, name, host, shape, ndim, false);
+}
+int lemas_dit_load_weight_device(lemas_dit* m, const char* name, const float* dev, const int64_t* shape, int32_t ndim) {
+  return dit_load(m, name, dev, shape, ndim, true);
 }
 int lemas_dit_finalize(lemas_dit* m) { return m ? m->finalize() : LEMAS_E_ARG; }
 

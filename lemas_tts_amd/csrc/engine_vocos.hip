@@ -123,11 +123,17 @@ int lemas_vocos_create(int32_t input_channels, int32_t dim, int32_t intermediate
   return 0;
 }
 void lemas_vocos_destroy(lemas_vocos* v) { delete v; }
-int lemas_vocos_load_weight(lemas_vocos* v, const char* name, const float* host, const int64_t* shape, int32_t ndim) {
-  if (!v || !name || !host) return LEMAS_E_ARG;
+static int vocos_load(lemas_vocos* v, const char* name, const float* src, const int64_t* shape, int32_t ndim, bool on_device) {
+  if (!v || !name || !src) return LEMAS_E_ARG;
   if (strncmp(name, "feature_extractor.", 18) == 0) return 0;  // mel front-end of the vocos checkpoint: not used by decode
   v->finalized = false;
-  return v->ws.load(name, host, shape, ndim);
+  return v->ws.load(name, src, shape, ndim, on_device);
+}
+int lemas_vocos_load_weight(lemas_vocos* v, const char* name, const float* host, const int64_t* shape, int32_t ndim) {
+  return vocos_load(v, name, host, shape, ndim, false);
+}
+int lemas_vocos_load_weight_device(lemas_vocos* v, const char* name, const float* dev, const int64_t* shape, int32_t ndim) {
+  return vocos_load(v, name, dev, shape, ndim, true);
 }
 int lemas_vocos_finalize(lemas_vocos* v) { return v ? v->finalize() : LEMAS_E_ARG; }
 int lemas_vocos_decode(lemas_vocos* v, const float* mel, int32_t batch, int32_t frames, float gain, float* wav, void* stream) {

@@ -639,7 +639,10 @@ struct LaunchQkv {
   }
   static hipError_t run(const GemmParams& pq, const GemmParams& pv, hipStream_t s) {
     const int tiles_q = ((pq.M + 255) / 256) * (pq.N / 128), tiles_v = ((pv.M + 255) / 256) * (pv.N / 128);
-    hipLaunchKernelGGL((gemm_qkv_fused_kernel<F8>), dim3(tiles_q + tiles_v), dim3(512), lds, s, pq, pv, tiles_q, tiles_v);
+    if (pq.ev_start)
+      hipExtLaunchKernelGGL((gemm_qkv_fused_kernel<F8>), dim3(tiles_q + tiles_v), dim3(512), lds, s, pq.ev_start, pq.ev_stop, 0, pq, pv, tiles_q, tiles_v);
+    else
+      hipLaunchKernelGGL((gemm_qkv_fused_kernel<F8>), dim3(tiles_q + tiles_v), dim3(512), lds, s, pq, pv, tiles_q, tiles_v);
     return hipGetLastError();
   }
 };

@@ -23,7 +23,15 @@ def _as_f32_host(v) -> np.ndarray:
     return np.ascontiguousarray(np.asarray(v, dtype=np.float32))
 
 
-def _load(fn, handle, name: str, arr) -> None:
+def _load(fn, handle, name: str, arr, fn_device=None) -> None:
+    """Hand one tensor to the library: host fp32 array, or -- when ``arr`` is a CUDA tensor and the engine has a device-side
+    loader -- the device pointer itself (weights that arrived by RCCL broadcast stay on the device)."""
+    if fn_device is not None and isinstance(arr, torch.Tensor) and arr.is_cuda:
+        t = arr.detach().to(torch.float32).contiguous()
+        torch.cuda.current_stream(t.device).synchronize()      # the loader copies on the NULL stream
+        shape = (C.c_int64 * t.ndim)(*t.shape)
+        _lib.check(fn_device(handle, name.encode(), C.c_void_p(t.data_ptr()), shape, t.ndim), f"load_weight_device({name})")
+        return
     a = _as_f32_host(arr)
     shape = (C.c_int64 * a.ndim)(*a.shape)
     _lib.check(fn(handle, name.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim), f"load_weight({name})")
@@ -81,7 +89,7 @@ class DiTEngine(_Streamed):
                     continue  # the prosody ENCODER is a "next" row; mel_spec keys are dropped by the reference loader
                 if not prosody and (name.startswith("prosody_to_mel.") or ".prosody_text_proj." in name):
                     raise _lib.LemasError(f"checkpoint has prosody tensor '{name}' but the model was built without it")
-                _load(L.lemas_dit_load_weight, self._h, name, v)
+                _load(L.lemas_dit_load_weight, self._h, name, v, L.lemas_dit_load_weight_device)
             for name, v in _aux_tables(arch).items():
                 _load(L.lemas_dit_load_weight, self._h, name, v)
             _lib.check(L.lemas_dit_finalize(self._h), "lemas_dit_finalize")
@@ -206,7 +214,7 @@ class VocosEngine(_Streamed):
             _lib.check(L.lemas_vocos_create(arch.input_channels, arch.dim, arch.intermediate_dim, arch.num_layers,
                                             arch.n_fft, arch.hop_length, C.byref(self._h)), "lemas_vocos_create")
             for name, v in state_dict.items():
-                _load(L.lemas_vocos_load_weight, self._h, name, v)
+                _load(L.lemas_vocos_load_weight, self._h, name, v, L.lemas_vocos_load_weight_device)
             _lib.check(L.lemas_vocos_finalize(self._h), "lemas_vocos_finalize")
 
     def close(self):

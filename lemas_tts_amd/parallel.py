@@ -36,23 +36,33 @@ def _shapes(arch, vocab, vocos: bool, prosody: bool):
 def broadcast_state_dict(sd: Optional[dict], arch, vocab, device, dist, *, vocos: bool = False, prosody: bool = False,
                          src: int = 0) -> dict:
     """Rank ``src`` holds ``sd`` (name -> fp32 array); every rank returns the same dict.  One flat fp32 buffer, one
-    broadcast (~1.35 GB for the DiT: a single large collective suits per-link-bound xGMI rings)."""
+    broadcast (~1.35 GB for the DiT: a single large collective suits per-link-bound xGMI rings).
+
+    With a CUDA ``device`` (backend ``nccl`` = RCCL) the returned values are VIEWS of that flat device buffer: the engines
+    load them with ``lemas_*_load_weight_device`` (device-to-device), so only rank ``src`` ever stages the weights through host
+    memory -- that is what the broadcast buys over every rank reading the checkpoint.  With ``device="cpu"`` (the gloo rehearsal
+    of the N > 1 path) numpy arrays come back, as from a checkpoint file."""
     shapes = _shapes(arch, vocab, vocos, prosody)
     total = int(sum(int(np.prod(s)) for s in shapes.values()))
     dev = torch.device(device)
     flat = torch.empty(total, dtype=torch.float32, device=dev)
     if dist.get_rank() == src:
+        host = np.empty(total, dtype=np.float32)
         off = 0
         for name, shp in shapes.items():
-            a = torch.as_tensor(np.asarray(sd[name], dtype=np.float32)).reshape(-1)
-            flat[off: off + a.numel()] = a.to(dev)
-            off += a.numel()
+            a = np.asarray(sd[name], dtype=np.float32).reshape(-1)
+            assert a.size == int(np.prod(shp)), name
+            host[off: off + a.size] = a
+            off += a.size
+        flat.copy_(torch.from_numpy(host))          # ONE host-to-device copy on the source rank
     dist.broadcast(flat, src=src)
-    host = flat.cpu()
+    if dev.type == "cuda":
+        torch.cuda.current_stream(dev).synchronize()
     out, off = {}, 0
     for name, shp in shapes.items():
         n = int(np.prod(shp))
-        out[name] = host[off: off + n].reshape(shp).numpy()
+        view = flat[off: off + n].reshape(tuple(shp))
+        out[name] = view if dev.type == "cuda" else view.numpy()
         off += n
     return out
 

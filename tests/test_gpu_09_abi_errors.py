@@ -142,3 +142,59 @@ def test_create_destroy_cycles_do_not_leak_device_memory():
     gc.collect(); torch.cuda.synchronize()
     free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 < 64 << 20, (free0, free1)          # < 64 MiB drift (torch's own caching allocator noise), not 12 x engine size
+
+
+def test_device_resident_weights_and_reload_after_finalize():
+    """lemas_*_load_weight_device (what the data-parallel launcher uses after the RCCL broadcast): an engine built from DEVICE
+    tensors gives the same bits as one built from host arrays; reloading a weight on a live handle invalidates what was
+    prepared / captured on the old tensors (no replay of a graph that baked freed addresses)."""
+    from lemas_tts_amd.engine import DiTEngine, VocosEngine
+    from lemas_tts_amd.model.cfm import CFM
+    arch = DiTArch(depth=2)
+    sd = synth.synth_cfm_state_dict(arch, 898, 77)
+    cond = torch.from_numpy(synth.synth_cond_mel(78, 40))[None]
+    text = torch.from_numpy(synth.synth_tokens(79, 12, 898))[None]
+    y0 = torch.from_numpy(synth.synth_noise(80, 96))[None]
+    kw = dict(steps=3, cfg_strength=2.0, sway_sampling_coef=5, y0=y0, use_acc_grl=False)
+    host = CFM(arch, 898, sd, device="cuda:0")
+    a, _ = host.sample(cond, text, 96, **kw)
+    flat = {k: torch.from_numpy(np.ascontiguousarray(v)).to("cuda:0") for k, v in sd.items()}
+    devm = CFM(arch, 898, flat, device="cuda:0")
+    b, _ = devm.sample(cond, text, 96, **kw)
+    np.testing.assert_array_equal(a.cpu().numpy(), b.cpu().numpy())
+    vsd = synth.synth_vocos_state_dict(81)
+    mel = a[:, 40:, :].permute(0, 2, 1)
+    w1 = VocosEngine(vsd, device="cuda:0").decode(mel)
+    w2 = VocosEngine({k: torch.from_numpy(np.ascontiguousarray(v)).to("cuda:0") for k, v in vsd.items()}, device="cuda:0").decode(mel)
+    np.testing.assert_array_equal(w1.cpu().numpy(), w2.cpu().numpy())
+
+    # reload on a live handle: same shape sampled before (a graph for it is cached), new weights must take effect
+    sd2 = synth.synth_cfm_state_dict(arch, 898, 177)
+    L, eng = _lib.lib(), host.engine
+    name = "transformer.transformer_blocks.0.attn.to_out.0.weight"
+    w = np.ascontiguousarray(sd2[name], dtype=np.float32)
+    shp = (C.c_int64 * w.ndim)(*w.shape)
+    assert L.lemas_dit_load_weight(eng._h, name.encode(), w.ctypes.data_as(C.c_void_p), shp, w.ndim) == 0
+    with pytest.raises(_lib.LemasError):          # not finalized again yet
+        host.sample(cond, text, 96, **kw)
+    assert L.lemas_dit_finalize(eng._h) == 0
+    c, _ = host.sample(cond, text, 96, **kw)
+    sd_mixed = dict(sd)
+    sd_mixed[name] = sd2[name]
+    ref, _ = CFM(arch, 898, sd_mixed, device="cuda:0").sample(cond, text, 96, **kw)
+    np.testing.assert_array_equal(c.cpu().numpy(), ref.cpu().numpy())
+    assert not np.array_equal(c.cpu().numpy(), a.cpu().numpy())
+
+
+def test_token_ids_outside_the_vocabulary_raise_like_nn_embedding():
+    from lemas_tts_amd.model.cfm import CFM
+    arch = DiTArch(depth=1)
+    m = CFM(arch, 50, synth.synth_cfm_state_dict(arch, 50, 3), device="cuda:0")
+    cond = torch.from_numpy(synth.synth_cond_mel(4, 30))[None]
+    y0 = torch.from_numpy(synth.synth_noise(5, 64))[None]
+    for bad in (50, 1000, -2):
+        text = torch.tensor([[1, 2, bad, 3]])
+        with pytest.raises(IndexError):
+            m.sample(cond, text, 64, steps=2, cfg_strength=2.0, y0=y0, use_acc_grl=False)
+    out, _ = m.sample(cond, torch.tensor([[1, 2, 49, -1]]), 64, steps=2, cfg_strength=2.0, y0=y0, use_acc_grl=False)
+    assert torch.isfinite(out).all()
