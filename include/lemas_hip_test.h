@@ -52,6 +52,11 @@ int lemas_k_convpos(const float* x, const float* w1, const float* b1, const floa
 int lemas_k_gemm_epi(int32_t epi, int32_t tile, const float* A, const float* W, const float* bias, const float* aux,
                      const int32_t* seq_len, float* out, int32_t batch, int32_t pitch, int32_t frames, int32_t N, int32_t K, void* stream);
 
+/* measurement hook for A/B runs: force the tile shape the dispatch picks for bf16 GEMMs with N == 1024 / N == 2048 (ids as in
+ * lemas_k_gemm_epi) and the XCD block grid of the tile order (8 = row-major, 4, 2, 1); 0 = production choice.  Process-global;
+ * cached hipGraphs are NOT invalidated -- set it before sampling. */
+int lemas_k_tile_override(int32_t n1024, int32_t n2048, int32_t xcd_gx);
+
 /* micro-benchmark of one step-loop kernel on synthetic operands: what = "gemm_gelu" | "gemm_gate" | "gemm_qk" | "gemm_v" |
  * "gemm_f32out" (M,N,K = GEMM shape; prefix "f8_" for the MXFP8 path) or "attention" (M = frames, N = batch*heads); returns
  * the average launch duration in microseconds over `iters` back-to-back launches (HIP events).  `variant` = GEMM tile as

@@ -122,6 +122,9 @@ struct GemmParams {
   // how many launches of this size run concurrently (the CFG lanes): the tile heuristic aims at ~256 / concurrency
   // workgroups, i.e. larger, more efficient tiles when another lane's kernel fills the other half of the chip.  0 = 1.
   int concurrency;
+  // XCD block grid of the tile order: the tile grid is cut into xcd_gx x (8 / xcd_gx) blocks, one per XCD (gemm_bf16.hip
+  // tile_coords).  0 = let the launcher choose (minimises the fabric-side fetch gy * |A| + gx * |W|); 8 = the row-major order.
+  int xcd_gx;
 };
 
 // ---- internal launchers (one per .hip translation unit) ----------------------------------------
@@ -130,6 +133,8 @@ hipError_t launch_gemm_bf16(int epi, const GemmParams& p, hipStream_t s);
 hipError_t launch_gemm_bf16_tile(int epi, const GemmParams& p, int tile, hipStream_t s);
 // one-time > 64 KB dynamic-LDS opt-in of every GEMM instantiation (called from lemas_kernels_init, never on a launch path)
 hipError_t gemm_bf16_init();
+// measurement hook: force the tile of the bf16 GEMMs with N == 1024 / N == 2048 and the XCD block grid (0 = production choice)
+void gemm_bf16_force_tiles(int n1024, int n2048, int xcd_gx);
 // one launch for a lane's QK (+RoPE) and V^T projections (same A, different W / bias / epilogue)
 hipError_t launch_gemm_qkv_fused(const GemmParams& pq, const GemmParams& pv, hipStream_t s);
 

@@ -35,16 +35,31 @@ constexpr int BK = 64;
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-__device__ __forceinline__ int xcd_tile_id() {
-  // XCD-aware tile order: consecutive logical ids (same A row-panel) land on one XCD's L2 (blocks are dispatched
-  // round-robin over the 8 XCDs).  Bijective for any grid size.
-  const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-}
-
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {   // the same bijection for a sub-range of a fused launch
+// XCD-aware tile order.  Workgroups are dispatched round-robin over the 8 XCDs (private, non-coherent L2s), so workgroup `bid` of
+// `nwg` runs on XCD bid & 7.  Step 1 (bijective for any grid size): give every XCD a CONTIGUOUS run of the logical sequence.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+// Step 2: the logical sequence walks the tile grid BLOCK by block, the grid cut into gx x gy blocks (gx * gy = 8), so one XCD's run
+// is (about) one block: it fetches 1/gx of the A panels and 1/gy of the W panels.  With the plain row-major sequence (gx = 8,
+// gy = 1) every XCD streamed ALL of W: PMC FETCH 45.8 MB for the QK GEMM against 15.8 MB algorithmic (profiles/r01o_traffic.json).
+// The host picks (gx, gy) to minimise gy * |A| + gx * |W| (GemmParams::xcd_gx).  Ragged grids: blocks at the edges are smaller.
+__device__ __forceinline__ void tile_coords(int seq, int tiles_m, int tiles_n, int gx, int& tm, int& tn) {
+  const int gy = 8 / gx;
+  const int bm = (tiles_m + gx - 1) / gx, bn = (tiles_n + gy - 1) / gy;
+  tm = tn = 0;
+  for (int bi = 0; bi < gx; ++bi) {
+    const int rows = min(bm, tiles_m - bi * bm);
+    if (rows <= 0) break;
+    for (int bj = 0; bj < gy; ++bj) {
+      const int cols = min(bn, tiles_n - bj * bn);
+      if (cols <= 0) break;
+      const int cnt = rows * cols;
+      if (seq < cnt) { tm = bi * bm + seq / cols; tn = bj * bn + seq % cols; return; }
+      seq -= cnt;
+    }
+  }
 }
 
 template <int N>
@@ -523,28 +538,206 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, int m
   }
 }
 
+// ================================================================================================================
+// 256 x 256 tile, 8 waves, "ping-pong" schedule for the batched shapes (bf16).
+//
+// The loop above has one barrier per K-tile with every wave in the same phase: all waves read LDS together, then all issue
+// MFMAs together, and the matrix pipe idles while the fragment reads are in flight (PMC: busy 52 % of a wave's residency;
+// 0.6-0.75 PFLOP/s at M = 18432).  Here the K-tile is cut into FOUR phases of one 64 x 32 accumulator quadrant each, and the two
+// wave rows (waves 0-3 / 4-7: one of each per SIMD) run ONE BARRIER APART: while one group issues its 8 MFMAs of a phase (256
+// cycles of matrix pipe), the other group does the LDS reads and the LDS-DMA issue of its next phase.  Every phase is
+//      L: fragment reads of this phase's quadrant, LDS-DMA of one half-tile a full K-tile ahead, counted vmcnt for the half-tile
+//         the NEXT phase reads;   s_barrier;   lgkmcnt(0);   M: 8 MFMAs;   s_barrier
+// so each barrier flips the two groups between L and M.  Operands live in LDS as eight 16-KiB half-tiles [K-tile parity][A|W][half]:
+// A half h = the h-th 64 rows of BOTH wave rows, W half h = the h-th 32 columns of all four wave columns, so the quadrant
+// order (A0,W0) (A0,W1) (A1,W1) (A1,W0) needs exactly one new half-tile per phase (two for the first) and each half-tile is
+// read from LDS once per K-tile (24 ds_read_b128 for 32 MFMAs per wave).  Half-tiles arrive by LDS-DMA (two 1-KiB pieces per wave),
+// up to four in flight; vmcnt never drains to 0 inside the loop.
+//
+// Ordering rules (both are what makes the schedule race-free, not just fast):
+//   RAW  a half-tile is waited for (vmcnt) in the L segment of phase p by every wave and read in phase p+1 at the earliest: the
+//        reader has then passed a barrier that follows every wave's wait, for either group;
+//   WAR  the DMA that overwrites buffer [parity][op][half] is issued a full K-tile (>= 2 phases, 4 barriers) after the last
+//        read of its previous content, and those reads were retired by an lgkmcnt(0) before their own MFMA segment.
+template <int EPI, bool SWAP>
+__device__ __forceinline__ void gemm_body_pp(const GemmParams& p, char* smem, int m0, int n0) {
+  constexpr int HT = 16384;                 // bytes per half-tile buffer: 128 rows x 128 B
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wm = wave >> 2, wn = wave & 3;  // 2 (M) x 4 (N) waves, 128 x 64 outputs each
+  const size_t rowb = (size_t)p.K * 2;
+  const int nk = p.K >> 6;
+
+  // ---- DMA sources.  Piece q of a half-tile = local rows 8q .. 8q+7; this wave moves pieces wave and wave + 8.
+  //      A half h, local row r -> tile row (r >> 6) * 128 + h * 64 + (r & 63);  W half h, local row r -> tile col (r >> 5) * 64 + h * 32 + (r & 31)
+  const int lr = lane >> 3, lp = lane & 7;
+  const char* asrc[2][2];
+  const char* wsrc[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int r = 8 * (wave + 8 * q) + lr;
+      const int sw = (lp ^ ((r >> 1) & 7)) << 4;          // the swizzle sits in the SOURCE address (LDS image is lane-linear)
+      int am = m0 + (r >> 6) * 128 + h * 64 + (r & 63);
+      am = am < p.M ? am : p.M - 1;                        // rows past M are computed and discarded
+      asrc[h][q] = reinterpret_cast<const char*>(p.A) + (size_t)am * rowb + sw;
+      wsrc[h][q] = reinterpret_cast<const char*>(p.W) + (size_t)(n0 + (r >> 5) * 64 + h * 32 + (r & 31)) * rowb + sw;
+    }
+  auto issue_half = [&](int op, int h, int t) {            // op 0 = A, 1 = W; t = K-tile
+    char* dst = smem + (((t & 1) * 2 + op) * 2 + h) * HT + wave * 1024;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const char* src = (op == 0 ? asrc[h][q] : wsrc[h][q]) + (size_t)t * 128;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(dst + q * 8192), 16, 0, 0);
+    }
+  };
+
+  // ---- fragment read addresses (byte offsets inside a half-tile buffer); +32 rows = +4096 B, the swizzle is unchanged
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  unsigned aoff[4], boff[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    aoff[kk] = lds_off(wm * 64 + l31, kk * 2 + hi);
+    boff[kk] = lds_off(wn * 32 + l31, kk * 2 + hi);
+  }
+  u32x4 fa[2][4], fb[2][4];      // fa[row block of the half][k-step]; fb[W half][k-step] (both W halves stay resident)
+  auto read_a = [&](int t, int h) {
+    const unsigned b = lds_base + (((t & 1) * 2 + 0) * 2 + h) * HT;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      lds_read_b128<0>(fa[0][kk], b + aoff[kk]);
+      lds_read_b128<4096>(fa[1][kk], b + aoff[kk]);
+    }
+  };
+  auto read_b = [&](int t, int h, u32x4 (&f)[4]) {
+    const unsigned b = lds_base + (((t & 1) * 2 + 1) * 2 + h) * HT;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) lds_read_b128<0>(f[kk], b + boff[kk]);
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto mma = [&](int ha, int jb, const u32x4 (&f)[4]) {     // the quadrant rows {2 ha, 2 ha + 1} x column block jb, K = 64
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const bf16x8 a = __builtin_bit_cast(bf16x8, fa[i][kk]), b = __builtin_bit_cast(bf16x8, f[kk]);
+        acc[ha * 2 + i][jb] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, acc[ha * 2 + i][jb], 0, 0, 0)
+                                   : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[ha * 2 + i][jb], 0, 0, 0);
+      }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  // end of an L segment: barrier, then this wave's fragment reads must have landed before its MFMAs
+  auto l_to_m = [&]() {
+    __builtin_amdgcn_s_barrier();
+    wait_lgkmcnt<0>();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto m_to_l = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+  };
+
+  // ---- prologue: the four half-tiles of K-tile 0 in consumption order (W0, A0, W1, A1); W0 and A0 must have landed
+  issue_half(1, 0, 0); issue_half(0, 0, 0); issue_half(1, 1, 0); issue_half(0, 1, 0);
+  wait_vmcnt<4>();
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();     // stagger: the second wave row runs one barrier behind the first
+
+  for (int t = 0; t < nk; ++t) {
+    const bool more = t + 1 < nk;
+    // phase 0: quadrant (A0, W0); prefetch W0 of the next K-tile; W1 of this K-tile must land for phase 1
+    read_b(t, 0, fb[0]);
+    read_a(t, 0);
+    if (more) { issue_half(1, 0, t + 1); wait_vmcnt<4>(); } else wait_vmcnt<2>();
+    l_to_m();
+    mma(0, 0, fb[0]);
+    m_to_l();
+    // phase 1: (A0, W1); prefetch A0'; A1 must land for phase 2
+    read_b(t, 1, fb[1]);
+    if (more) { issue_half(0, 0, t + 1); wait_vmcnt<4>(); } else wait_vmcnt<0>();
+    l_to_m();
+    mma(0, 1, fb[1]);
+    m_to_l();
+    // phase 2: (A1, W1); prefetch W1'
+    read_a(t, 1);
+    if (more) issue_half(1, 1, t + 1);
+    l_to_m();
+    mma(1, 1, fb[1]);
+    m_to_l();
+    // phase 3: (A1, W0), no LDS reads; prefetch A1'; W0' and A0' must land for the next phase 0
+    if (more) { issue_half(0, 1, t + 1); wait_vmcnt<4>(); }
+    l_to_m();
+    mma(1, 0, fb[0]);
+    m_to_l();
+  }
+  if (wm == 0) __builtin_amdgcn_s_barrier();     // the first wave row catches up: equal barrier counts for all waves
+  __syncthreads();   // every wave is done with the half-tiles: the LDS becomes the epilogue slabs
+  char* slab = smem + wave * slab_bytes<EPI, 32, 64>();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f32x16 (&blk)[1][2] = *reinterpret_cast<f32x16 (*)[1][2]>(&acc[i]);
+    if (SWAP) epilogue_rows<EPI, 1, 2>(p, blk, slab, m0 + wm * 128 + 32 * i, n0 + wn * 64, lane);
+    else epilogue_vt<1, 2>(p, blk, slab, m0 + wm * 128 + 32 * i, n0 + wn * 64, lane);
+  }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int tm, tn;
+  tile_coords(xcd_remap(blockIdx.x, gridDim.x), (p.M + 255) / 256, p.N / 256, p.xcd_gx, tm, tn);
+  gemm_body_pp<EPI, EPI != EPI_V_T>(p, smem, tm * 256, tn * 256);
+}
+
+template <int EPI>
+struct LaunchPP {
+  static constexpr int lds = 8 * 16384;
+  static_assert(8 * slab_bytes<EPI, 32, 64>() <= lds, "epilogue slabs must fit the half-tile buffers");
+  static hipError_t init() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  }
+  static hipError_t run(const GemmParams& p, hipStream_t s) {
+    if (p.N % 256 != 0 || p.K % 64 != 0) return hipErrorInvalidValue;
+    const dim3 grid(((p.M + 255) / 256) * (p.N / 256)), block(512);
+    if (p.ev_start) hipExtLaunchKernelGGL((gemm_pp_kernel<EPI>), grid, block, lds, s, p.ev_start, p.ev_stop, 0, p);
+    else hipLaunchKernelGGL((gemm_pp_kernel<EPI>), grid, block, lds, s, p);
+    return hipGetLastError();
+  }
+};
+
 template <int EPI, int TBM, int TBN, int NSTAGE, int NWM, int NWN, bool F8>
 __global__ __launch_bounds__(64 * NWM * NWN) void gemm_bf16_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tiles_n = p.N / TBN;
-  const int lid = xcd_tile_id();
-  const int m0 = (lid / tiles_n) * TBM, n0 = (lid % tiles_n) * TBN;
-  gemm_body<EPI, TBM, TBN, NSTAGE, NWM, NWN, EPI != EPI_V_T, F8>(p, smem, m0, n0);
+  int tm, tn;
+  tile_coords(xcd_remap(blockIdx.x, gridDim.x), (p.M + TBM - 1) / TBM, p.N / TBN, p.xcd_gx, tm, tn);
+  gemm_body<EPI, TBM, TBN, NSTAGE, NWM, NWN, EPI != EPI_V_T, F8>(p, smem, tm * TBM, tn * TBN);
 }
 
-// The tile shapes in use.  All run the hand-scheduled loop above.
-//   T256x128: 8 waves (4 x 2), 3-stage ring, 147 KB LDS -- N >= 2048 GEMMs at batch 1
-//   T128x128: 8 waves (2 x 4), 3-stage ring,  96 KB      -- N = 1024 GEMMs at batch 1
-//   T128x64 : 4 waves (2 x 2), 3-stage ring,  72 KB      -- short utterances
-//   T256x256: 8 waves (2 x 4), 2-stage ring, 128 KB      -- batched shapes (several rounds of tiles per CU): 33 % fewer operand
-//             bytes per flop, measured 8-13 % faster per tile area at M = 30720 (bf16 only)
+// The tile shapes in use.
+//   T256x128: 8 waves (4 x 2), 3-stage ring, 147 KB LDS -- N >= 2048 GEMMs at batch 1 (hand-scheduled loop of gemm_body)
+//   T128x128: 8 waves (2 x 4), 3-stage ring,  96 KB      -- mid-size shapes
+//   T128x64 : 4 waves (2 x 2), 3-stage ring,  72 KB      -- N = 1024 GEMMs at batch 1, short utterances (2 workgroups per CU)
+//   T256x256: 8 waves (2 x 4), ping-pong schedule of gemm_body_pp, 128 KB -- batched shapes (several rounds of tiles per CU);
+//             bf16 only.  Its K loop runs at 1.45 PFLOP/s-equivalent per CU (K = 4096: 89 us for 64 tiles); with K = 1024 the
+//             ~12 us of launch + prologue + epilogue per round leave 0.86-1.0 PFLOP/s at M = 30720 (tools/kbench.py)
 enum GemmTile : int { T256x128 = 16, T128x128 = 17, T128x64 = 18, T256x256 = 22 };
 
 template <int TILE> struct TileCfg;
 template <> struct TileCfg<T256x128> { static constexpr int BM = 256, BN = 128, ST = 3, WM = 4, WN = 2; };
 template <> struct TileCfg<T128x128> { static constexpr int BM = 128, BN = 128, ST = 3, WM = 2, WN = 4; };
 template <> struct TileCfg<T128x64>  { static constexpr int BM = 128, BN = 64,  ST = 3, WM = 2, WN = 2; };
-template <> struct TileCfg<T256x256> { static constexpr int BM = 256, BN = 256, ST = 2, WM = 2, WN = 4; };
 
 template <int EPI, int TILE, bool F8>
 struct Launch {
@@ -571,7 +764,11 @@ struct Launch {
 
 // Largest tile that still yields about one workgroup per CU (measured at M = 1920 / 3840 / 18432 with tools/kbench.py).
 // With two CFG lanes in flight each launch only needs half the chip (p.concurrency = 2: +1.8 % end to end for the larger tiles).
+int g_force_n1024 = 0, g_force_n2048 = 0, g_force_gx = 0;   // measurement hook (lemas_k_tile_override, include/lemas_hip_test.h); 0 = off
+
 int pick_tile(const GemmParams& p) {
+  if (!p.f8 && p.N == 1024 && g_force_n1024) return g_force_n1024;
+  if (!p.f8 && p.N == 2048 && g_force_n2048) return g_force_n2048;
   const long conc = p.concurrency > 1 ? p.concurrency : 1;
   const long t256 = (long)((p.M + 255) / 256) * (p.N / 128), t128 = (long)((p.M + 127) / 128) * (p.N / 128);
   const long want = 200 / conc;
@@ -593,7 +790,7 @@ hipError_t dispatch(const GemmParams& p, int tile, hipStream_t s) {
     case T128x128: return Launch<EPI, T128x128, F8>::run(p, s);
     case T128x64: return Launch<EPI, T128x64, F8>::run(p, s);
     case T256x256:
-      if constexpr (!F8) return Launch<EPI, T256x256, false>::run(p, s);
+      if constexpr (!F8) return LaunchPP<EPI>::run(p, s);
       else return hipErrorInvalidValue;
     default: return hipErrorInvalidValue;
   }
@@ -606,7 +803,7 @@ hipError_t init_epi() {
   if ((e = Launch<EPI, T128x128, F8>::init()) != hipSuccess) return e;
   if ((e = Launch<EPI, T128x64, F8>::init()) != hipSuccess) return e;
   if constexpr (!F8) {
-    if ((e = Launch<EPI, T256x256, false>::init()) != hipSuccess) return e;
+    if ((e = LaunchPP<EPI>::init()) != hipSuccess) return e;
   }
   return hipSuccess;
 }
@@ -618,12 +815,13 @@ template <bool F8>
 __global__ __launch_bounds__(512) void gemm_qkv_fused_kernel(const GemmParams pq, const GemmParams pv, int tiles_q, int tiles_v) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int bid = blockIdx.x;
+  int tm, tn;
   if (bid < tiles_q) {
-    const int tn = pq.N / 128, lid = xcd_remap(bid, tiles_q);
-    gemm_body<EPI_QK_ROPE, 256, 128, 3, 4, 2, true, F8>(pq, smem, (lid / tn) * 256, (lid % tn) * 128);
+    tile_coords(xcd_remap(bid, tiles_q), (pq.M + 255) / 256, pq.N / 128, pq.xcd_gx, tm, tn);
+    gemm_body<EPI_QK_ROPE, 256, 128, 3, 4, 2, true, F8>(pq, smem, tm * 256, tn * 128);
   } else {
-    const int tn = pv.N / 128, lid = xcd_remap(bid - tiles_q, tiles_v);
-    gemm_body<EPI_V_T, 256, 128, 3, 4, 2, false, F8>(pv, smem, (lid / tn) * 256, (lid % tn) * 128);
+    tile_coords(xcd_remap(bid - tiles_q, tiles_v), (pv.M + 255) / 256, pv.N / 128, pv.xcd_gx, tm, tn);
+    gemm_body<EPI_V_T, 256, 128, 3, 4, 2, false, F8>(pv, smem, tm * 256, tn * 128);
   }
 }
 
@@ -649,6 +847,8 @@ struct LaunchQkv {
 
 }  // namespace
 
+void gemm_bf16_force_tiles(int n1024, int n2048, int xcd_gx) { g_force_n1024 = n1024; g_force_n2048 = n2048; g_force_gx = xcd_gx; }
+
 hipError_t gemm_bf16_init() {
   hipError_t e;
 #define LEMAS_INIT(EPI)                                                   \
@@ -662,13 +862,30 @@ hipError_t gemm_bf16_init() {
   return LaunchQkv<true>::init();
 }
 
-hipError_t launch_gemm_qkv_fused(const GemmParams& pq, const GemmParams& pv, hipStream_t s) {
+// XCD block grid (gx x 8/gx, see tile_coords): fabric-side fetch ~ gy * |A| + gx * |W| -> minimise gy * M + gx * N
+static int pick_xcd_gx(int M, int N) {
+  if (g_force_gx) return g_force_gx;
+  int best = 8;
+  long cost = -1;
+  for (int gx : {8, 4, 2, 1}) {
+    const long c = (long)(8 / gx) * M + (long)gx * N;
+    if (cost < 0 || c < cost) { cost = c; best = gx; }
+  }
+  return best;
+}
+
+hipError_t launch_gemm_qkv_fused(const GemmParams& pq_in, const GemmParams& pv_in, hipStream_t s) {
+  GemmParams pq = pq_in, pv = pv_in;
+  if (pq.xcd_gx <= 0) pq.xcd_gx = pick_xcd_gx(pq.M, pq.N);
+  if (pv.xcd_gx <= 0) pv.xcd_gx = pick_xcd_gx(pv.M, pv.N);
   if (pq.K % 128 != 0 || pq.N % 128 != 0 || pv.N % 128 != 0 || pq.M != pv.M || pq.f8 != pv.f8 || pq.M <= 0) return hipErrorInvalidValue;
   if (pq.f8 && (!pq.a_mx || !pq.w_scale || !pv.w_scale)) return hipErrorInvalidValue;
   return pq.f8 ? LaunchQkv<true>::run(pq, pv, s) : LaunchQkv<false>::run(pq, pv, s);
 }
 
-hipError_t launch_gemm_bf16_tile(int epi, const GemmParams& p, int tile, hipStream_t s) {
+hipError_t launch_gemm_bf16_tile(int epi, const GemmParams& p_in, int tile, hipStream_t s) {
+  GemmParams p = p_in;
+  if (p.xcd_gx != 8 && p.xcd_gx != 4 && p.xcd_gx != 2 && p.xcd_gx != 1) p.xcd_gx = pick_xcd_gx(p.M, p.N);
   if (p.K % BK != 0 || p.N % 128 != 0 || p.M <= 0 || p.seq_pitch <= 0) return hipErrorInvalidValue;
   // the row-wise epilogues store whole 16-B chunks: 4 fp32 / 8 bf16 / 16 e4m3 columns, so the stored width and the row
   // pitch must be multiples of that (every shape of the path is: 100, 1024, 2048)

@@ -1,0 +1,74 @@
+#!/usr/bin/env python
+"""End-to-end A/B of dispatch choices on one workload (development aid; needs the MI355X): same timing discipline as bench.py
+(hoists + 32 steps + vocoder + D2H per utterance batch), several arms in ONE process on one box, interleaved rounds.
+
+    python tools/e2e_ab.py --workload configs1 --arms default n1024=18 n1024=18,qkv_fused=0 [--rounds 3] [--steps 6]
+
+Arm syntax: comma-separated key=value with keys n1024 / n2048 / gx (GEMM tile ids and XCD block grid, lemas_k_tile_override), qkv_fused, dual, fp8."""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import bench as Bn  # noqa: E402
+from lemas_tts_amd import _lib, synth  # noqa: E402
+from lemas_tts_amd.engine import VocosEngine  # noqa: E402
+from lemas_tts_amd.model.cfm import CFM  # noqa: E402
+from lemas_tts_amd.model.layout import DiTArch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="configs1")
+    ap.add_argument("--arms", nargs="+", default=["default"])
+    ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=6)
+    a = ap.parse_args()
+    w = Bn.WORKLOADS[a.workload]
+    B, F, N = w["B"], w["F"], w["N"]
+    dev = torch.device("cuda:0")
+    arch = DiTArch()
+    sd = synth.synth_cfm_state_dict(arch, Bn.VOCAB, 1234)
+    vocoder = VocosEngine(synth.synth_vocos_state_dict(1234), device=dev)
+    cond, text, y0, _ = Bn.build_inputs(w, 1, dev)
+    L = _lib.lib()
+    host = torch.empty((B, Bn.HOP * (N - F)), dtype=torch.float32).pin_memory()
+    models = {}
+    for arm in a.arms:
+        opts = dict(kv.split("=") for kv in arm.split(",")) if arm != "default" else {}
+        L.lemas_k_tile_override(int(opts.get("n1024", 0)), int(opts.get("n2048", 0)), int(opts.get("gx", 0)))
+        m = CFM(arch, Bn.VOCAB, sd, device=dev)
+        for k in ("qkv_fused", "dual", "fp8"):
+            if k in opts:
+                m.engine.set_option(k, int(opts[k]))
+        m.engine.set_option("table_cache", 0)
+        models[arm] = (m, opts)
+
+    def run(arm, n):
+        m, opts = models[arm]
+        L.lemas_k_tile_override(int(opts.get("n1024", 0)), int(opts.get("n2048", 0)), int(opts.get("gx", 0)))   # graphs are captured on first use of the arm
+        for _ in range(n):
+            out, _ = m.sample(cond, text, N, steps=Bn.NFE, cfg_strength=Bn.CFG, sway_sampling_coef=Bn.SWAY, y0=y0, use_acc_grl=False)
+            host.copy_(vocoder.decode(out[:, F - 1:, :].permute(0, 2, 1)), non_blocking=True)
+        torch.cuda.synchronize()
+
+    for arm in a.arms:
+        run(arm, 2)
+    res = {arm: [] for arm in a.arms}
+    for r in range(a.rounds):
+        for arm in a.arms:
+            t0 = time.perf_counter()
+            run(arm, a.steps)
+            res[arm].append((time.perf_counter() - t0) / a.steps)
+    audio = B * Bn.HOP * (N - F) / Bn.SR
+    for arm in a.arms:
+        best, med = min(res[arm]), sorted(res[arm])[len(res[arm]) // 2]
+        print(f"{a.workload:9s} {arm:28s} median {1e3 * med:8.2f} ms = {audio / med:7.1f} audio-s/s   best {1e3 * best:8.2f} ms = {audio / best:7.1f}")
+    L.lemas_k_tile_override(0, 0, 0)
+
+
+if __name__ == "__main__":
+    main()
