@@ -129,7 +129,7 @@ struct GemmParams {
 
 // ---- internal launchers (one per .hip translation unit) ----------------------------------------
 hipError_t launch_gemm_bf16(int epi, const GemmParams& p, hipStream_t s);
-// explicit tile shape (16 = 256x128, 17 = 128x128, 18 = 128x64, 22 = 256x256; 0 = the production choice): unit tests and kbench
+// explicit tile shape (16 = 256x128, 17 = 128x128, 18 = 128x64, 19 = 64x64, 22 = 256x256; 0 = the production choice): unit tests and kbench
 hipError_t launch_gemm_bf16_tile(int epi, const GemmParams& p, int tile, hipStream_t s);
 // one-time > 64 KB dynamic-LDS opt-in of every GEMM instantiation (called from lemas_kernels_init, never on a launch path)
 hipError_t gemm_bf16_init();

@@ -728,16 +728,18 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_bf16_kernel(const GemmPar
 // The tile shapes in use.
 //   T256x128: 8 waves (4 x 2), 3-stage ring, 147 KB LDS -- N >= 2048 GEMMs at batch 1 (hand-scheduled loop of gemm_body)
 //   T128x128: 8 waves (2 x 4), 3-stage ring,  96 KB      -- mid-size shapes
-//   T128x64 : 4 waves (2 x 2), 3-stage ring,  72 KB      -- N = 1024 GEMMs at batch 1, short utterances (2 workgroups per CU)
+//   T128x64 : 4 waves (2 x 2), 3-stage ring,  72 KB      -- short utterances (2 workgroups per CU)
+//   T64x64  : 4 waves (2 x 2), 3-stage ring,  48 KB      -- N <= 1024 GEMMs of short utterances (M = 768: 8.0 vs 10.2 us, 12.1 vs 15.5 at K = 2048)
 //   T256x256: 8 waves (2 x 4), ping-pong schedule of gemm_body_pp, 128 KB -- batched shapes (several rounds of tiles per CU);
 //             bf16 only.  Its K loop runs at 1.45 PFLOP/s-equivalent per CU (K = 4096: 89 us for 64 tiles); with K = 1024 the
 //             ~12 us of launch + prologue + epilogue per round leave 0.86-1.0 PFLOP/s at M = 30720 (tools/kbench.py)
-enum GemmTile : int { T256x128 = 16, T128x128 = 17, T128x64 = 18, T256x256 = 22 };
+enum GemmTile : int { T256x128 = 16, T128x128 = 17, T128x64 = 18, T64x64 = 19, T256x256 = 22 };
 
 template <int TILE> struct TileCfg;
 template <> struct TileCfg<T256x128> { static constexpr int BM = 256, BN = 128, ST = 3, WM = 4, WN = 2; };
 template <> struct TileCfg<T128x128> { static constexpr int BM = 128, BN = 128, ST = 3, WM = 2, WN = 4; };
 template <> struct TileCfg<T128x64>  { static constexpr int BM = 128, BN = 64,  ST = 3, WM = 2, WN = 2; };
+template <> struct TileCfg<T64x64>   { static constexpr int BM = 64,  BN = 64,  ST = 3, WM = 2, WN = 2; };
 
 template <int EPI, int TILE, bool F8>
 struct Launch {
@@ -773,6 +775,8 @@ int pick_tile(const GemmParams& p) {
   const long t256 = (long)((p.M + 255) / 256) * (p.N / 128), t128 = (long)((p.M + 127) / 128) * (p.N / 128);
   const long want = 200 / conc;
   int tile = t256 >= want ? T256x128 : t128 >= want ? T128x128 : T128x64;
+  // short utterances: when even 128x64 tiles leave most CUs without work, halve the tile height (N <= 1024: out-proj, FF2, V)
+  if (tile == T128x64 && p.N <= 1024 && (long)((p.M + 127) / 128) * (p.N / 64) < 130) tile = T64x64;
   if (!p.f8 && tile == T256x128 && p.N % 256 == 0) {
     // batched workloads: 256x256 when at least two full rounds of them exist and the whole-round count favours them
     const long cus = 256 / conc, tbig = (long)((p.M + 255) / 256) * (p.N / 256);
@@ -789,6 +793,7 @@ hipError_t dispatch(const GemmParams& p, int tile, hipStream_t s) {
     case T256x128: return Launch<EPI, T256x128, F8>::run(p, s);
     case T128x128: return Launch<EPI, T128x128, F8>::run(p, s);
     case T128x64: return Launch<EPI, T128x64, F8>::run(p, s);
+    case T64x64: return Launch<EPI, T64x64, F8>::run(p, s);
     case T256x256:
       if constexpr (!F8) return LaunchPP<EPI>::run(p, s);
       else return hipErrorInvalidValue;
@@ -802,6 +807,7 @@ hipError_t init_epi() {
   if ((e = Launch<EPI, T256x128, F8>::init()) != hipSuccess) return e;
   if ((e = Launch<EPI, T128x128, F8>::init()) != hipSuccess) return e;
   if ((e = Launch<EPI, T128x64, F8>::init()) != hipSuccess) return e;
+  if ((e = Launch<EPI, T64x64, F8>::init()) != hipSuccess) return e;
   if constexpr (!F8) {
     if ((e = LaunchPP<EPI>::init()) != hipSuccess) return e;
   }
@@ -809,41 +815,54 @@ hipError_t init_epi() {
 }
 
 // QK (+RoPE) and V^T projections of one lane in ONE launch: they only share their input, so instead of two launches of ~half
-// a chip each, run back to back, the first tiles_q workgroups take 256x128 QK tiles and the remaining ones 256x128 V tiles
-// (128 + 64 workgroups at configs[1]; measured 0.6 % faster end to end than 128x128 V tiles).
-template <bool F8>
-__global__ __launch_bounds__(512) void gemm_qkv_fused_kernel(const GemmParams pq, const GemmParams pv, int tiles_q, int tiles_v) {
+// a chip each, run back to back, the first tiles_q workgroups take QK tiles and the remaining ones V tiles of the same shape:
+// 256x128 at configs[1] (128 + 64 workgroups; measured 0.6 % faster end to end than 128x128 V tiles), 128x128 / 128x64 for short
+// utterances, where 256-row tiles leave most of the chip idle (N = 750: 72 workgroups, 19.6 us -- as long as at N = 1875).
+template <bool F8, int TILE>
+__global__ __launch_bounds__(64 * TileCfg<TILE>::WM * TileCfg<TILE>::WN) void gemm_qkv_fused_kernel(const GemmParams pq, const GemmParams pv,
+                                                                                                      int tiles_q, int tiles_v) {
+  using C = TileCfg<TILE>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int bid = blockIdx.x;
   int tm, tn;
   if (bid < tiles_q) {
-    tile_coords(xcd_remap(bid, tiles_q), (pq.M + 255) / 256, pq.N / 128, pq.xcd_gx, tm, tn);
-    gemm_body<EPI_QK_ROPE, 256, 128, 3, 4, 2, true, F8>(pq, smem, tm * 256, tn * 128);
+    tile_coords(xcd_remap(bid, tiles_q), (pq.M + C::BM - 1) / C::BM, pq.N / C::BN, pq.xcd_gx, tm, tn);
+    gemm_body<EPI_QK_ROPE, C::BM, C::BN, C::ST, C::WM, C::WN, true, F8>(pq, smem, tm * C::BM, tn * C::BN);
   } else {
-    tile_coords(xcd_remap(bid - tiles_q, tiles_v), (pv.M + 255) / 256, pv.N / 128, pv.xcd_gx, tm, tn);
-    gemm_body<EPI_V_T, 256, 128, 3, 4, 2, false, F8>(pv, smem, tm * 256, tn * 128);
+    tile_coords(xcd_remap(bid - tiles_q, tiles_v), (pv.M + C::BM - 1) / C::BM, pv.N / C::BN, pv.xcd_gx, tm, tn);
+    gemm_body<EPI_V_T, C::BM, C::BN, C::ST, C::WM, C::WN, false, F8>(pv, smem, tm * C::BM, tn * C::BN);
   }
 }
 
-template <bool F8>
+template <bool F8, int TILE>
 struct LaunchQkv {
-  static constexpr int ring = 3 * ((256 + 128) * 128 + (F8 ? 256 * 4 : 0));
-  static constexpr int slab_q = 8 * slab_bytes<EPI_QK_ROPE, 32, 64>(), slab_v = 8 * slab_bytes<EPI_V_T, 32, 64>();
+  using C = TileCfg<TILE>;
+  static constexpr int ring = C::ST * ((C::BM + C::BN) * 128 + (F8 ? C::BM * 4 : 0));
+  static constexpr int NW = C::WM * C::WN;
+  static constexpr int slab_q = NW * slab_bytes<EPI_QK_ROPE, 32, C::BN / C::WN>(), slab_v = NW * slab_bytes<EPI_V_T, 32, C::BN / C::WN>();
   static constexpr int slab = slab_q > slab_v ? slab_q : slab_v;
   static constexpr int lds = ring > slab ? ring : slab;
   static_assert(lds <= 160 * 1024, "LDS budget");
   static hipError_t init() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_qkv_fused_kernel<F8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_qkv_fused_kernel<F8, TILE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   }
   static hipError_t run(const GemmParams& pq, const GemmParams& pv, hipStream_t s) {
-    const int tiles_q = ((pq.M + 255) / 256) * (pq.N / 128), tiles_v = ((pv.M + 255) / 256) * (pv.N / 128);
+    const int tiles_q = ((pq.M + C::BM - 1) / C::BM) * (pq.N / C::BN), tiles_v = ((pv.M + C::BM - 1) / C::BM) * (pv.N / C::BN);
+    const dim3 grid(tiles_q + tiles_v), block(64 * NW);
     if (pq.ev_start)
-      hipExtLaunchKernelGGL((gemm_qkv_fused_kernel<F8>), dim3(tiles_q + tiles_v), dim3(512), lds, s, pq.ev_start, pq.ev_stop, 0, pq, pv, tiles_q, tiles_v);
+      hipExtLaunchKernelGGL((gemm_qkv_fused_kernel<F8, TILE>), grid, block, lds, s, pq.ev_start, pq.ev_stop, 0, pq, pv, tiles_q, tiles_v);
     else
-      hipLaunchKernelGGL((gemm_qkv_fused_kernel<F8>), dim3(tiles_q + tiles_v), dim3(512), lds, s, pq, pv, tiles_q, tiles_v);
+      hipLaunchKernelGGL((gemm_qkv_fused_kernel<F8, TILE>), grid, block, lds, s, pq, pv, tiles_q, tiles_v);
     return hipGetLastError();
   }
 };
+
+// tile of the fused QK+V launch: the largest whose QK part alone still gives ~100 workgroups per lane (two lanes share the chip)
+int pick_qkv_tile(const GemmParams& pq) {
+  if (g_force_n2048 == T256x128 || g_force_n2048 == T128x128 || g_force_n2048 == T128x64) return g_force_n2048;
+  const long t256 = (long)((pq.M + 255) / 256) * (pq.N / 128), t128 = (long)((pq.M + 127) / 128) * (pq.N / 128);
+  return t256 >= 100 ? T256x128 : t128 >= 100 ? T128x128 : T128x64;
+}
 
 }  // namespace
 
@@ -858,8 +877,12 @@ hipError_t gemm_bf16_init() {
   LEMAS_INIT(EPI_V_T)
 #undef LEMAS_INIT
   if ((e = init_epi<EPI_BIAS_GELU_F8, true>()) != hipSuccess) return e;
-  if ((e = LaunchQkv<false>::init()) != hipSuccess) return e;
-  return LaunchQkv<true>::init();
+  if ((e = LaunchQkv<false, T256x128>::init()) != hipSuccess) return e;
+  if ((e = LaunchQkv<false, T128x128>::init()) != hipSuccess) return e;
+  if ((e = LaunchQkv<false, T128x64>::init()) != hipSuccess) return e;
+  if ((e = LaunchQkv<true, T256x128>::init()) != hipSuccess) return e;
+  if ((e = LaunchQkv<true, T128x128>::init()) != hipSuccess) return e;
+  return LaunchQkv<true, T128x64>::init();
 }
 
 // XCD block grid (gx x 8/gx, see tile_coords): fabric-side fetch ~ gy * |A| + gx * |W| -> minimise gy * M + gx * N
@@ -880,7 +903,11 @@ hipError_t launch_gemm_qkv_fused(const GemmParams& pq_in, const GemmParams& pv_i
   if (pv.xcd_gx <= 0) pv.xcd_gx = pick_xcd_gx(pv.M, pv.N);
   if (pq.K % 128 != 0 || pq.N % 128 != 0 || pv.N % 128 != 0 || pq.M != pv.M || pq.f8 != pv.f8 || pq.M <= 0) return hipErrorInvalidValue;
   if (pq.f8 && (!pq.a_mx || !pq.w_scale || !pv.w_scale)) return hipErrorInvalidValue;
-  return pq.f8 ? LaunchQkv<true>::run(pq, pv, s) : LaunchQkv<false>::run(pq, pv, s);
+  switch (pick_qkv_tile(pq)) {
+    case T256x128: return pq.f8 ? LaunchQkv<true, T256x128>::run(pq, pv, s) : LaunchQkv<false, T256x128>::run(pq, pv, s);
+    case T128x128: return pq.f8 ? LaunchQkv<true, T128x128>::run(pq, pv, s) : LaunchQkv<false, T128x128>::run(pq, pv, s);
+    default: return pq.f8 ? LaunchQkv<true, T128x64>::run(pq, pv, s) : LaunchQkv<false, T128x64>::run(pq, pv, s);
+  }
 }
 
 hipError_t launch_gemm_bf16_tile(int epi, const GemmParams& p_in, int tile, hipStream_t s) {

@@ -6,7 +6,7 @@
     python tools/kbench.py one <what> <M> <N> <K> [tile] [--iters 20]       # ONE kernel (for rocprofv3 --pmc passes)
 
 Cells are average launch microseconds (algorithmic TFLOP/s).  Tiles: 0 = production choice, 16 = 256x128, 17 = 128x128,
-18 = 128x64, 22 = 256x256 (bf16 only)."""
+18 = 128x64, 19 = 64x64, 22 = 256x256 (bf16 only)."""
 import argparse
 import ctypes as C
 import os
