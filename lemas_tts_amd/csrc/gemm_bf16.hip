@@ -777,11 +777,14 @@ int pick_tile(const GemmParams& p) {
   int tile = t256 >= want ? T256x128 : t128 >= want ? T128x128 : T128x64;
   // short utterances: when even 128x64 tiles leave most CUs without work, halve the tile height (N <= 1024: out-proj, FF2, V)
   if (tile == T128x64 && p.N <= 1024 && (long)((p.M + 127) / 128) * (p.N / 64) < 130) tile = T64x64;
-  if (!p.f8 && tile == T256x128 && p.N % 256 == 0) {
-    // batched workloads: 256x256 when at least two full rounds of them exist and the whole-round count favours them
+  if (!p.f8 && p.N % 256 == 0 && p.N >= 1024) {
+    // batched workloads: the ping-pong 256x256 tile once its tiles cover the CUs of this launch 1.5 times (N >= 2048) / 1.1 times
+    // (N = 1024).  Measured end to end with two lanes in flight (tools/e2e_ab.py --batch B, profiles/r02_e2e_ab_pingpong_batch.txt):
+    // N = 2048 GEMMs: -3 % at M = 2304 per lane, +1 % at 4608, +8 % at 6912 and 9216; adding the N = 1024 GEMMs: -24 %, -3 %, -5 %,
+    // +1.3 % (configs[3]'s share: 155 -> 169 audio-s/s).  The tile count, not a round-quantisation model, is what predicts it: with
+    // two lanes sharing the chip a partial last round of one lane is filled by the other.
     const long cus = 256 / conc, tbig = (long)((p.M + 255) / 256) * (p.N / 256);
-    const double cost_big = (double)((tbig + cus - 1) / cus) * (2.0 / 1.10), cost_std = (double)((t256 + cus - 1) / cus);
-    if (tbig >= 2 * cus && cost_big < cost_std) tile = T256x256;
+    if (p.N >= 2048 ? 2 * tbig >= 3 * cus : 10 * tbig >= 11 * cus) tile = T256x256;
   }
   return tile;
 }

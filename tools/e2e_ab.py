@@ -26,8 +26,11 @@ def main():
     ap.add_argument("--arms", nargs="+", default=["default"])
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--batch", type=int, default=0, help="override the workload's utterances per batch (seeded inputs)")
     a = ap.parse_args()
-    w = Bn.WORKLOADS[a.workload]
+    w = dict(Bn.WORKLOADS[a.workload])
+    if a.batch:
+        w["B"], w["golden"] = a.batch, None
     B, F, N = w["B"], w["F"], w["N"]
     dev = torch.device("cuda:0")
     arch = DiTArch()
