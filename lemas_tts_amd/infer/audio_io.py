@@ -73,8 +73,11 @@ def load_wav(path) -> tuple[torch.Tensor, int]:
 
 def save_wav(path, wav, sample_rate: int, subtype: str = "PCM_16") -> None:
     """``soundfile.write(path, wav, sr)`` for mono/multi-channel float data: ``wav`` is ``[frames]`` or ``[frames, channels]``.
-    ``PCM_16`` (soundfile's default for .wav) rounds ``x * 32768`` and saturates; ``PCM_24`` as used for the denoised prompt
-    (``tts_multilingual.py:84``); ``FLOAT`` stores float32."""
+    The float -> integer step restates libsndfile's, as python-soundfile drives it (it switches SFC_SET_CLIPPING on, so the
+    ``*_clip_array`` converters of libsndfile's pcm.c run): ``PCM_16`` (soundfile's default for .wav) = ``lrint(x * 0x8000)``
+    saturated to int16; ``PCM_24`` (the denoised prompt, ``tts_multilingual.py:84``) = ``lrint(x * 0x80000000)`` saturated to
+    int32, of which the top three bytes are written (an arithmetic ``>> 8``, not a second rounding); ``FLOAT`` stores float32.
+    Neither package is installed here, so this is restated from the published sources, not pinned."""
     a = np.asarray(wav, dtype=np.float64)
     if a.ndim == 1:
         a = a[:, None]
@@ -83,7 +86,7 @@ def save_wav(path, wav, sample_rate: int, subtype: str = "PCM_16") -> None:
         q = np.clip(np.rint(a * 32768.0), -32768, 32767).astype("<i2")
         body, tag, bits = q.tobytes(), _PCM, 16
     elif subtype == "PCM_24":
-        q = np.clip(np.rint(a * 8388608.0), -8388608, 8388607).astype(np.int32)
+        q = np.clip(np.rint(a * 2147483648.0), -2147483648.0, 2147483647.0).astype(np.int64) >> 8
         u = (q & 0xFFFFFF).astype(np.uint32).reshape(-1)
         body = np.stack([u & 0xFF, (u >> 8) & 0xFF, (u >> 16) & 0xFF], axis=1).astype(np.uint8).tobytes()
         tag, bits = _PCM, 24
