@@ -8,53 +8,69 @@
 
 namespace {
 
-// one wave per row; D = 1024 -> 16 elements per lane as 2 groups of 8 consecutive columns (2 x float4 loads each), so the
+// one wave per ROWS rows; D = 1024 -> 16 elements per lane and row as 2 groups of 8 consecutive columns (2 x float4 loads each), so the
 // bf16 result leaves as 16-B write-through (sc1) stores: the next kernel (a GEMM on other XCDs) reads it from memory anyway and
 // the launch does not end on an L2 write-back of 3.9 MB
-template <int D>
+template <int D, int ROWS>
 __global__ __launch_bounds__(256) void ln_mod_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, int M,
                                                      const float* __restrict__ tab, int tab_stride, int scale_off,
                                                      int shift_off, const int* __restrict__ step_idx) {
   constexpr int PER = D / 512;  // groups of 8 columns per lane
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS;
+  if (row0 >= M) return;
   const int lane = threadIdx.x & 63;
   const float* base = tab + (step_idx ? (size_t)step_idx[0] * tab_stride : 0);
-  const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * D);
-  float4 v[PER][2];
-  float s = 0.f;
+  // ROWS rows per wave: all their loads are issued before the first reduction (a wave with one row has 64 B per lane in flight
+  // and then sits through two dependent shuffle reductions; the kernel is latency-, not bandwidth-bound at batch 1)
+  float4 v[ROWS][PER][2];
 #pragma unroll
-  for (int i = 0; i < PER; ++i)
+  for (int r = 0; r < ROWS; ++r) {
+    const int row = row0 + r < M ? row0 + r : M - 1;
+    const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * D);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      v[i][h] = xr[(lane + 64 * i) * 2 + h];
-      s += v[i][h].x + v[i][h].y + v[i][h].z + v[i][h].w;
-    }
-  const float mean = wave_sum(s) * (1.0f / D);
-  float q = 0.f;
+    for (int i = 0; i < PER; ++i)
 #pragma unroll
-  for (int i = 0; i < PER; ++i)
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const float a = v[i][h].x - mean, b = v[i][h].y - mean, c = v[i][h].z - mean, d = v[i][h].w - mean;
-      q += a * a + b * b + c * c + d * d;
-    }
-  const float rstd = rsqrtf(wave_sum(q) * (1.0f / D) + 1e-6f);
+      for (int h = 0; h < 2; ++h) v[r][i][h] = xr[(lane + 64 * i) * 2 + h];
+  }
   const float4* sc = reinterpret_cast<const float4*>(base + scale_off);
   const float4* sh = reinterpret_cast<const float4*>(base + shift_off);
-  bf16_t* orow = out + (size_t)row * D;
+  float4 a[PER][2], b[PER][2];
 #pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    bf16x8 o;
+  for (int i = 0; i < PER; ++i)
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const float4 a = sc[(lane + 64 * i) * 2 + h], b = sh[(lane + 64 * i) * 2 + h];
-      o[4 * h + 0] = (bf16_t)((v[i][h].x - mean) * rstd * (1.0f + a.x) + b.x);
-      o[4 * h + 1] = (bf16_t)((v[i][h].y - mean) * rstd * (1.0f + a.y) + b.y);
-      o[4 * h + 2] = (bf16_t)((v[i][h].z - mean) * rstd * (1.0f + a.z) + b.z);
-      o[4 * h + 3] = (bf16_t)((v[i][h].w - mean) * rstd * (1.0f + a.w) + b.w);
+    for (int h = 0; h < 2; ++h) { a[i][h] = sc[(lane + 64 * i) * 2 + h]; b[i][h] = sh[(lane + 64 * i) * 2 + h]; }
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) s += v[r][i][h].x + v[r][i][h].y + v[r][i][h].z + v[r][i][h].w;
+    const float mean = wave_sum(s) * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float c0 = v[r][i][h].x - mean, c1 = v[r][i][h].y - mean, c2 = v[r][i][h].z - mean, c3 = v[r][i][h].w - mean;
+        q += c0 * c0 + c1 * c1 + c2 * c2 + c3 * c3;
+      }
+    const float rstd = rsqrtf(wave_sum(q) * (1.0f / D) + 1e-6f);
+    if (row0 + r < M) {
+      bf16_t* orow = out + (size_t)(row0 + r) * D;
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        bf16x8 o;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          o[4 * h + 0] = (bf16_t)((v[r][i][h].x - mean) * rstd * (1.0f + a[i][h].x) + b[i][h].x);
+          o[4 * h + 1] = (bf16_t)((v[r][i][h].y - mean) * rstd * (1.0f + a[i][h].y) + b[i][h].y);
+          o[4 * h + 2] = (bf16_t)((v[r][i][h].z - mean) * rstd * (1.0f + a[i][h].z) + b[i][h].z);
+          o[4 * h + 3] = (bf16_t)((v[r][i][h].w - mean) * rstd * (1.0f + a[i][h].w) + b[i][h].w);
+        }
+        store_wt_b128(orow + (lane + 64 * i) * 8, __builtin_bit_cast(u32x4, o));
+      }
     }
-    store_wt_b128(orow + (lane + 64 * i) * 8, __builtin_bit_cast(u32x4, o));
   }
 }
 
@@ -224,8 +240,8 @@ inline int grid_for(size_t n, int block = 256) {
 hipError_t launch_ln_mod(const float* x, bf16_t* out, int M, int D, const float* tab, int tab_stride, int scale_off,
                          int shift_off, const int* step_idx, hipStream_t s) {
   if (D != 1024) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(ln_mod_kernel<1024>, dim3((M + 3) / 4), dim3(256), 0, s, x, out, M, tab, tab_stride, scale_off,
-                     shift_off, step_idx);
+  // two rows per wave: +0.4 ... 1.3 % end to end over one (tools/e2e_ab.py, all three workloads)
+  hipLaunchKernelGGL((ln_mod_kernel<1024, 2>), dim3((M + 7) / 8), dim3(256), 0, s, x, out, M, tab, tab_stride, scale_off, shift_off, step_idx);
   return hipGetLastError();
 }
 
