@@ -166,24 +166,9 @@ def test_fp8_sampler_vs_emulation_and_reference_golden(golden_dir, name):
     assert mse_ref <= tol, mse_ref
 
 
-def test_fp8_full_depth_nfe32_within_reference_tolerance():
-    """22 blocks, NFE = 32, CFG 2, sway 5 (the configuration the tolerance is stated for), F = 100 / N = 300 so the fp32
-    oracle finishes in about a minute: fp8 GEMMs stay inside mel-MSE <= 1e-4 of the fp32 reference restatement."""
-    from oracle import lemas_oracle as O
-    from lemas_tts_amd import synth
-    from lemas_tts_amd.model.layout import DiTArch
-    arch, vocab = DiTArch(), 898
-    sd = synth.synth_cfm_state_dict(arch, vocab, 21)
-    F_, N = 100, 300
-    cond = torch.from_numpy(synth.synth_cond_mel(22, F_))[None]
-    text = torch.from_numpy(synth.synth_tokens(23, 40, vocab))[None]
-    y0 = torch.from_numpy(synth.synth_noise(24, N))[None]
-    m = _fp8_model(arch, vocab, sd)
-    out, _ = m.sample(cond, text, N, steps=32, cfg_strength=2.0, sway_sampling_coef=5, y0=y0, use_acc_grl=False)
-    ref, _ = O.OracleCFM(sd, arch).sample(cond, text, N, y0=y0, steps=32, cfg_strength=2.0, sway_sampling_coef=5)
-    mse = float(((out.cpu() - ref)[:, F_:] ** 2).mean())
-    print(f"\n[fp8 22 blocks NFE 32 N={N}] mel-MSE vs fp32 oracle {mse:.3e}")
-    assert mse <= 1e-4, mse
+# The full-depth, NFE-32 tolerance of the fp8 path is checked at FULL SIZE against the reference's own output in
+# tests/test_gpu_06_configs.py::test_configs1_full_size_full_nfe_vs_the_reference (mel-MSE 4.2e-5 against the 1e-4 target); the
+# round-1 form of that check (N = 300 against a 2-minute oracle run on the GPU box's host cores) was dropped for it.
 
 
 def test_fp8_graph_eager_dual_bit_identical(golden_dir):
