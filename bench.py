@@ -24,7 +24,8 @@ Multi-GPU: utterance-level data parallelism, weights generated on rank 0 and bro
 (loaded device-to-device on every rank), no collective in the step loop.
 
 CORRECTNESS inside the run: the mel the timed region produced last is compared with the committed output of the REFERENCE
-itself on the same inputs (tests/golden/configs1_nfe32.npz: 22 blocks, all 32 steps; made by oracle/gen_golden.py
+itself on the same inputs (tests/golden/configs1_nfe32.npz, configs3_share_nfe32.npz: 22 blocks, all 32 steps; the short
+workload against configs0_nfe16.npz, the same utterance over 16 steps, in one extra untimed solve; made by oracle/gen_golden.py
 --full-size); the run FAILS above mel-MSE 1e-4 and the value is reported as ``mel_mse_vs_reference``.
 
 The JSON line also carries
@@ -66,9 +67,9 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 WORKLOADS = {
     "configs1": dict(B=1, F=938, N=1875, golden="configs1_nfe32.npz", golden_steps=32,
                      desc="BASELINE configs[1]: multilingual_grl, batch 1, 10 s ref + 10 s target"),
-    "configs3": dict(B=8, F=375, N=1125, golden="configs3_share_4steps.npz", golden_steps=4,
+    "configs3": dict(B=8, F=375, N=1125, golden="configs3_share_nfe32.npz", golden_steps=32,
                      desc="BASELINE configs[3] per-GPU share: multilingual_grl, 8 utterances of 4 s ref + 8 s target as one batch"),
-    "short": dict(B=1, F=375, N=750, golden=None, golden_steps=0,
+    "short": dict(B=1, F=375, N=750, golden="configs0_nfe16.npz", golden_steps=16,
                   desc="one short utterance: multilingual_grl, batch 1, 4 s ref + 4 s target"),
 }
 
@@ -96,11 +97,9 @@ def build_inputs(w: dict, rank: int, device):
     B, F, N = w["B"], w["F"], w["N"]
     fx = None
     if w["golden"] and os.path.exists(os.path.join(GOLDEN, w["golden"])):
-        fx = np.load(os.path.join(GOLDEN, w["golden"]))
+        fx = synth.expand_reference_fixture(dict(np.load(os.path.join(GOLDEN, w["golden"]))))
     if fx is not None and rank == 0:
         cond, text, y0 = torch.from_numpy(fx["cond"]), torch.from_numpy(fx["text"]), torch.from_numpy(fx["y0"])
-        if "y0_shared" in fx:            # equal durations draw the same noise (cfm.py:430-435 re-seeds per sample): one copy stored
-            y0 = y0.expand(B, -1, -1).contiguous()
         assert tuple(cond.shape) == (B, F, 100) and tuple(y0.shape) == (B, N, 100)
     else:
         nt = round(N * 0.17)

@@ -122,10 +122,24 @@ def run_case(name, arch, *, wseed, B, F, lens, Nt, duration, steps, cfg, coef, n
         duration=np.asarray(durs.tolist(), dtype=np.int64),
         lens=np.asarray(lens_eff, dtype=np.int64),
     )
-    if not store_traj and B > 1 and all(torch.equal(y0[0], y0[b]) for b in range(B)):
-        # cfm.py:430-435 re-seeds per sample: equal durations draw the SAME noise; keep one copy (loaders broadcast it)
-        fx["y0"] = y0[:1].numpy()
-        fx["y0_shared"] = np.int64(1)
+    if not store_traj and B > 1:
+        # cfm.py:430-435 re-seeds per sample, so every sample's noise is a PREFIX of the longest sample's draw (zero-padded
+        # beyond its duration): keep that one draw (loaders cut and pad it).  The full-size fixtures also blank `out` outside the
+        # generated frames (conditioning frames are a copy of `cond`, frames past a sample's duration are never compared).
+        j = int(np.argmax(durs.numpy()))
+        ok = all(torch.equal(y0[b, : int(durs[b])], y0[j, : int(durs[b])]) and not y0[b, int(durs[b]):].any() for b in range(B))
+        if ok:
+            fx["y0"] = y0[j: j + 1].numpy()
+            fx["y0_shared"] = np.int64(1)
+        else:          # ragged durations: the draws are not prefixes of one another; the loader re-draws them from the seed
+            del fx["y0"]
+            fx["noise_seed"] = np.int64(noise_seed)
+        o = out.numpy().copy()
+        for b in range(B):
+            o[b, : lens_eff[b]] = 0
+            o[b, int(durs[b]):] = 0
+        fx["out"] = o
+        fx["out_generated_only"] = np.int64(1)
     if store_traj:           # the full-size cases keep only `out`: a [33, 1, 1875, 100] trajectory is 25 MB
         fx["trajectory"] = traj.numpy()
     fx["ref_seconds"] = np.float64(dt)
@@ -162,22 +176,39 @@ def run_prosody_case(name, wseed, frames):
     print(f"{name}: frames={frames} emb norm {emb.norm(dim=-1).tolist()}")
 
 
-def run_full_size_cases():
-    """BASELINE configs[1] at FULL size and FULL NFE (22 blocks, F = 938, N = 1875, 32 Euler steps, cfg 2, sway 5): the headline
-    parity number, "mel MSE <= 1e-4 vs reference" (cfm.py:382-425,456).  The reference needs ~10 min of host time for it, so it
-    is run once here and its output committed; bench.py and tests/test_gpu_06_configs.py compare against it on every run.
-    configs[3]'s per-GPU share (8 utterances of 4 s + 8 s, N = 1125) at full depth over 4 steps is pinned the same way."""
-    run_case("configs1_nfe32", FULL, wseed=1234, B=1, F=938, lens=None, Nt=[319], duration=1875, steps=32,
-             cfg=2.0, coef=5, noise_seed=1234, store_traj=False)
-    run_case("configs3_share_4steps", FULL, wseed=1234, B=8, F=375, lens=None, Nt=[191] * 8, duration=1125, steps=4,
-             cfg=2.0, coef=5, noise_seed=4321, store_traj=False)
+def run_full_size_cases(which=None):
+    """The BASELINE configurations at FULL size, FULL depth (22 blocks) and FULL NFE against the reference's own CFM.sample
+    (cfm.py:206-473, CPU fp32): "mel MSE <= 1e-4 vs reference" measured where it is claimed.  The reference needs 2-10 min of host
+    time per case, so each is run once here and its output committed; bench.py and tests/test_gpu_06_configs.py compare against
+    them on every run.
+      configs0_nfe16        configs[0]: one sentence, 4 s prompt (F = 375), N = 750, NFE 16
+      configs1_nfe32        configs[1]: batch 1, 10 s + 10 s (F = 938, N = 1875), NFE 32            <- the headline
+      configs2_prosody_b8   configs[2]: multilingual_prosody, batch 8 of mixed lengths (ragged lens / durations), sway, NFE 32
+      configs3_share_nfe32  configs[3]: the per-GPU share of the 64-utterance batch, 8 x (4 s + 8 s) (N = 1125), NFE 32
+      configs4_edit_nfe48   configs[4]: speech-edit infill of a 30 s source (F = 2813), 3 edit spans, NFE 48, sway 3"""
+    cases = {
+        "configs0_nfe16": dict(arch=FULL, wseed=1234, B=1, F=375, lens=None, Nt=[128], duration=750, steps=16, cfg=2.0, coef=5, noise_seed=1230),
+        "configs1_nfe32": dict(arch=FULL, wseed=1234, B=1, F=938, lens=None, Nt=[319], duration=1875, steps=32, cfg=2.0, coef=5, noise_seed=1234),
+        "configs2_prosody_b8": dict(arch=FULL, wseed=1235, B=8, F=938, lens=[375, 420, 500, 610, 700, 780, 850, 938],
+                                    Nt=[153, 172, 192, 219, 241, 265, 289, 323], duration=[900, 1010, 1130, 1290, 1420, 1560, 1700, 1900],
+                                    steps=32, cfg=2.0, coef=5, noise_seed=1232, prosody=True),
+        "configs3_share_nfe32": dict(arch=FULL, wseed=1234, B=8, F=375, lens=None, Nt=[191] * 8, duration=1125, steps=32, cfg=2.0, coef=5,
+                                     noise_seed=4321),
+        "configs4_edit_nfe48": dict(arch=FULL, wseed=1234, B=1, F=2813, lens=None, Nt=[400], duration=2813, steps=48, cfg=2.0, coef=3.0,
+                                    noise_seed=1236, edit_spans=[(4.0, 6.5), (12.0, 15.0), (22.0, 24.0)]),
+    }
+    for name, kw in cases.items():
+        if which and name not in which:
+            continue
+        arch = kw.pop("arch")
+        run_case(name, arch, store_traj=False, **kw)
 
 
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     torch.set_num_threads(8)
     if "--full-size" in sys.argv:
-        run_full_size_cases()
+        run_full_size_cases([a for a in sys.argv[1:] if not a.startswith("--")] or None)
         return
     run_case("mini_plain", MINI, wseed=11, B=1, F=60, lens=None, Nt=[30], duration=160, steps=4,
              cfg=2.0, coef=5, noise_seed=101)

@@ -179,58 +179,48 @@ def test_config1_plumbing_sentence_nfe16():
     assert (wav - wref).abs().max().item() < 1e-4 * max(1.0, wref.abs().max().item())
 
 
-def _reference_fixture(name):
+FULL_SIZE = ["configs0_nfe16", "configs1_nfe32", "configs2_prosody_b8", "configs3_share_nfe32"]
+
+
+@pytest.mark.parametrize("name", FULL_SIZE)
+def test_baseline_config_full_size_full_nfe_vs_the_reference(golden_dir, name):
+    """THE parity numbers: every BASELINE configuration at FULL size, FULL depth (22 blocks) and FULL NFE, bf16 MFMA operands,
+    against the output of the REFERENCE's own CFM.sample (cfm.py:206-473, CPU fp32) on identical inputs -- fixtures made once by
+    `python -m oracle.gen_golden --full-size` (the reference needs 20 s ... 10 min per case on the build box).  Target: mel-MSE
+    <= 1e-4 over the generated frames (BASELINE.json).  configs[1] and configs[4] are also run with fp8 MFMA weights (configs[4]'s
+    precision).
+      configs0_nfe16        one sentence, F = 375, N = 750, NFE 16
+      configs1_nfe32        batch 1, 10 s + 10 s (F = 938, N = 1875), NFE 32: what bench.py times
+      configs2_prosody_b8   batch 8 of mixed lengths (ragged lens / durations), prosody conditioning, sway, NFE 32
+      configs3_share_nfe32  configs[3]'s per-GPU share: 8 x (4 s + 8 s), N = 1125, NFE 32 (256x256 GEMM tiles, BH = 128 attention)
+      configs4_edit_nfe48   speech-edit infill of a 30 s source (N = 2814), 3 edit spans, NFE 48, sway 3"""
     import os
-    from conftest import GOLDEN
-    path = os.path.join(GOLDEN, name)
-    if not os.path.exists(path):
-        pytest.fail(f"{name} is missing: run `python -m oracle.gen_golden --full-size` in the build container (needs /root/reference)")
-    fx = dict(np.load(path))
-    if "y0_shared" in fx:                # equal durations draw the same noise (cfm.py:430-435 re-seeds per sample): one copy stored
-        fx["y0"] = np.repeat(fx["y0"], int(fx["B"]), axis=0)
-    arch = DiTArch()
-    sd = synth.synth_cfm_state_dict(arch, int(fx["vocab"]), int(fx["wseed"]))
-    assert abs(synth.checksum(sd) - float(fx["wchecksum"])) < 1e-6 * abs(float(fx["wchecksum"])), "synthetic weights drifted from the ones the reference ran with"
-    return fx, arch, sd
-
-
-def test_configs1_full_size_full_nfe_vs_the_reference():
-    """THE headline parity number: BASELINE configs[1] at full size (22 blocks, F=938, N=1875), all 32 Euler steps, cfg 2, sway 5,
-    bf16 MFMA operands, against the output of the REFERENCE's own CFM.sample (cfm.py:206-473, CPU fp32) on identical inputs
-    (tests/golden/configs1_nfe32.npz, made by oracle/gen_golden.py --full-size).  Target: mel-MSE <= 1e-4 (BASELINE.json)."""
-    from lemas_tts_amd.model.cfm import CFM
-    fx, arch, sd = _reference_fixture("configs1_nfe32.npz")
-    F_, N, S = int(fx["F"]), int(fx["N"]), int(fx["steps"])
-    assert (F_, N, S) == (938, 1875, 32)
-    m = CFM(arch, int(fx["vocab"]), sd, device="cuda:0")
-    out, _ = m.sample(torch.from_numpy(fx["cond"]), torch.from_numpy(fx["text"]), N, steps=S, cfg_strength=float(fx["cfg"]),
-                      sway_sampling_coef=float(fx["coef"]), y0=torch.from_numpy(fx["y0"]), use_acc_grl=False)
-    d = (out.cpu().double() - torch.from_numpy(fx["out"]).double())[:, F_:]
-    mse, mx = float((d ** 2).mean()), float(d.abs().max())
-    print(f"\n[configs1 FULL: 22 blocks, N=1875, NFE=32] mel-MSE vs reference {mse:.3e}  max|err| {mx:.3e}  (reference CPU run took {float(fx['ref_seconds']):.0f} s)")
-    assert mse <= 1e-4
-    np.testing.assert_array_equal(out.cpu().numpy()[:, :F_], fx["out"][:, :F_])      # conditioning frames are copied
-    # fp8 MFMA weights (configs[4]'s precision) on the same case
-    m.engine.set_option("fp8", 1)
-    out8, _ = m.sample(torch.from_numpy(fx["cond"]), torch.from_numpy(fx["text"]), N, steps=S, cfg_strength=float(fx["cfg"]),
-                       sway_sampling_coef=float(fx["coef"]), y0=torch.from_numpy(fx["y0"]), use_acc_grl=False)
-    mse8 = float(((out8.cpu().double() - torch.from_numpy(fx["out"]).double())[:, F_:] ** 2).mean())
-    print(f"[configs1 FULL, fp8 GEMM operands] mel-MSE vs reference {mse8:.3e}")
-    assert mse8 <= 1e-4
-
-
-def test_configs3_share_full_depth_four_steps_vs_the_reference():
-    """BASELINE configs[3]'s per-GPU share (8 utterances of 4 s + 8 s, N = 1125, one batch) at full depth over 4 Euler steps
-    against the REFERENCE's output (tests/golden/configs3_share_4steps.npz): the batched tile shapes (256x256 GEMM tiles,
-    BH = 128 attention) on the real depth."""
-    from lemas_tts_amd.model.cfm import CFM
-    fx, arch, sd = _reference_fixture("configs3_share_4steps.npz")
-    B, F_, N, S = int(fx["B"]), int(fx["F"]), int(fx["N"]), int(fx["steps"])
-    assert (B, F_, N) == (8, 375, 1125) and S >= 4
-    m = CFM(arch, int(fx["vocab"]), sd, device="cuda:0")
-    out, _ = m.sample(torch.from_numpy(fx["cond"]), torch.from_numpy(fx["text"]), N, steps=S, cfg_strength=float(fx["cfg"]),
-                      sway_sampling_coef=float(fx["coef"]), y0=torch.from_numpy(fx["y0"]), use_acc_grl=False)
-    d = (out.cpu().double() - torch.from_numpy(fx["out"]).double())[:, F_:]
-    per = (d ** 2).mean(dim=(1, 2))
-    print(f"\n[configs3 share: B=8, 22 blocks, N=1125, {S} steps] mel-MSE vs reference {float(per.mean()):.3e} (per sample max {float(per.max()):.3e})")
-    assert float(per.max()) <= 1e-4
+    import test_gpu_00_sample as T
+    if not os.path.exists(os.path.join(golden_dir, name + ".npz")):
+        pytest.fail(f"{name}.npz is missing: run `python -m oracle.gen_golden --full-size {name}` in the build container (needs /root/reference)")
+    fx, arch, sd = T._load(golden_dir, name)
+    fx = synth.expand_reference_fixture(fx)
+    assert arch.depth == 22
+    out, _ = T._run_case(fx, arch, sd, graph=True, traj=False)
+    mse = T._gen_mse(out, fx["out"], fx)
+    B = int(fx["B"])
+    print(f"\n[{name}: 22 blocks, B={B}, N={out.shape[1]}, NFE={int(fx['steps'])}] mel-MSE vs the reference {mse:.3e} "
+          f"(the reference's CPU run took {float(fx['ref_seconds']):.0f} s)")
+    assert mse <= 1e-4, mse
+    if "edit_mask" in fx:      # kept frames are copied from the source mel, exactly (cfm.py:459-461)
+        em = np.pad(fx["edit_mask"][0], (0, out.shape[1] - fx["edit_mask"].shape[1]))
+        np.testing.assert_array_equal(out[0, em][:, :], np.pad(fx["cond"][0], ((0, out.shape[1] - fx["cond"].shape[1]), (0, 0)))[em])
+    elif "prosody_embeds" not in fx:
+        for b in range(B):
+            L = int(fx["lens"][b])
+            np.testing.assert_array_equal(out[b, :L], fx["cond"][b, :L])
+    if name in ("configs1_nfe32", "configs4_edit_nfe48"):
+        m = T._model(arch, int(fx["vocab"]), int(fx["wseed"]), bool(fx["prosody"]), sd)
+        m.engine.set_option("fp8", 1)
+        try:
+            out8, _ = T._run_case(fx, arch, sd, graph=True, traj=False)
+        finally:
+            m.engine.set_option("fp8", 0)
+        mse8 = T._gen_mse(out8, fx["out"], fx)
+        print(f"[{name}, fp8 GEMM operands] mel-MSE vs the reference {mse8:.3e}")
+        assert mse8 <= 1e-4, mse8
