@@ -179,7 +179,7 @@ def test_config1_plumbing_sentence_nfe16():
     assert (wav - wref).abs().max().item() < 1e-4 * max(1.0, wref.abs().max().item())
 
 
-FULL_SIZE = ["configs0_nfe16", "configs1_nfe32", "configs2_prosody_b8", "configs3_share_nfe32"]
+FULL_SIZE = ["configs0_nfe16", "configs1_nfe32", "configs2_prosody_b8", "configs3_share_nfe32", "configs4_edit_nfe48"]
 
 
 @pytest.mark.parametrize("name", FULL_SIZE)
