@@ -66,6 +66,19 @@ def test_oracle_matches_reference_golden(golden_dir, name):
             np.testing.assert_array_equal(out.numpy()[b, :L], fx["cond"][b, :L])
 
 
+def test_oracle_matches_the_reference_at_full_depth_and_production_length(golden_dir):
+    """configs[0] as the reference itself ran it (22 blocks, F = 375, N = 750, all 16 Euler steps; tests/golden/configs0_nfe16.npz):
+    the oracle is pinned at the real depth and a production sequence length over a whole solve, not only on the 2-block minis and
+    the 3-step full_plain case.  ~30 s of host time."""
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    fx, arch, sd = load_case(golden_dir, "configs0_nfe16")
+    assert arch.depth == 22
+    out, _ = oracle_sample(fx, arch, sd)
+    err = np.abs(out.numpy() - fx["out"]).max()
+    print(f"\n[oracle vs reference, configs0 full size, NFE 16] max|err| {err:.3e}")
+    np.testing.assert_allclose(out.numpy(), fx["out"], atol=ATOL, rtol=0)
+
+
 def test_sway_cap_values():
     # values the survey measured by running the reference's closure (cfm.py:343-373, SURVEY.md 8a-W)
     for steps, want in ((16, 4.532), (32, 3.486), (48, 3.047), (64, 2.788)):
