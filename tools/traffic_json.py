@@ -14,7 +14,7 @@ EPI = {"0": "EPI_BIAS_BF16", "1": "EPI_BIAS_GELU", "2": "EPI_BIAS_F32", "3": "EP
 
 
 def symbol(k: str):
-    m = re.search(r"gemm_(?:bf16|pp)_kernel<(\d)", k)
+    m = re.search(r"gemm_(?:bf16|pp2?)_kernel<(\d)", k)
     if m:
         return f"gemm_bf16_kernel<{EPI.get(m.group(1), m.group(1))}>"
     for s in ("gemm_qkv_fused_kernel", "attn_fwd_splitkv_kernel", "ln_mod_kernel", "convpos_kernel", "gemm_f32_kernel"):
