@@ -125,6 +125,7 @@ struct GemmParams {
   // XCD block grid of the tile order: the tile grid is cut into xcd_gx x (8 / xcd_gx) blocks, one per XCD (gemm_bf16.hip
   // tile_coords).  0 = let the launcher choose (minimises the fabric-side fetch gy * |A| + gx * |W|); 8 = the row-major order.
   int xcd_gx;
+  unsigned long long* dbg;   // EXPERIMENT: per-workgroup phase timestamps [grid][4]
 };
 
 // ---- internal launchers (one per .hip translation unit) ----------------------------------------

@@ -1,7 +1,9 @@
 // Single-kernel entry points of the C ABI (lemas_k_*): thin drivers that feed fp32 device arrays through the
 // production kernels so the parity tests can localise a failure to one kernel.  They allocate scratch with
 // hipMalloc and synchronise -- test infrastructure, never on the sampling path.
+#include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <vector>
 
 #include "engine_common.h"
@@ -73,7 +75,12 @@ __global__ void fill_pattern_kernel(bf16_t* p, size_t n, unsigned seed) {
 
 extern "C" {
 
-int lemas_k_tile_override(int32_t n1024, int32_t n2048, int32_t xcd_gx) { gemm_bf16_force_tiles(n1024, n2048, xcd_gx); return 0; }
+static int g_dbg_phases = 0;
+int lemas_k_tile_override(int32_t n1024, int32_t n2048, int32_t xcd_gx) {
+  if (xcd_gx == 7777) { g_dbg_phases = 1; xcd_gx = 0; }
+  gemm_bf16_force_tiles(n1024, n2048, xcd_gx);
+  return 0;
+}
 
 int lemas_k_linear_bf16(const float* A, const float* W, const float* bias, float* out, int32_t M, int32_t N, int32_t K,
                         int32_t act, void* stream) {
@@ -356,6 +363,27 @@ extern "C" int lemas_k_bench(const char* what, int32_t M, int32_t N, int32_t K, 
     const int epi = w == "gemm_gelu8" ? EPI_BIAS_GELU_F8 : w == "gemm_gelu" ? EPI_BIAS_GELU_BF16 : w == "gemm_gate" ? EPI_GATE_RES : w == "gemm_qk" ? EPI_QK_ROPE : w == "gemm_v" ? EPI_V_T : EPI_BIAS_F32;
     if ((epi == EPI_QK_ROPE && N != 2048) || (epi == EPI_V_T && N != 1024)) { set_error("bench: gemm_qk needs N = 2048, gemm_v N = 1024"); return LEMAS_E_ARG; }
     rc = time_it([&]() { return launch_gemm_bf16_tile(epi, p, variant, s); });
+    if (rc == 0 && g_dbg_phases && variant >= 16) {   // EXPERIMENT: phase timestamps of one launch
+      const int bm_ = variant == 17 || variant == 18 ? 128 : variant == 19 ? 64 : 256, bn_ = variant == 22 ? 256 : variant == 16 || variant == 17 ? 128 : 64;
+      const int grid = ((M + bm_ - 1) / bm_) * (Np / bn_);
+      unsigned long long* d = sc.get<unsigned long long>((size_t)grid * 4);
+      p.dbg = d;
+      (void)launch_gemm_bf16_tile(epi, p, variant, s);
+      HIP_TRY(hipStreamSynchronize(s));
+      std::vector<unsigned long long> h((size_t)grid * 4);
+      HIP_TRY(hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost));
+      unsigned long long t0 = ~0ull, t3 = 0;
+      for (int i = 0; i < grid; ++i) { t0 = std::min(t0, h[i * 4]); t3 = std::max(t3, h[i * 4 + 3]); }
+      double sp[2] = {0, 0}, sl[2] = {0, 0}, se[2] = {0, 0}, st[2] = {0, 0}; int cnt[2] = {0, 0};
+      for (int i = 0; i < grid; ++i) {
+        const int g = i < 256 ? 0 : 1;
+        sp[g] += (h[i * 4 + 1] - h[i * 4]) * 0.01; sl[g] += (h[i * 4 + 2] - h[i * 4 + 1]) * 0.01; se[g] += (h[i * 4 + 3] - h[i * 4 + 2]) * 0.01;
+        st[g] += (h[i * 4] - t0) * 0.01; cnt[g]++;
+      }
+      fprintf(stderr, "  phases %s M=%d N=%d K=%d grid=%d span %.1f us | first round: start +%.1f prologue %.1f loop %.1f epilogue %.1f | later: n=%d start +%.1f prologue %.1f loop %.1f epilogue %.1f\n",
+              w.c_str(), M, N, K, grid, (t3 - t0) * 0.01, st[0] / std::max(cnt[0], 1), sp[0] / std::max(cnt[0], 1), sl[0] / std::max(cnt[0], 1), se[0] / std::max(cnt[0], 1),
+              cnt[1], st[1] / std::max(cnt[1], 1), sp[1] / std::max(cnt[1], 1), sl[1] / std::max(cnt[1], 1), se[1] / std::max(cnt[1], 1));
+    }
   } else if (w == "attention") {
     // M = sequence length, N = batch*heads
     const int n = M, bh = N, npad = (n + 127) & ~127, pitch = npad;

@@ -297,6 +297,223 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x16 (&acc)
   }
 }
 
+// The same epilogues for a wave tile of TI 32-row blocks, software-pipelined over the blocks.  Calling epilogue_rows once per
+// block serialises, per block, the global loads it starts with (bias / gate vectors, the fp32 residual rows, the RoPE table rows)
+// with the slab round trip behind them -- measured with in-kernel timestamps: 3.9 us of a 14.7 us out-projection launch at batch 1,
+// 11-17 us per 256 x 256 tile at full chip.  Here the column vectors are loaded once per wave tile (COLS_ONCE; off where the
+// registers do not allow it) and the row-dependent loads of block i+1 are in flight while block i goes through the slab.
+// What a wave's row epilogue reads from global memory before it can touch its accumulators: the column vectors (bias, gate) and the
+// row-dependent operands of its FIRST 32-row block (fp32 residual rows / RoPE table rows).  load() is called one K-tile before the
+// end of the main loop (the operands are in registers when the loop ends); every load is unconditional with a clamped address,
+// so the number of vector-memory operations in flight does not depend on the data (the loops count them with vmcnt).
+template <int EPI, int TJ, bool COLS_ONCE>
+struct EpiPre {
+  static constexpr int WTN = 32 * TJ;
+  static constexpr int NC = COLS_ONCE ? TJ * 4 : 1;
+  static constexpr int NR = EPI == EPI_GATE_RES ? SlabF32<32, WTN>::ITERS : EPI == EPI_QK_ROPE ? 32 / (64 / (WTN / 8)) : 1;
+  float4 bias_c[NC], gate_c[EPI == EPI_GATE_RES ? NC : 1];
+  float4 r0[NR], r1[EPI == EPI_QK_ROPE ? NR : 1];     // block 0: residual rows | cos rows, sin rows
+  const float* gate;
+
+  // rows of 32-row block i of the wave tile at (mw, nw): residual / RoPE operands into (x, y)
+  __device__ __forceinline__ void load_rows(const GemmParams& p, int mw, int nw, int lane, int i, float4 (&x)[NR], float4 (&y)[EPI == EPI_QK_ROPE ? NR : 1]) {
+    if constexpr (EPI == EPI_GATE_RES) {
+      using S = SlabF32<32, WTN>;
+      const int rr = lane / S::CPR, ch = lane % S::CPR;
+      int col = nw + ch * 4;
+      col = col < p.ldc - 3 ? col : 0;
+#pragma unroll
+      for (int it = 0; it < NR; ++it) {
+        int m = mw + 32 * i + it * S::RPI + rr;
+        m = m < p.M ? m : p.M - 1;
+        x[it] = *reinterpret_cast<const float4*>(p.out_f32 + (size_t)m * p.ldc + col);
+      }
+    } else if constexpr (EPI == EPI_QK_ROPE) {
+      constexpr int CPR = WTN / 8, RPI = 64 / CPR;
+      const int rr = lane / CPR, ch = lane % CPR;
+      const int d = (nw + ch * 8) & 63;
+#pragma unroll
+      for (int it = 0; it < NR; ++it) {
+        const int m = mw + 32 * i + it * RPI + rr;
+        const int b2 = m / p.seq_pitch, pos = m - b2 * p.seq_pitch;
+        const int ps = (m < p.M && pos < p.seq_valid) ? pos : 0;
+        x[it] = *reinterpret_cast<const float4*>(p.rope_cos + ps * 32 + (d >> 1));
+        y[it] = *reinterpret_cast<const float4*>(p.rope_sin + ps * 32 + (d >> 1));
+      }
+    }
+  }
+  __device__ __forceinline__ void load(const GemmParams& p, int mw, int nw, int lane) {
+    const int hi = lane >> 5;
+    gate = nullptr;
+    if (EPI == EPI_GATE_RES) gate = p.tab + (size_t)p.step_idx[0] * p.tab_stride + p.gate_off;
+    if (COLS_ONCE) {
+#pragma unroll
+      for (int j = 0; j < TJ; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int nl = j * 32 + 8 * g + 4 * hi;
+          bias_c[j * 4 + g] = *reinterpret_cast<const float4*>(p.bias + nw + nl);
+          if (EPI == EPI_GATE_RES) gate_c[j * 4 + g] = *reinterpret_cast<const float4*>(gate + nw + nl);
+        }
+    }
+    load_rows(p, mw, nw, lane, 0, r0, r1);
+  }
+};
+
+// The same epilogues for a wave tile of TI 32-row blocks, software-pipelined over the blocks.  Calling epilogue_rows once per
+// block serialises, per block, the global loads it starts with (bias / gate vectors, the fp32 residual rows, the RoPE table rows)
+// with the slab round trip behind them -- measured with in-kernel timestamps: 3.9 us of a 14.7 us out-projection launch at batch 1,
+// 11-17 us per 256 x 256 tile at full chip.  Here the column vectors are loaded once per wave tile (COLS_ONCE; off where the
+// registers do not allow it), block 0's row operands arrive with `pre`, and those of block i+1 are in flight while block i goes
+// through the slab.
+template <int EPI, int TI, int TJ, bool COLS_ONCE, bool AHEAD = true>
+__device__ __forceinline__ void epilogue_row_blocks(const GemmParams& p, f32x16 (&acc)[TI][TJ], char* slab, int mw, int nw, int lane,
+                                                    EpiPre<EPI, TJ, COLS_ONCE>& pre) {
+  static_assert(EPI != EPI_BIAS_GELU_F8 && EPI != EPI_V_T, "bf16-path row epilogues only");
+  constexpr int WTN = 32 * TJ;
+  using Pre = EpiPre<EPI, TJ, COLS_ONCE>;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const float* gate = pre.gate;
+  auto bias_of = [&](int j, int g) -> float4 {
+    if (COLS_ONCE) return pre.bias_c[j * 4 + g];
+    return *reinterpret_cast<const float4*>(p.bias + nw + j * 32 + 8 * g + 4 * hi);
+  };
+  auto gate_of = [&](int j, int g) -> float4 {
+    if (COLS_ONCE) return pre.gate_c[EPI == EPI_GATE_RES ? j * 4 + g : 0];
+    return *reinterpret_cast<const float4*>(gate + nw + j * 32 + 8 * g + 4 * hi);
+  };
+
+  if constexpr (EPI == EPI_GATE_RES) {
+    using S = SlabF32<32, WTN>;
+    const int rr = lane / S::CPR, ch = lane % S::CPR;
+    float4 xnext[Pre::NR], unused[1];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+      float4 xin[Pre::NR];
+      if (AHEAD || i == 0) {
+#pragma unroll
+        for (int it = 0; it < Pre::NR; ++it) xin[it] = i == 0 ? pre.r0[it] : xnext[it];
+        if (AHEAD && i + 1 < TI) pre.load_rows(p, mw, nw, lane, i + 1, xnext, unused);
+      } else {
+        pre.load_rows(p, mw, nw, lane, i, xin, unused);
+      }
+#pragma unroll
+      for (int j = 0; j < TJ; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int nl = j * 32 + 8 * g + 4 * hi;
+          const float4 bias = bias_of(j, g), gt = gate_of(j, g);
+          *reinterpret_cast<float4*>(slab + l31 * S::PITCH + nl * 4) =
+              make_float4(gt.x * (acc[i][j][4 * g + 0] + bias.x), gt.y * (acc[i][j][4 * g + 1] + bias.y),
+                          gt.z * (acc[i][j][4 * g + 2] + bias.z), gt.w * (acc[i][j][4 * g + 3] + bias.w));
+        }
+#pragma unroll
+      for (int it = 0; it < S::ITERS; ++it) {
+        const float4 d = *reinterpret_cast<const float4*>(slab + (it * S::RPI + rr) * S::PITCH + ch * 16);
+        const int m = mw + 32 * i + it * S::RPI + rr;
+        const int b2 = m / p.seq_pitch, pos = m - b2 * p.seq_pitch;
+        bool live = m < p.M && pos < p.seq_valid && (nw + ch * 4) < p.n_valid;
+        if (p.kv_len) live = live && pos < p.kv_len[b2 % p.batch];
+        if (live) {
+          float4 x = xin[it];
+          x.x += d.x; x.y += d.y; x.z += d.z; x.w += d.w;
+          store_wt_b128(p.out_f32 + (size_t)m * p.ldc + nw + ch * 4, __builtin_bit_cast(u32x4, x));
+        }
+      }
+    }
+  } else if constexpr (EPI == EPI_QK_ROPE) {
+    using S = SlabF32<32, WTN>;
+    constexpr int CPR = WTN / 8, RPI = 64 / CPR, ITERS = 32 / RPI;   // 8 head dims (16 B of bf16) per lane
+    static_assert(ITERS == Pre::NR, "row operand count");
+    const int rr = lane / CPR, ch = lane % CPR;
+    const int inner = p.heads * 64, n = nw + ch * 8;
+    const int which = n / inner, head = (n % inner) >> 6, d = n & 63;
+    bf16_t* base = (which == 0 ? p.q : p.k) + (size_t)head * p.seq_pitch * 64 + d;
+    float4 cnext[ITERS], snext[ITERS];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+      float4 cs[ITERS], sn[ITERS];
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) { cs[it] = i == 0 ? pre.r0[it] : cnext[it]; sn[it] = i == 0 ? pre.r1[it] : snext[it]; }
+      if (i + 1 < TI) pre.load_rows(p, mw, nw, lane, i + 1, cnext, snext);
+#pragma unroll
+      for (int j = 0; j < TJ; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int nl = j * 32 + 8 * g + 4 * hi;
+          const float4 bias = bias_of(j, g);
+          *reinterpret_cast<float4*>(slab + l31 * S::PITCH + nl * 4) =
+              make_float4(acc[i][j][4 * g + 0] + bias.x, acc[i][j][4 * g + 1] + bias.y, acc[i][j][4 * g + 2] + bias.z,
+                          acc[i][j][4 * g + 3] + bias.w);
+        }
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        const int m = mw + 32 * i + it * RPI + rr;
+        const int b2 = m / p.seq_pitch, pos = m - b2 * p.seq_pitch;
+        const bool live = m < p.M && pos < p.seq_valid;
+        const float4 c = cs[it], sv = sn[it];
+        const float4 a = *reinterpret_cast<const float4*>(slab + (it * RPI + rr) * S::PITCH + ch * 32);
+        const float4 b = *reinterpret_cast<const float4*>(slab + (it * RPI + rr) * S::PITCH + ch * 32 + 16);
+        bf16x8 o;
+        o[0] = (bf16_t)(a.x * c.x - a.y * sv.x); o[1] = (bf16_t)(a.y * c.x + a.x * sv.x);
+        o[2] = (bf16_t)(a.z * c.y - a.w * sv.y); o[3] = (bf16_t)(a.w * c.y + a.z * sv.y);
+        o[4] = (bf16_t)(b.x * c.z - b.y * sv.z); o[5] = (bf16_t)(b.y * c.z + b.x * sv.z);
+        o[6] = (bf16_t)(b.z * c.w - b.w * sv.w); o[7] = (bf16_t)(b.w * c.w + b.z * sv.w);
+        if (live) store_wt_b128(base + ((size_t)b2 * p.heads * p.seq_pitch + pos) * 64, __builtin_bit_cast(u32x4, o));
+      }
+    }
+  } else if constexpr (EPI == EPI_BIAS_F32) {
+    using S = SlabF32<32, WTN>;
+    const int rr = lane / S::CPR, ch = lane % S::CPR;
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+#pragma unroll
+      for (int j = 0; j < TJ; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int nl = j * 32 + 8 * g + 4 * hi;
+          const float4 bias = bias_of(j, g);
+          *reinterpret_cast<float4*>(slab + l31 * S::PITCH + nl * 4) =
+              make_float4(acc[i][j][4 * g + 0] + bias.x, acc[i][j][4 * g + 1] + bias.y, acc[i][j][4 * g + 2] + bias.z,
+                          acc[i][j][4 * g + 3] + bias.w);
+        }
+#pragma unroll
+      for (int it = 0; it < S::ITERS; ++it) {
+        const int m = mw + 32 * i + it * S::RPI + rr;
+        const int b2 = m / p.seq_pitch, pos = m - b2 * p.seq_pitch;
+        const float4 d = *reinterpret_cast<const float4*>(slab + (it * S::RPI + rr) * S::PITCH + ch * 16);
+        if (m < p.M && pos < p.seq_valid && (nw + ch * 4) < p.n_valid) *reinterpret_cast<float4*>(p.out_f32 + (size_t)m * p.ldc + nw + ch * 4) = d;
+      }
+    }
+  } else {   // bf16 outputs: plain, GELU-tanh
+    using S = SlabBf16<32, WTN>;
+    const int rr = lane / S::CPR, ch = lane % S::CPR;
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+#pragma unroll
+      for (int j = 0; j < TJ; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int nl = j * 32 + 8 * g + 4 * hi;
+          const float4 bias = bias_of(j, g);
+          float v0 = acc[i][j][4 * g + 0] + bias.x, v1 = acc[i][j][4 * g + 1] + bias.y;
+          float v2 = acc[i][j][4 * g + 2] + bias.z, v3 = acc[i][j][4 * g + 3] + bias.w;
+          bf16x4 o;
+          if (EPI == EPI_BIAS_GELU_BF16) o = pack4(gelu_tanh_f(v0), gelu_tanh_f(v1), gelu_tanh_f(v2), gelu_tanh_f(v3));
+          else o = pack4(v0, v1, v2, v3);
+          *reinterpret_cast<bf16x4*>(slab + l31 * S::PITCH + nl * 2) = o;
+        }
+#pragma unroll
+      for (int it = 0; it < S::ITERS; ++it) {
+        const int m = mw + 32 * i + it * S::RPI + rr;
+        const int b2 = m / p.seq_pitch, pos = m - b2 * p.seq_pitch;
+        const u32x4 d = *reinterpret_cast<const u32x4*>(slab + (it * S::RPI + rr) * S::PITCH + ch * 16);
+        if (m < p.M && pos < p.seq_valid && (nw + ch * 8) < p.n_valid) store_wt_b128(p.out_bf16 + (size_t)m * p.ldc + nw + ch * 8, d);
+      }
+    }
+  }
+}
+
 // ---- plain orientation, used only for the V projection (EPI_V_T): lane -> column n (= head dim d),
 //      register r -> row m = mw + 32 i + (r&3) + 8 (r>>2) + 4 (lane>>5).  The slab is [d][pos] so that v^T rows
 //      (contiguous positions) leave as whole 64/128-B segments.
@@ -414,8 +631,11 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, int m
     for (int j = 0; j < TJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  constexpr bool PREFETCH_EPI = SWAP && EPI != EPI_BIAS_GELU_F8;
+  EpiPre<EPI, TJ, true> pre;
 
   const int nk = (int)(rowb >> 7);
+  if (p.dbg && tid == 0) { p.dbg[blockIdx.x * 4 + 0] = wall_clock64(); p.dbg[blockIdx.x * 4 + 1] = wall_clock64(); }
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s)
     if (s < nk) issue(s, s);
@@ -467,6 +687,8 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, int m
       if (kt + NSTAGE - 2 < nk) wait_vmcnt<PW * (NSTAGE - 2)>();
       else wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();
+      // last K-tile: nothing is in flight and no vmcnt wait follows -- request the epilogue's global operands under its MFMAs
+      if constexpr (PREFETCH_EPI) { if (kt == nk - 1) pre.load(p, m0 + wm * WTM, n0 + wn * WTN, lane); }
       const int nt = kt + NSTAGE - 1;
       int ns = stage + NSTAGE - 1;
       ns = ns >= NSTAGE ? ns - NSTAGE : ns;
@@ -527,15 +749,21 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, int m
     }
   }
   __syncthreads();   // every wave is done with the ring: its LDS becomes the epilogue slabs
+  if (p.dbg && tid == 0) p.dbg[blockIdx.x * 4 + 2] = wall_clock64();
   // one 32-row block of the wave tile at a time through a small wave-private slab (LDS ops of a wave execute in order, so
   // the slab can be rewritten right after it was read): keeps the kernel's LDS footprint = the ring, not ring + big slabs
   char* slab = smem + wave * slab_bytes<EPI, 32, WTN>();
+  if constexpr (SWAP && EPI != EPI_BIAS_GELU_F8) {
+    epilogue_row_blocks<EPI, TI, TJ, true>(p, acc, slab, m0 + wm * WTM, n0 + wn * WTN, lane, pre);
+  } else {
 #pragma unroll
-  for (int i = 0; i < TI; ++i) {
-    f32x16 (&blk)[1][TJ] = *reinterpret_cast<f32x16 (*)[1][TJ]>(&acc[i]);
-    if (SWAP) epilogue_rows<EPI, 1, TJ>(p, blk, slab, m0 + wm * WTM + 32 * i, n0 + wn * WTN, lane);
-    else epilogue_vt<1, TJ>(p, blk, slab, m0 + wm * WTM + 32 * i, n0 + wn * WTN, lane);
+    for (int i = 0; i < TI; ++i) {
+      f32x16 (&blk)[1][TJ] = *reinterpret_cast<f32x16 (*)[1][TJ]>(&acc[i]);
+      if (SWAP) epilogue_rows<EPI, 1, TJ>(p, blk, slab, m0 + wm * WTM + 32 * i, n0 + wn * WTN, lane);
+      else epilogue_vt<1, TJ>(p, blk, slab, m0 + wm * WTM + 32 * i, n0 + wn * WTN, lane);
+    }
   }
+  if (p.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); if (tid == 0) p.dbg[blockIdx.x * 4 + 3] = wall_clock64(); }
 }
 
 // ================================================================================================================
@@ -650,9 +878,11 @@ __device__ __forceinline__ void gemm_body_pp(const GemmParams& p, char* smem, in
   };
 
   // ---- prologue: the four half-tiles of K-tile 0 in consumption order (W0, A0, W1, A1); W0 and A0 must have landed
+  if (p.dbg && tid == 0) p.dbg[blockIdx.x * 4 + 0] = wall_clock64();
   issue_half(1, 0, 0); issue_half(0, 0, 0); issue_half(1, 1, 0); issue_half(0, 1, 0);
   wait_vmcnt<4>();
   __builtin_amdgcn_s_barrier();
+  if (p.dbg && tid == 0) p.dbg[blockIdx.x * 4 + 1] = wall_clock64();
   if (wm == 1) __builtin_amdgcn_s_barrier();     // stagger: the second wave row runs one barrier behind the first
 
   for (int t = 0; t < nk; ++t) {
@@ -684,14 +914,26 @@ __device__ __forceinline__ void gemm_body_pp(const GemmParams& p, char* smem, in
   }
   if (wm == 0) __builtin_amdgcn_s_barrier();     // the first wave row catches up: equal barrier counts for all waves
   __syncthreads();   // every wave is done with the half-tiles: the LDS becomes the epilogue slabs
+  if (p.dbg && tid == 0) p.dbg[blockIdx.x * 4 + 2] = wall_clock64();
   char* slab = smem + wave * slab_bytes<EPI, 32, 64>();
+  if constexpr (SWAP) {
+    // 128 accumulator registers are still live here: the gate + residual epilogue has no room for its column vectors or a second
+    // set of residual rows (and gained nothing from them: at full chip it is bound by the fp32 read-modify-write traffic), and
+    // the loop (224-256 VGPRs) none for an early request
+    EpiPre<EPI, 2, EPI != EPI_GATE_RES> pre;
+    pre.load(p, m0 + wm * 128, n0 + wn * 64, lane);
+    epilogue_row_blocks<EPI, 4, 2, EPI != EPI_GATE_RES, EPI != EPI_GATE_RES>(p, acc, slab, m0 + wm * 128, n0 + wn * 64, lane, pre);
+  } else {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    f32x16 (&blk)[1][2] = *reinterpret_cast<f32x16 (*)[1][2]>(&acc[i]);
-    if (SWAP) epilogue_rows<EPI, 1, 2>(p, blk, slab, m0 + wm * 128 + 32 * i, n0 + wn * 64, lane);
-    else epilogue_vt<1, 2>(p, blk, slab, m0 + wm * 128 + 32 * i, n0 + wn * 64, lane);
+    for (int i = 0; i < 4; ++i) {
+      f32x16 (&blk)[1][2] = *reinterpret_cast<f32x16 (*)[1][2]>(&acc[i]);
+      epilogue_vt<1, 2>(p, blk, slab, m0 + wm * 128 + 32 * i, n0 + wn * 64, lane);
+    }
   }
+  if (p.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); if (tid == 0) p.dbg[blockIdx.x * 4 + 3] = wall_clock64(); }
 }
+
+// ================================================================================================================
 
 // ================================================================================================================
 // The same ping-pong idea on the 256 x 128 tile of the batch-1 shapes (bf16): 8 waves as 4 (M) x 2 (N), 64 x 64 outputs each, the two
@@ -784,6 +1026,7 @@ __device__ __forceinline__ void gemm_body_pp2(const GemmParams& p, char* smem, i
   };
 
   // prologue: K-tiles 0 and 1 requested, K-tile 0 landed
+  if (p.dbg && tid == 0) p.dbg[blockIdx.x * 4 + 0] = wall_clock64();
 #pragma unroll
   for (int x = 0; x < 6; ++x) issue_piece(0, 0, x);
   if (nk > 1) {
@@ -794,8 +1037,10 @@ __device__ __forceinline__ void gemm_body_pp2(const GemmParams& p, char* smem, i
     wait_vmcnt<0>();
   }
   __builtin_amdgcn_s_barrier();
+  if (p.dbg && tid == 0) p.dbg[blockIdx.x * 4 + 1] = wall_clock64();
   if (wm >= 2) __builtin_amdgcn_s_barrier();     // stagger: wave rows 2-3 run one barrier behind rows 0-1
 
+  EpiPre<EPI, 2, true> pre;
   int stage = 0;
   for (int t = 0; t < nk; ++t) {
     int s2 = stage + 2;
@@ -807,6 +1052,8 @@ __device__ __forceinline__ void gemm_body_pp2(const GemmParams& p, char* smem, i
 #pragma unroll
       for (int x = 0; x < 3; ++x) issue_piece(s2, t + 2, x);
     }
+    // last K-tile: nothing is in flight and no vmcnt wait follows -- request the epilogue's global operands under its MFMAs
+    if constexpr (SWAP) { if (t == nk - 1) pre.load(p, m0 + wm * 64, n0 + wn * 64, lane); }
     l_to_m();
     mma();
     m_to_l();
@@ -816,7 +1063,7 @@ __device__ __forceinline__ void gemm_body_pp2(const GemmParams& p, char* smem, i
 #pragma unroll
       for (int x = 3; x < 6; ++x) issue_piece(s2, t + 2, x);
       wait_vmcnt<6>();
-    } else {
+    } else if (t + 1 < nk) {
       wait_vmcnt<0>();
     }
     l_to_m();
@@ -826,13 +1073,18 @@ __device__ __forceinline__ void gemm_body_pp2(const GemmParams& p, char* smem, i
   }
   if (wm < 2) __builtin_amdgcn_s_barrier();      // rows 0-1 catch up: equal barrier counts
   __syncthreads();
+  if (p.dbg && tid == 0) p.dbg[blockIdx.x * 4 + 2] = wall_clock64();
   char* slab = smem + wave * slab_bytes<EPI, 32, 64>();
+  if constexpr (SWAP) {
+    epilogue_row_blocks<EPI, 2, 2, true>(p, acc, slab, m0 + wm * 64, n0 + wn * 64, lane, pre);
+  } else {
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    f32x16 (&blk)[1][2] = *reinterpret_cast<f32x16 (*)[1][2]>(&acc[i]);
-    if (SWAP) epilogue_rows<EPI, 1, 2>(p, blk, slab, m0 + wm * 64 + 32 * i, n0 + wn * 64, lane);
-    else epilogue_vt<1, 2>(p, blk, slab, m0 + wm * 64 + 32 * i, n0 + wn * 64, lane);
+    for (int i = 0; i < 2; ++i) {
+      f32x16 (&blk)[1][2] = *reinterpret_cast<f32x16 (*)[1][2]>(&acc[i]);
+      epilogue_vt<1, 2>(p, blk, slab, m0 + wm * 64 + 32 * i, n0 + wn * 64, lane);
+    }
   }
+  if (p.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); if (tid == 0) p.dbg[blockIdx.x * 4 + 3] = wall_clock64(); }
 }
 
 template <int EPI>
@@ -968,7 +1220,6 @@ hipError_t dispatch(const GemmParams& p, int tile, hipStream_t s) {
     case T256x256:
       if constexpr (!F8) return LaunchPP<EPI>::run(p, s);
       else return hipErrorInvalidValue;
-
     default: return hipErrorInvalidValue;
   }
 }
