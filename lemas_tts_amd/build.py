@@ -22,6 +22,7 @@ INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          "-I", INCLUDE, "-I", CSRC]
+FLAGS += os.environ.get("LEMAS_EXTRA_HIPCC_FLAGS", "").split()     # e.g. -DLEMAS_PHASE_TIMESTAMPS for a measurement build
 
 
 def _sources():

@@ -125,7 +125,9 @@ struct GemmParams {
   // XCD block grid of the tile order: the tile grid is cut into xcd_gx x (8 / xcd_gx) blocks, one per XCD (gemm_bf16.hip
   // tile_coords).  0 = let the launcher choose (minimises the fabric-side fetch gy * |A| + gx * |W|); 8 = the row-major order.
   int xcd_gx;
-  unsigned long long* dbg;   // EXPERIMENT: per-workgroup phase timestamps [grid][4]
+#ifdef LEMAS_PHASE_TIMESTAMPS
+  unsigned long long* dbg;   // measurement builds: per-workgroup phase timestamps [grid][4] (gemm_bf16.hip PHASE_STAMP)
+#endif
 };
 
 // ---- internal launchers (one per .hip translation unit) ----------------------------------------

@@ -75,12 +75,7 @@ __global__ void fill_pattern_kernel(bf16_t* p, size_t n, unsigned seed) {
 
 extern "C" {
 
-static int g_dbg_phases = 0;
-int lemas_k_tile_override(int32_t n1024, int32_t n2048, int32_t xcd_gx) {
-  if (xcd_gx == 7777) { g_dbg_phases = 1; xcd_gx = 0; }
-  gemm_bf16_force_tiles(n1024, n2048, xcd_gx);
-  return 0;
-}
+int lemas_k_tile_override(int32_t n1024, int32_t n2048, int32_t xcd_gx) { gemm_bf16_force_tiles(n1024, n2048, xcd_gx); return 0; }
 
 int lemas_k_linear_bf16(const float* A, const float* W, const float* bias, float* out, int32_t M, int32_t N, int32_t K,
                         int32_t act, void* stream) {
@@ -363,7 +358,8 @@ extern "C" int lemas_k_bench(const char* what, int32_t M, int32_t N, int32_t K, 
     const int epi = w == "gemm_gelu8" ? EPI_BIAS_GELU_F8 : w == "gemm_gelu" ? EPI_BIAS_GELU_BF16 : w == "gemm_gate" ? EPI_GATE_RES : w == "gemm_qk" ? EPI_QK_ROPE : w == "gemm_v" ? EPI_V_T : EPI_BIAS_F32;
     if ((epi == EPI_QK_ROPE && N != 2048) || (epi == EPI_V_T && N != 1024)) { set_error("bench: gemm_qk needs N = 2048, gemm_v N = 1024"); return LEMAS_E_ARG; }
     rc = time_it([&]() { return launch_gemm_bf16_tile(epi, p, variant, s); });
-    if (rc == 0 && g_dbg_phases && variant >= 16) {   // EXPERIMENT: phase timestamps of one launch
+#ifdef LEMAS_PHASE_TIMESTAMPS
+    if (rc == 0 && variant >= 16) {   // phase timestamps of one more launch
       const int bm_ = variant == 17 || variant == 18 ? 128 : variant == 19 ? 64 : 256, bn_ = variant == 22 ? 256 : variant == 16 || variant == 17 ? 128 : 64;
       const int grid = ((M + bm_ - 1) / bm_) * (Np / bn_);
       unsigned long long* d = sc.get<unsigned long long>((size_t)grid * 4);
@@ -384,6 +380,7 @@ extern "C" int lemas_k_bench(const char* what, int32_t M, int32_t N, int32_t K, 
               w.c_str(), M, N, K, grid, (t3 - t0) * 0.01, st[0] / std::max(cnt[0], 1), sp[0] / std::max(cnt[0], 1), sl[0] / std::max(cnt[0], 1), se[0] / std::max(cnt[0], 1),
               cnt[1], st[1] / std::max(cnt[1], 1), sp[1] / std::max(cnt[1], 1), sl[1] / std::max(cnt[1], 1), se[1] / std::max(cnt[1], 1));
     }
+#endif
   } else if (w == "attention") {
     // M = sequence length, N = batch*heads
     const int n = M, bh = N, npad = (n + 127) & ~127, pitch = npad;

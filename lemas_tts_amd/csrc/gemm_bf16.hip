@@ -33,6 +33,16 @@ namespace {
 
 constexpr int BK = 64;
 
+// Measurement builds only (-DLEMAS_PHASE_TIMESTAMPS, see profiles/r02_kbench_phases.txt): thread 0 of every workgroup stamps the 100 MHz
+// wall clock at entry, after the prologue, after the K loop and after its last store has drained.  Compiled out of the product.
+#ifdef LEMAS_PHASE_TIMESTAMPS
+#define PHASE_STAMP(k) do { if (p.dbg && threadIdx.x == 0) p.dbg[blockIdx.x * 4 + (k)] = wall_clock64(); } while (0)
+#define PHASE_STAMP_END() do { if (p.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); PHASE_STAMP(3); } } while (0)
+#else
+#define PHASE_STAMP(k) do { } while (0)
+#define PHASE_STAMP_END() do { } while (0)
+#endif
+
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
 // XCD-aware tile order.  Workgroups are dispatched round-robin over the 8 XCDs (private, non-coherent L2s), so workgroup `bid` of
@@ -635,7 +645,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, int m
   EpiPre<EPI, TJ, true> pre;
 
   const int nk = (int)(rowb >> 7);
-  if (p.dbg && tid == 0) { p.dbg[blockIdx.x * 4 + 0] = wall_clock64(); p.dbg[blockIdx.x * 4 + 1] = wall_clock64(); }
+  PHASE_STAMP(0); PHASE_STAMP(1);
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s)
     if (s < nk) issue(s, s);
@@ -749,7 +759,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, int m
     }
   }
   __syncthreads();   // every wave is done with the ring: its LDS becomes the epilogue slabs
-  if (p.dbg && tid == 0) p.dbg[blockIdx.x * 4 + 2] = wall_clock64();
+  PHASE_STAMP(2);
   // one 32-row block of the wave tile at a time through a small wave-private slab (LDS ops of a wave execute in order, so
   // the slab can be rewritten right after it was read): keeps the kernel's LDS footprint = the ring, not ring + big slabs
   char* slab = smem + wave * slab_bytes<EPI, 32, WTN>();
@@ -763,7 +773,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, int m
       else epilogue_vt<1, TJ>(p, blk, slab, m0 + wm * WTM + 32 * i, n0 + wn * WTN, lane);
     }
   }
-  if (p.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); if (tid == 0) p.dbg[blockIdx.x * 4 + 3] = wall_clock64(); }
+  PHASE_STAMP_END();
 }
 
 // ================================================================================================================
@@ -878,11 +888,11 @@ __device__ __forceinline__ void gemm_body_pp(const GemmParams& p, char* smem, in
   };
 
   // ---- prologue: the four half-tiles of K-tile 0 in consumption order (W0, A0, W1, A1); W0 and A0 must have landed
-  if (p.dbg && tid == 0) p.dbg[blockIdx.x * 4 + 0] = wall_clock64();
+  PHASE_STAMP(0);
   issue_half(1, 0, 0); issue_half(0, 0, 0); issue_half(1, 1, 0); issue_half(0, 1, 0);
   wait_vmcnt<4>();
   __builtin_amdgcn_s_barrier();
-  if (p.dbg && tid == 0) p.dbg[blockIdx.x * 4 + 1] = wall_clock64();
+  PHASE_STAMP(1);
   if (wm == 1) __builtin_amdgcn_s_barrier();     // stagger: the second wave row runs one barrier behind the first
 
   for (int t = 0; t < nk; ++t) {
@@ -914,7 +924,7 @@ __device__ __forceinline__ void gemm_body_pp(const GemmParams& p, char* smem, in
   }
   if (wm == 0) __builtin_amdgcn_s_barrier();     // the first wave row catches up: equal barrier counts for all waves
   __syncthreads();   // every wave is done with the half-tiles: the LDS becomes the epilogue slabs
-  if (p.dbg && tid == 0) p.dbg[blockIdx.x * 4 + 2] = wall_clock64();
+  PHASE_STAMP(2);
   char* slab = smem + wave * slab_bytes<EPI, 32, 64>();
   if constexpr (SWAP) {
     // 128 accumulator registers are still live here: the gate + residual epilogue has no room for its column vectors or a second
@@ -930,7 +940,7 @@ __device__ __forceinline__ void gemm_body_pp(const GemmParams& p, char* smem, in
       epilogue_vt<1, 2>(p, blk, slab, m0 + wm * 128 + 32 * i, n0 + wn * 64, lane);
     }
   }
-  if (p.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); if (tid == 0) p.dbg[blockIdx.x * 4 + 3] = wall_clock64(); }
+  PHASE_STAMP_END();
 }
 
 // ================================================================================================================
@@ -1026,7 +1036,7 @@ __device__ __forceinline__ void gemm_body_pp2(const GemmParams& p, char* smem, i
   };
 
   // prologue: K-tiles 0 and 1 requested, K-tile 0 landed
-  if (p.dbg && tid == 0) p.dbg[blockIdx.x * 4 + 0] = wall_clock64();
+  PHASE_STAMP(0);
 #pragma unroll
   for (int x = 0; x < 6; ++x) issue_piece(0, 0, x);
   if (nk > 1) {
@@ -1037,7 +1047,7 @@ __device__ __forceinline__ void gemm_body_pp2(const GemmParams& p, char* smem, i
     wait_vmcnt<0>();
   }
   __builtin_amdgcn_s_barrier();
-  if (p.dbg && tid == 0) p.dbg[blockIdx.x * 4 + 1] = wall_clock64();
+  PHASE_STAMP(1);
   if (wm >= 2) __builtin_amdgcn_s_barrier();     // stagger: wave rows 2-3 run one barrier behind rows 0-1
 
   EpiPre<EPI, 2, true> pre;
@@ -1073,7 +1083,7 @@ __device__ __forceinline__ void gemm_body_pp2(const GemmParams& p, char* smem, i
   }
   if (wm < 2) __builtin_amdgcn_s_barrier();      // rows 0-1 catch up: equal barrier counts
   __syncthreads();
-  if (p.dbg && tid == 0) p.dbg[blockIdx.x * 4 + 2] = wall_clock64();
+  PHASE_STAMP(2);
   char* slab = smem + wave * slab_bytes<EPI, 32, 64>();
   if constexpr (SWAP) {
     epilogue_row_blocks<EPI, 2, 2, true>(p, acc, slab, m0 + wm * 64, n0 + wn * 64, lane, pre);
@@ -1084,7 +1094,7 @@ __device__ __forceinline__ void gemm_body_pp2(const GemmParams& p, char* smem, i
       epilogue_vt<1, 2>(p, blk, slab, m0 + wm * 64 + 32 * i, n0 + wn * 64, lane);
     }
   }
-  if (p.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); if (tid == 0) p.dbg[blockIdx.x * 4 + 3] = wall_clock64(); }
+  PHASE_STAMP_END();
 }
 
 template <int EPI>
