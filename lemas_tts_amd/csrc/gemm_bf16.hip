@@ -1157,17 +1157,23 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_bf16_kernel(const GemmPar
 //             gemm_body_pp2 (K loop 0.68 vs 0.78 us per K-tile), fp8 on the lock-step hand-scheduled loop of gemm_body
 //   T128x128: 8 waves (2 x 4), 3-stage ring,  96 KB      -- mid-size shapes
 //   T128x64 : 4 waves (2 x 2), 3-stage ring,  72 KB      -- short utterances (2 workgroups per CU)
+//   T128x128W4: the same 128 x 128 tile with FOUR waves (2 x 2, 64 x 64 outputs each: 16 instead of 24 fragment reads per wave and K-tile, one
+//             wave per SIMD), 96 KB.  Alone it is 5-10 % SLOWER than the 8-wave form (13.3 -> 14.6 us for the out-projection at M = 1875); with
+//             two CFG lanes in flight it is the better FF1 tile end to end (+2.3 % on configs[1] against the 256 x 128 ping-pong tile, which is
+//             itself 5 % better there than the 8-wave 128 x 128): 240 workgroups of half the register / wave-slot footprint pack with the other
+//             lane's kernels where 128 eight-wave workgroups of 147 KB do not
 //   T64x64  : 4 waves (2 x 2), 3-stage ring,  48 KB      -- N <= 1024 GEMMs of short utterances (M = 768: 8.0 vs 10.2 us, 12.1 vs 15.5 at K = 2048)
 //   T256x256: 8 waves (2 x 4), ping-pong schedule of gemm_body_pp, 128 KB -- batched shapes (several rounds of tiles per CU);
 //             bf16 only.  Its K loop runs at 1.45 PFLOP/s-equivalent per CU (K = 4096: 89 us for 64 tiles); with K = 1024 the
 //             ~12 us of launch + prologue + epilogue per round leave 0.86-1.0 PFLOP/s at M = 30720 (tools/kbench.py)
-enum GemmTile : int { T256x128 = 16, T128x128 = 17, T128x64 = 18, T64x64 = 19, T256x256 = 22 };
+enum GemmTile : int { T256x128 = 16, T128x128 = 17, T128x64 = 18, T64x64 = 19, T256x256 = 22, T128x128W4 = 26 };
 
 template <int TILE> struct TileCfg;
 template <> struct TileCfg<T256x128> { static constexpr int BM = 256, BN = 128, ST = 3, WM = 4, WN = 2; };
 template <> struct TileCfg<T128x128> { static constexpr int BM = 128, BN = 128, ST = 3, WM = 2, WN = 4; };
 template <> struct TileCfg<T128x64>  { static constexpr int BM = 128, BN = 64,  ST = 3, WM = 2, WN = 2; };
 template <> struct TileCfg<T64x64>   { static constexpr int BM = 64,  BN = 64,  ST = 3, WM = 2, WN = 2; };
+template <> struct TileCfg<T128x128W4> { static constexpr int BM = 128, BN = 128, ST = 3, WM = 2, WN = 2; };
 
 template <int EPI, int TILE, bool F8>
 struct Launch {
@@ -1194,7 +1200,7 @@ struct Launch {
 
 // Largest tile that still yields about one workgroup per CU (measured at M = 1920 / 3840 / 18432 with tools/kbench.py).
 // With two CFG lanes in flight each launch only needs half the chip (p.concurrency = 2: +1.8 % end to end for the larger tiles).
-int g_force_n1024 = 0, g_force_n2048 = 0, g_force_gx = 0;   // measurement hook (lemas_k_tile_override, include/lemas_hip_test.h); 0 = off
+int g_force_n1024 = 0, g_force_n2048 = 0, g_force_gx = 0, g_force_qkv = 0;   // measurement hook (lemas_k_tile_override, include/lemas_hip_test.h); 0 = off
 
 int pick_tile(const GemmParams& p) {
   if (!p.f8 && p.N == 1024 && g_force_n1024) return g_force_n1024;
@@ -1205,6 +1211,11 @@ int pick_tile(const GemmParams& p) {
   int tile = t256 >= want ? T256x128 : t128 >= want ? T128x128 : T128x64;
   // short utterances: when even 128x64 tiles leave most CUs without work, halve the tile height (N <= 1024: out-proj, FF2, V)
   if (tile == T128x64 && p.N <= 1024 && (long)((p.M + 127) / 128) * (p.N / 64) < 130) tile = T64x64;
+  // Two lanes in flight and a stand-alone N >= 2048 GEMM (FF1) of at most 256 128 x 128 tiles: the 4-wave form of that tile instead of the
+  // 256 x 128 ping-pong tile.  End to end on configs[1] (M = 1875 per lane; tools/e2e_ab.py, ONE engine re-captured per arm, 6 interleaved
+  // rounds, profiles/r02_e2e_ab_w4_tile.txt): 87.1 -> 89.1 audio-s/s (+2.3 %); M = 1152: ties; M = 2304 (288 tiles): -2 %, M = 3456: -5 % (not
+  // chosen there).  For the N = 1024 GEMMs it LOSES 1 % against the 8-wave 128 x 128 tile, for the fused QK+V launch 7 %.
+  if (!p.f8 && conc >= 2 && p.N >= 2048 && (tile == T256x128 || tile == T128x128) && t128 <= 256) tile = T128x128W4;
   if (!p.f8 && p.N % 256 == 0 && p.N >= 1024) {
     // batched workloads: the ping-pong 256x256 tile once its tiles cover the CUs of this launch 1.5 times (N >= 2048) / 1.1 times
     // (N = 1024).  Measured end to end with two lanes in flight (tools/e2e_ab.py --batch B, profiles/r02_e2e_ab_pingpong_batch.txt):
@@ -1227,6 +1238,7 @@ hipError_t dispatch(const GemmParams& p, int tile, hipStream_t s) {
     case T128x128: return Launch<EPI, T128x128, F8>::run(p, s);
     case T128x64: return Launch<EPI, T128x64, F8>::run(p, s);
     case T64x64: return Launch<EPI, T64x64, F8>::run(p, s);
+    case T128x128W4: return Launch<EPI, T128x128W4, F8>::run(p, s);
     case T256x256:
       if constexpr (!F8) return LaunchPP<EPI>::run(p, s);
       else return hipErrorInvalidValue;
@@ -1241,6 +1253,7 @@ hipError_t init_epi() {
   if ((e = Launch<EPI, T128x128, F8>::init()) != hipSuccess) return e;
   if ((e = Launch<EPI, T128x64, F8>::init()) != hipSuccess) return e;
   if ((e = Launch<EPI, T64x64, F8>::init()) != hipSuccess) return e;
+  if ((e = Launch<EPI, T128x128W4, F8>::init()) != hipSuccess) return e;
   if constexpr (!F8) {
     if ((e = LaunchPP<EPI>::init()) != hipSuccess) return e;
     if ((e = LaunchPP2<EPI>::init()) != hipSuccess) return e;
@@ -1295,6 +1308,7 @@ struct LaunchQkv {
 
 // tile of the fused QK+V launch: the largest whose QK part alone still gives ~100 workgroups per lane (two lanes share the chip)
 int pick_qkv_tile(const GemmParams& pq) {
+  if (g_force_qkv) return g_force_qkv;
   if (g_force_n2048 == T256x128 || g_force_n2048 == T128x128 || g_force_n2048 == T128x64) return g_force_n2048;
   const long t256 = (long)((pq.M + 255) / 256) * (pq.N / 128), t128 = (long)((pq.M + 127) / 128) * (pq.N / 128);
   return t256 >= 100 ? T256x128 : t128 >= 100 ? T128x128 : T128x64;
@@ -1302,7 +1316,11 @@ int pick_qkv_tile(const GemmParams& pq) {
 
 }  // namespace
 
-void gemm_bf16_force_tiles(int n1024, int n2048, int xcd_gx) { g_force_n1024 = n1024; g_force_n2048 = n2048; g_force_gx = xcd_gx; }
+void gemm_bf16_force_tiles(int n1024, int n2048, int xcd_gx) {
+  g_force_qkv = 0;
+  if (xcd_gx >= 100) { g_force_qkv = xcd_gx - 100; xcd_gx = 0; }     // measurement hook: tile of the fused QK+V launch
+  g_force_n1024 = n1024; g_force_n2048 = n2048; g_force_gx = xcd_gx;
+}
 
 hipError_t gemm_bf16_init() {
   hipError_t e;
@@ -1316,6 +1334,8 @@ hipError_t gemm_bf16_init() {
   if ((e = LaunchQkv<false, T256x128>::init()) != hipSuccess) return e;
   if ((e = LaunchQkv<false, T128x128>::init()) != hipSuccess) return e;
   if ((e = LaunchQkv<false, T128x64>::init()) != hipSuccess) return e;
+  if ((e = LaunchQkv<false, T128x128W4>::init()) != hipSuccess) return e;
+  if ((e = LaunchQkv<true, T128x128W4>::init()) != hipSuccess) return e;
   if ((e = LaunchQkv<true, T256x128>::init()) != hipSuccess) return e;
   if ((e = LaunchQkv<true, T128x128>::init()) != hipSuccess) return e;
   return LaunchQkv<true, T128x64>::init();
@@ -1342,6 +1362,7 @@ hipError_t launch_gemm_qkv_fused(const GemmParams& pq_in, const GemmParams& pv_i
   switch (pick_qkv_tile(pq)) {
     case T256x128: return pq.f8 ? LaunchQkv<true, T256x128>::run(pq, pv, s) : LaunchQkv<false, T256x128>::run(pq, pv, s);
     case T128x128: return pq.f8 ? LaunchQkv<true, T128x128>::run(pq, pv, s) : LaunchQkv<false, T128x128>::run(pq, pv, s);
+    case T128x128W4: return pq.f8 ? LaunchQkv<true, T128x128W4>::run(pq, pv, s) : LaunchQkv<false, T128x128W4>::run(pq, pv, s);
     default: return pq.f8 ? LaunchQkv<true, T128x64>::run(pq, pv, s) : LaunchQkv<false, T128x64>::run(pq, pv, s);
   }
 }

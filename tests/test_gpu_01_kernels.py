@@ -241,7 +241,7 @@ def _gemm_epi_case(tile, epi, batch, frames, N, K, seed, ragged=False):
     assert err < tol, (tile, epi, batch, frames, N, K, err)
 
 
-@pytest.mark.parametrize("tile", [16, 17, 18, 19, 22])
+@pytest.mark.parametrize("tile", [16, 17, 18, 19, 22, 26])
 @pytest.mark.parametrize("epi,N,K", [(EPI_F32, 1024, 1024), (EPI_GELU, 2048, 1024), (EPI_GATE, 1024, 2048), (EPI_QK, 2048, 1024),
                                      (EPI_VT, 1024, 1024), (EPI_BF16, 1024, 1024)])
 def test_gemm_every_tile_and_epilogue_batch1(tile, epi, N, K):
