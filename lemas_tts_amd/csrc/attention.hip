@@ -34,6 +34,11 @@ namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+#ifdef LEMAS_PHASE_TIMESTAMPS      // measurement builds only (tools/kbench_phases.sh); compiled out of the product
+#define ATTN_STAMP(k) do { if (p.dbg && threadIdx.x == 0) p.dbg[blockIdx.x * 4 + (k)] = wall_clock64(); } while (0)
+#else
+#define ATTN_STAMP(k) do { } while (0)
+#endif
 constexpr int QB = 128;            // queries per workgroup
 constexpr int KB = 64;             // keys per tile
 constexpr int TILE = KB * 64 * 2;  // 8 KiB per operand tile
@@ -78,6 +83,7 @@ constexpr int STAGE2 = 4 * TILE;
 
 __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_fwd_splitkv_kernel(const AttnParams p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE2];
+  ATTN_STAMP(0);
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -227,6 +233,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(4, 4))) 
       }
     }
   };
+  ATTN_STAMP(1);
   issue(0, 0);
   for (int i = 0; i < nsup; i += 2) {
     pair(i, std::integral_constant<int, 0>{});
@@ -235,6 +242,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(4, 4))) 
 
   // ---- merge the two key-parity partials: group 1 parks (m, l, O^T) in LDS, group 0 folds it in
   __syncthreads();
+  ATTN_STAMP(2);
   float* xch = reinterpret_cast<float*>(smem) + (size_t)wq * 64 * 36 + lane * 36;   // 34 floats used per lane, 36 pitch
   if (grp == 1) {
     xch[0] = m_run;
@@ -303,6 +311,9 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(4, 4))) 
       if (q < N) store_wt_b128(p.out + ((size_t)b2 * p.pitch + q) * (p.heads * 64) + h * 64 + ch * 8, d);
     }
   }
+#ifdef LEMAS_PHASE_TIMESTAMPS
+  if (p.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); ATTN_STAMP(3); }
+#endif
 }
 
 }  // namespace

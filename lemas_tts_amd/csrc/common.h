@@ -153,6 +153,9 @@ struct AttnParams {
   uint8_t* out8;     // fp8 path: when set, the output is written as MXFP8 here ([B2*pitch, H*64] e4m3) instead of `out`
   uint8_t* out_mx;   //           [B2*pitch, H*2] E8M0
   hipEvent_t ev_start, ev_stop;   // profiling: kernel begin / end stamps (see GemmParams)
+#ifdef LEMAS_PHASE_TIMESTAMPS
+  unsigned long long* dbg;   // measurement builds: per-workgroup phase timestamps [grid][4]
+#endif
 };
 hipError_t launch_attention(const AttnParams& p, hipStream_t s);
 

@@ -396,6 +396,25 @@ extern "C" int lemas_k_bench(const char* what, int32_t M, int32_t N, int32_t K, 
     p.q = q; p.k = k; p.vt = vt; p.out = o; p.kv_len = nullptr; p.b2 = bh / 16; p.batch = bh / 16; p.heads = 16; p.n = n; p.npad = npad; p.pitch = pitch;
     p.scale = 0.125f;
     rc = time_it([&]() { return launch_attention(p, s); });
+#ifdef LEMAS_PHASE_TIMESTAMPS
+    if (rc == 0) {   // phase timestamps of one more launch
+      const int grid = ((n + 127) / 128) * bh;
+      unsigned long long* d = sc.get<unsigned long long>((size_t)grid * 4);
+      p.dbg = d;
+      (void)launch_attention(p, s);
+      HIP_TRY(hipStreamSynchronize(s));
+      std::vector<unsigned long long> h((size_t)grid * 4);
+      HIP_TRY(hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost));
+      unsigned long long t0 = ~0ull, t3 = 0;
+      for (int i = 0; i < grid; ++i) { t0 = std::min(t0, h[i * 4]); t3 = std::max(t3, h[i * 4 + 3]); }
+      double sp = 0, sl = 0, se = 0, st = 0;
+      for (int i = 0; i < grid; ++i) {
+        sp += (h[i * 4 + 1] - h[i * 4]) * 0.01; sl += (h[i * 4 + 2] - h[i * 4 + 1]) * 0.01; se += (h[i * 4 + 3] - h[i * 4 + 2]) * 0.01; st += (h[i * 4] - t0) * 0.01;
+      }
+      fprintf(stderr, "  phases attention N=%d BH=%d grid=%d span %.1f us | start +%.1f prologue (Q fragments) %.1f loop %.1f merge + epilogue %.1f\n",
+              n, bh, grid, (t3 - t0) * 0.01, st / grid, sp / grid, sl / grid, se / grid);
+    }
+#endif
   } else {
     set_error("bench: unknown kernel '%s'", what);
     rc = LEMAS_E_ARG;

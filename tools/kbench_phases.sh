@@ -14,5 +14,9 @@ for M, tiles in ((750, (18, 19)), (1875, (16, 17, 18)), (9216, (22,)), (30720, (
             us = C.c_double()
             L.lemas_k_bench(what.encode(), M, N, K, 20, t, C.byref(us))
             print(f"M={M} {what} N={N} K={K} tile {t}: {us.value:.1f} us", flush=True)
+for n, bh in ((750, 16), (1875, 16), (1875, 32), (1125, 128), (1875, 256)):
+    us = C.c_double()
+    L.lemas_k_bench(b"attention", n, bh, 0, 20, 0, C.byref(us))
+    print(f"attention N={n} BH={bh}: {us.value:.1f} us", flush=True)
 PY
 python -c "from lemas_tts_amd import build; build.build_library(force=True)"      # back to the product build
