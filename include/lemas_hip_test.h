@@ -57,6 +57,11 @@ int lemas_k_gemm_epi(int32_t epi, int32_t tile, const float* A, const float* W, 
  * cached hipGraphs are NOT invalidated -- set it before sampling. */
 int lemas_k_tile_override(int32_t n1024, int32_t n2048, int32_t xcd_gx);
 
+/* Measurement builds only (-DLEMAS_PHASE_TIMESTAMPS, tools/timeline_step.py): every block GEMM and attention launch the engines enqueue from now
+ * on stamps its workgroups' start / end (100 MHz wall clock) into slot k of `buf` (u64 [slots][4096]: [workgroup][4]), k counting the
+ * launches of one forward pass in enqueue order; buf = NULL switches it off.  In a product build this returns LEMAS_E_STATE. */
+int lemas_k_timeline(void* buf, int32_t slots);
+
 /* micro-benchmark of one step-loop kernel on synthetic operands: what = "gemm_gelu" | "gemm_gate" | "gemm_qk" | "gemm_v" |
  * "gemm_f32out" (M,N,K = GEMM shape; prefix "f8_" for the MXFP8 path) or "attention" (M = frames, N = batch*heads); returns
  * the average launch duration in microseconds over `iters` back-to-back launches (HIP events).  `variant` = GEMM tile as

@@ -95,6 +95,7 @@ def lib():
         "lemas_k_ln_mod": (C.c_int, [vp, vp, vp, vp, i32, i32, vp]),
         "lemas_k_convpos": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
         "lemas_k_tile_override": (C.c_int, [i32, i32, i32]),
+        "lemas_k_timeline": (C.c_int, [C.c_void_p, i32]),
         "lemas_k_gemm_epi": (C.c_int, [i32, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
         "lemas_k_bench": (C.c_int, [C.c_char_p, i32, i32, i32, i32, i32, C.POINTER(C.c_double)]),
     }
@@ -115,7 +116,7 @@ EXPORTED = [
     "lemas_prosody_create", "lemas_prosody_destroy", "lemas_prosody_load_weight", "lemas_prosody_finalize", "lemas_prosody_fbank_frames",
     "lemas_prosody_fbank", "lemas_prosody_encode",
     "lemas_k_linear_bf16",
-    "lemas_k_linear_f32", "lemas_k_attention", "lemas_k_ln_mod", "lemas_k_convpos", "lemas_k_bench", "lemas_k_gemm_epi", "lemas_k_tile_override",
+    "lemas_k_linear_f32", "lemas_k_attention", "lemas_k_ln_mod", "lemas_k_convpos", "lemas_k_bench", "lemas_k_gemm_epi", "lemas_k_tile_override", "lemas_k_timeline",
     "lemas_k_mx_quant", "lemas_k_w_quant_f8", "lemas_k_ln_mod_f8", "lemas_k_linear_f8",
 ]
 

@@ -492,7 +492,20 @@ int lemas_dit::prepare(const lemas_sample_args* a, hipStream_t s) {
   return 0;
 }
 
+#ifdef LEMAS_PHASE_TIMESTAMPS   // measurement builds: in-situ timeline of one forward pass (include/lemas_hip_test.h: lemas_k_timeline)
+static unsigned long long* g_tl = nullptr;
+static int g_tl_slots = 0, g_tl_next = 0;
+extern "C" int lemas_k_timeline(void* buf, int32_t slots) { g_tl = static_cast<unsigned long long*>(buf); g_tl_slots = slots; return 0; }
+#define TL_SLOT(P) do { (P).dbg = (g_tl && g_tl_next < g_tl_slots) ? g_tl + (size_t)(g_tl_next++) * 4096 : nullptr; } while (0)
+#define TL_RESET() do { g_tl_next = 0; } while (0)
+#else
+extern "C" int lemas_k_timeline(void*, int32_t) { set_error("lemas_k_timeline: not a measurement build"); return LEMAS_E_STATE; }
+#define TL_SLOT(P) do { } while (0)
+#define TL_RESET() do { } while (0)
+#endif
+
 int lemas_dit::enqueue_forward(hipStream_t s) {
+  TL_RESET();
   const int d = cfg.dim, md = cfg.mel_dim, in = inner(), ffd = cfg.ff_mult * d;
   const int* step = d_step.as<int>();
   const float* tab = d_tab.as<float>();
@@ -595,6 +608,10 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
       operands(hbf, h8, hmx, w.wqkv, w.wqkv8, w.sqkv, (size_t)2 * in, d);
       gv.A = g.A; gv.a_mx = g.a_mx; gv.W = g.W; gv.w_scale = g.w_scale;
       gv.bias = w.bqkv.as<float>() + 2 * in; gv.N = in; gv.K = d; gv.n_valid = in; gv.kv_len = nullptr;
+      TL_SLOT(gq);
+#ifdef LEMAS_PHASE_TIMESTAMPS
+      gv.dbg = gq.dbg;
+#endif
       HIP_TRY(launch_gemm_qkv_fused(gq, gv, q));
       g.K = d;
     } else {
@@ -602,19 +619,23 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
       operands(hbf, h8, hmx, w.wqkv, w.wqkv8, w.sqkv, 0, d);
       g.bias = w.bqkv.as<float>(); g.N = 2 * in; g.K = d; g.n_valid = 2 * in;
       g.kv_len = nullptr;
+      TL_SLOT(g);
       HIP_TRY(launch_gemm_bf16(EPI_QK_ROPE, g, q));
       RC_TRY(pkernel(PC_GEMM_V, &g.ev_start, &g.ev_stop));
       operands(hbf, h8, hmx, w.wqkv, w.wqkv8, w.sqkv, (size_t)2 * in, d);
       g.bias = w.bqkv.as<float>() + 2 * in; g.N = in; g.n_valid = in;
+      TL_SLOT(g);
       HIP_TRY(launch_gemm_bf16(EPI_V_T, g, q));
     }
     RC_TRY(pkernel(PC_ATTN, &at.ev_start, &at.ev_stop));
     at.out8 = a8; at.out_mx = amx;
+    TL_SLOT(at);
     HIP_TRY(launch_attention(at, q));
     RC_TRY(pkernel(PC_GEMM_OUT, &g.ev_start, &g.ev_stop));
     operands(abf, a8, amx, w.wo, w.wo8, w.so, 0, in);
     g.bias = w.bo; g.N = d; g.K = in; g.n_valid = d;
     g.out_f32 = xres; g.ldc = d; g.gate_off = base + 2 * d; g.kv_len = has_len ? d_len.as<int>() : nullptr;
+    TL_SLOT(g);
     HIP_TRY(launch_gemm_bf16(EPI_GATE_RES, g, q));
     RC_TRY(pbegin(PC_LN, q));
     if (fp8) HIP_TRY(launch_ln_mod_f8(xres, h8, hmx, rows, d, tab, tab_stride, base + 4 * d, base + 3 * d, step, q));
@@ -624,11 +645,13 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     operands(hbf, h8, hmx, w.w1, w.w18, w.s1, 0, d);
     g.bias = w.b1; g.N = ffd; g.K = d; g.n_valid = ffd;
     g.out_bf16 = ffb; g.out_f8 = ff8; g.out_mx = ffmx; g.ldc = ffd; g.kv_len = nullptr;
+    TL_SLOT(g);
     HIP_TRY(launch_gemm_bf16(fp8 ? EPI_BIAS_GELU_F8 : EPI_BIAS_GELU_BF16, g, q));
     RC_TRY(pkernel(PC_GEMM_FF2, &g.ev_start, &g.ev_stop));
     operands(ffb, ff8, ffmx, w.w2, w.w28, w.s2, 0, ffd);
     g.bias = w.b2; g.N = d; g.K = ffd; g.n_valid = d;
     g.out_f32 = xres; g.ldc = d; g.gate_off = base + 5 * d;
+    TL_SLOT(g);
     HIP_TRY(launch_gemm_bf16(EPI_GATE_RES, g, q));
     return 0;
   };
