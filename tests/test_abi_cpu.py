@@ -47,3 +47,10 @@ def test_product_does_not_import_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f"{f} imports the oracle"
+
+
+def test_measurement_hooks_are_compiled_out_of_the_product_build():
+    """the in-situ timeline (tools/timeline_step.sh) exists only in a -DLEMAS_PHASE_TIMESTAMPS build: the in-tree library refuses it"""
+    L = _lib.lib()
+    assert L.lemas_k_timeline(None, 0) != 0
+    assert b"not a measurement build" in L.lemas_last_error()
