@@ -21,11 +21,19 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line) {
   return -(int)e;
 }
 
+// The > 64 KB dynamic-LDS opt-in of the GEMM kernels is a per-DEVICE function attribute: once per device a process touches (one
+// process per GPU is the deployment model, but nothing stops a caller from building engines on two devices).
 int kernels_init() {
-  static std::once_flag once;
-  static hipError_t err = hipSuccess;
-  std::call_once(once, [] { err = gemm_bf16_init(); });
+  static std::mutex mu;
+  static bool done[64] = {};
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  if (dev < 0 || dev >= 64) { set_error("kernels_init: device index %d out of range", dev); return LEMAS_E_STATE; }
+  if (done[dev]) return 0;
+  const hipError_t err = gemm_bf16_init();
   if (err != hipSuccess) return hip_fail(err, "gemm_bf16_init()", __FILE__, __LINE__);
+  done[dev] = true;
   return 0;
 }
 
