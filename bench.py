@@ -28,11 +28,18 @@ itself on the same inputs (tests/golden/configs1_nfe32.npz, configs3_share_nfe32
 workload against configs0_nfe16.npz, the same utterance over 16 steps, in one extra untimed solve; made by oracle/gen_golden.py
 --full-size); the run FAILS above mel-MSE 1e-4 and the value is reported as ``mel_mse_vs_reference``.
 
+Pipelining (``--overlap 1``, the default): the Vocos decode + D2H of utterance i run on a side stream under the step loop of
+utterance i+1 (the step loop itself still holds ONE utterance batch at a time: the B = 1 definition of configs[1] is unchanged;
+every waveform is on the host when the timed region ends).  ``--overlap 0`` serialises them as the reference's loop does.
+
 The JSON line also carries
   roofline     -- the dominant kernel BY SYMBOL (what rocprofv3 --stats lists; out-proj and FF2 share one instantiation):
                   algorithmic FLOPs per launch / average launch duration, measured live with HIP event pairs stamped by the
                   dispatch itself (hipExtLaunchKernelGGL) in a short eager pass with the timed region's launch shapes, vs
                   2.5 PFLOP/s dense bf16; ``roofline_gemm_family`` = all block GEMMs together, ``path_frac`` = whole path;
+  roofline_vocoder -- the HBM-bound phase: algorithmic bytes of one decode (fp32 weights + 400 L + 1024 (L-1)) over
+                  its measured duration, vs 8 TB/s; ``phase_ms`` = hoists / step loop / vocoder / D2H of one utterance, measured
+                  serially with stream events after the timed region;
   cpu_baseline -- the fp32 oracle (oracle/lemas_oracle.py, a port of the reference's path) timed on this box's host
                   cores on a bounded sample (1 of the 32 Euler steps at full N, scaled x32, + the full vocoder).
 """
@@ -178,6 +185,9 @@ def main():
     ap.add_argument("--fp8", type=int, default=0, help="1 = block GEMMs on the fp8-e4m3 (MXFP8) path of BASELINE config 5; "
                     "NOT the headline configuration (configs[1] is bf16): the line is then labelled dtype fp8")
     ap.add_argument("--dual", type=int, default=1, help="1 = CFG branches as two concurrent lanes (default), 0 = one stream")
+    ap.add_argument("--overlap", type=int, default=1, help="1 = Vocos decode + D2H of utterance i on a side stream under the step loop of "
+                    "utterance i+1 (default), 0 = strictly serial")
+    ap.add_argument("--ln-fused", type=int, default=-1, help="engine option ln_fused (-1 = engine default)")
     a = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -188,6 +198,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    # LEMAS_FORCE_DIST=1: run the N > 1 code path (process group, weight broadcast into device memory, device-to-device engine
+    # load, collectives around the timed region) with a world of ONE -- every RCCL call of the 8-GPU run, executable on a 1-GPU box
+    force_dist = os.environ.get("LEMAS_FORCE_DIST") == "1"
+    use_dist = world > 1 or force_dist
     assert torch.cuda.is_available(), "bench.py needs the MI355X (there is no CPU path)"
     # LEMAS_DIST_BACKEND=gloo + LEMAS_SHARE_GPU=1 exist only to rehearse the N>1 code path on a 1-GPU box
     backend = os.environ.get("LEMAS_DIST_BACKEND", "nccl")
@@ -198,16 +212,22 @@ def main():
     dist = None
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
-    if world > 1:
+    from lemas_tts_amd.parallel import pin_to_gpu_numa_node  # noqa: E402
+    affinity = pin_to_gpu_numa_node(local_rank) if use_dist else None     # one rank per GPU: host threads next to that GPU's NUMA node
+    if use_dist:
         import torch.distributed as dist  # noqa: F811
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if "MASTER_PORT" not in os.environ:       # world of one without a launcher
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
         assert dist.get_world_size() == a.gpus
-    comm_device = device if (world == 1 or backend == "nccl") else torch.device("cpu")
+    comm_device = device if (not use_dist or backend == "nccl") else torch.device("cpu")
 
     from lemas_tts_amd.engine import VocosEngine  # noqa: E402
     from lemas_tts_amd.model.cfm import CFM, time_grid  # noqa: E402
@@ -220,27 +240,47 @@ def main():
     sd = synth.synth_cfm_state_dict(arch, VOCAB, 1234) if rank == 0 else None
     vsd = synth.synth_vocos_state_dict(1234) if rank == 0 else None
     sd_host, vsd_host = sd, vsd
-    if world > 1:
+    bcast = None
+    if use_dist:
+        t_b = time.perf_counter()
         sd = broadcast_state_dict(sd, arch, VOCAB, comm_device, dist)
         vsd = broadcast_state_dict(vsd, None, None, comm_device, dist, vocos=True)
+        nbytes = 4 * (sum(int(np.prod(v.shape)) for v in sd.values()) + sum(int(np.prod(v.shape)) for v in vsd.values()))
+        bcast = {"backend": backend, "bytes": nbytes, "seconds": time.perf_counter() - t_b,
+                 "on_device": bool(comm_device.type == "cuda"), "world": world}
     model = CFM(arch, VOCAB, sd, device=device)
     model.engine.set_option("dual", a.dual)
     model.engine.set_option("fp8", a.fp8)
+    if a.ln_fused >= 0:
+        model.engine.set_option("ln_fused", a.ln_fused)
     model.engine.set_option("table_cache", 0)      # hoists are redone for every utterance: nothing cached across steps
     vocoder = VocosEngine(vsd, device=device)
     del sd, vsd                                     # the engines own their copies; the broadcast buffer can go
     cond, text, y0, fx = build_inputs(w, rank, device)
+    text = text.cpu().pin_memory()                 # token ids arrive from the host frontend (api.py:201-204): no D2H sync per utterance
     L_GEN = N_TOT - F_REF + 1
     host_wav = torch.empty((B, HOP * (L_GEN - 1)), dtype=torch.float32).pin_memory()
     last = {}
+    side = torch.cuda.Stream(device) if a.overlap else None
 
-    def step(steps=NFE):
-        out, _ = model.sample(cond, text, N_TOT, steps=steps, cfg_strength=CFG, sway_sampling_coef=SWAY, y0=y0, use_acc_grl=False)
+    def vocode(out):
         # the driver vocodes generated[:, nw // 256:] = frames F-1.. (utils_infer.py:520,546): L_gen = N - F + 1
         wav = vocoder.decode(out[:, F_REF - 1:, :].permute(0, 2, 1))
         host_wav.copy_(wav, non_blocking=True)
-        last["out"] = out
         return wav
+
+    def step(steps=NFE):
+        out, _ = model.sample(cond, text, N_TOT, steps=steps, cfg_strength=CFG, sway_sampling_coef=SWAY, y0=y0, use_acc_grl=False)
+        last["out"] = out
+        if side is None:
+            return vocode(out)
+        # decode + D2H of THIS utterance on the side stream; the next utterance's hoists and step loop follow on the main one
+        done = torch.cuda.Event()
+        done.record()
+        with torch.cuda.stream(side):
+            side.wait_event(done)
+            out.record_stream(side)
+            return vocode(out)
 
     for _ in range(a.warmup):
         step()
@@ -256,8 +296,13 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    per_rank_ms = [1e3 * elapsed / max(a.steps, 1)]
     if dist:
-        tmax = torch.tensor([elapsed], device=comm_device, dtype=torch.float64)
+        mine = torch.tensor([elapsed], device=comm_device, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)                       # load imbalance stays visible: per-rank step times, not only the max
+        per_rank_ms = [1e3 * float(t.item()) / max(a.steps, 1) for t in every]
+        tmax = mine.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     assert np.isfinite(host_wav.numpy()).all()
@@ -290,13 +335,22 @@ def main():
                                    + " / fp32 state, Vocos decode + D2H included",
                        "workload_key": a.workload,
                        "utterances_per_gpu_per_step": B, "audio_seconds_per_step": audio_per_step,
+                       "utterances_total": world * B * a.steps, "utterances_per_step_all_gpus": world * B,
+                       "audio_seconds_per_rank": a.steps * audio_per_step,
+                       "pipelining": ("vocoder + D2H of utterance i on a side stream under the step loop of utterance i+1"
+                                      if a.overlap else "none (strictly serial)"),
                        "parallelism": f"dp{world} ({world} process(es), one per GPU; utterance sharding, RCCL weight broadcast into "
                                       "device memory, no step-loop collectives)",
                        "depth": a.depth, "weights": "synthetic N(0,0.02^2), seed 1234",
                        "parity_fixture": w["golden"] if mse is not None else None},
             "path_tflops": path_tflops,
             "path_frac": path_tflops / (MFMA_BF16_PEAK_TFLOPS if not a.fp8 else MFMA_FP8_PEAK_TFLOPS),
+            "per_rank_ms": {"min": min(per_rank_ms), "max": max(per_rank_ms), "all": [round(x, 3) for x in per_rank_ms]},
         }
+        if bcast is not None:
+            result["weight_broadcast"] = bcast
+        if affinity is not None:
+            result["config"]["cpu_affinity"] = affinity
 
     # ---- roofline of the dominant kernel: short eager pass with per-launch HIP events (rank 0, N == 1 only)
     if rank == 0 and world == 1:
@@ -323,17 +377,29 @@ def main():
         fl = d["flops"] / d["launches"]
         ach = fl / (avg_us * 1e-6) / 1e12
         total_ms = sum(v[0] for v in prof.values())
-        traffic = None   # HBM-side bytes per launch from the committed PMC passes (rocprofv3 cannot run inside bench.py)
+        # HBM-side bytes per launch and the rocprofv3 average of the same symbol come from COMMITTED profiler passes over this very
+        # command (rocprofv3 cannot run inside bench.py); both are labelled with the file they were read from
+        traffic, traffic_src, rocprof_us, rocprof_src = None, None, None, None
+        for name in ("r03_traffic.json", "r02_traffic.json"):
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", name)))
+                traffic, traffic_src = tj[a.workload][dom]["hbm_bytes_per_launch"], f"profiles/{name} <- {tj.get('_source', '?')}"
+                break
+            except (OSError, KeyError, ValueError, TypeError):
+                continue
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
-            traffic = tj[a.workload][dom]["hbm_bytes_per_launch"]
+            kj = json.load(open(os.path.join(ROOT, "profiles", "r03_kernel_avgs.json")))
+            rocprof_us, rocprof_src = kj[a.workload][dom]["avg_us"], f"profiles/r03_kernel_avgs.json <- {kj.get('_source', '?')}"
         except (OSError, KeyError, ValueError, TypeError):
             pass
         is_gemm = dom != "attn_fwd_splitkv_kernel"
         peak = MFMA_FP8_PEAK_TFLOPS if (a.fp8 and is_gemm) else MFMA_BF16_PEAK_TFLOPS   # attention stays bf16
         result["roofline"] = {"bound": "mfma", "kernel": dom, "classes": d["classes"], "achieved": ach, "peak": peak,
-                              "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
-                              "avg_launch_us": avg_us, "launches": d["launches"], "flops_per_launch": fl,
+                              "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src,
+                              "avg_launch_us": avg_us, "avg_launch_us_source": "this run: eager pass, per-launch HIP event pairs, lanes serialised",
+                              "avg_launch_us_rocprof": rocprof_us, "avg_launch_us_rocprof_source": rocprof_src,
+                              "frac_rocprof": (fl / (rocprof_us * 1e-6) / 1e12 / peak) if rocprof_us else None,
+                              "launches": d["launches"], "flops_per_launch": fl,
                               "time_share": d["ms"] / total_ms,
                               "launch_shape": f"{bb} x {N_TOT} frames per launch ({lanes} concurrent lane(s) in the timed region)"}
         g_ms = sum(v["ms"] for s, v in by_sym.items() if s != "attn_fwd_splitkv_kernel")
@@ -344,6 +410,43 @@ def main():
         result["kernel_tflops"] = {k: round(class_flops(k, rows, N_TOT, bb) / (1e3 * v[0] / v[1] * 1e-6) / 1e12, 1) for k, v in mm.items()}
         result["kernel_time_share"] = {k: round(v[0] / total_ms, 4) for k, v in prof.items() if v[1] > 0}
         result["kernel_avg_us"] = {k: round(1e3 * v[0] / v[1], 2) for k, v in prof.items() if v[1] > 0}
+
+        # ---- the other phases of one utterance, serially, with stream events: hoists / step loop / vocoder / D2H
+        def timed_ms(fn, reps=3):
+            best = None
+            for _ in range(reps):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record()
+                r = fn()
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1)
+                best = ms if best is None else min(best, ms)
+            return best, r
+
+        tgf = time_grid(NFE, SWAY)
+        condp = torch.nn.functional.pad(cond, (0, 0, 0, N_TOT - F_REF))
+        hoist_ms, _ = timed_ms(lambda: eng.prepare(condp, cm, text, tgf.numpy(), cond_frames=F_REF, cfg_strength=CFG))
+        loop_ms, (o_, _y) = timed_ms(lambda: eng.solve(y0), reps=2)
+        mel_in = o_[:, F_REF - 1:, :].permute(0, 2, 1).contiguous()
+        voc_ms, wav_ = timed_ms(lambda: vocoder.decode(mel_in))
+        d2h_ms, _ = timed_ms(lambda: host_wav.copy_(wav_, non_blocking=True))
+        tot = hoist_ms + loop_ms + voc_ms + d2h_ms
+        result["hoist_ms"] = hoist_ms
+        result["phase_ms"] = {"hoists": hoist_ms, "step_loop": loop_ms, "vocoder": voc_ms, "d2h": d2h_ms, "sum_serial": tot,
+                              "note": "one utterance batch, phases serialised and timed with stream events after the timed region; "
+                                      "with --overlap 1 vocoder + d2h run under the next utterance's step loop"}
+        result["phase_share"] = {"hoists": hoist_ms / tot, "step_loop": loop_ms / tot, "vocoder": voc_ms / tot, "d2h": d2h_ms / tot}
+        # kernel_time_share covers the step loop; rescaled to the utterance and joined by the hoist / vocoder phases
+        result["kernel_time_share_utterance"] = dict({k: round(v * loop_ms / tot, 4) for k, v in result["kernel_time_share"].items()},
+                                                     hoists=round(hoist_ms / tot, 4), vocoder=round(voc_ms / tot, 4), d2h=round(d2h_ms / tot, 4))
+        wbytes = 4 * sum(int(np.prod(np.shape(v))) for v in vsd_host.values())
+        voc_bytes = B * (400.0 * L_GEN + 1024.0 * (L_GEN - 1)) + wbytes      # weights + mel in + wav out
+        result["roofline_vocoder"] = {"bound": "hbm", "achieved": voc_bytes / (voc_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                      "frac": voc_bytes / (voc_ms * 1e-3) / 8e12, "algorithmic_bytes": voc_bytes, "decode_ms": voc_ms,
+                                      "frames": L_GEN, "traffic": None,
+                                      "note": "launch-/latency-bound at batch 1: ~60 small fp32 launches for 25 GFLOP"}
         if not a.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(sd_host, vsd_host, arch, w)
     if rank == 0:

@@ -18,7 +18,7 @@
  *   lemas_prosody_*                         <- lemas_tts/model/backbones/prosody_encoder.py ProsodyEncoder / extract_fbank_16k,
  *                                              called per sample at lemas_tts/model/cfm.py:248-262
  * Single-kernel entry points for the parity tests and micro-benchmarks (lemas_k_*) are declared in lemas_hip_test.h; they
- * are exported by the same library but are not part of the drop-in surface.
+ * live in a separate library, liblemas_hip_test.so, and are not part of the drop-in surface.
  *
  * Conventions: plain pointers and sizes only.  "device" pointers are HIP device addresses on the current device
  * (e.g. torch.Tensor.data_ptr()); "host" pointers are ordinary memory.  `stream` is a hipStream_t passed as void*
@@ -100,8 +100,17 @@ int lemas_dit_finalize(lemas_dit* m);
  * "dual" (1 = run the two CFG branches as concurrent lanes on two streams / graph branches, default 1),
  * "fp8" (1 = the DiT block GEMMs run on fp8-e4m3 MFMA: e4m3 weights with one fp32 scale per output channel, MXFP8
  *        activations (one E8M0 scale per 32 K); attention, norms, residual stream and ODE state unchanged; default 0;
- *        takes effect at the next prepare()/sample()) */
+ *        takes effect at the next prepare()/sample()),
+ * "ln_fused" (1 = the AdaLN LayerNorms that follow the gated residual updates (modules.py:637, the next block's :314, the final
+ *        :335) run as the tail of the out-projection / FF2 launches whenever all workgroups of those launches fit the chip at
+ *        once, default 1; 0 = always separate launches),
+ * measurement options (0 = the production choice; each drops the cached graphs): "tile_n1024", "tile_n2048", "tile_qkv" = explicit
+ *        GEMM tile ids (include/lemas_hip_test.h) for the block GEMMs of that width / the fused QK+V launch, "xcd_gx" = XCD block
+ *        grid of the tile order (8, 4, 2, 1).  Per engine: there is no process-global dispatch switch. */
 int lemas_dit_set_option(lemas_dit* m, const char* key, int64_t value);
+/* synchronises the device and returns 0, or LEMAS_E_STATE when a device-side wait of this engine gave up (fused LayerNorm tail):
+ * every result since then is invalid and prepare() / solve() refuse to run */
+int lemas_dit_health(lemas_dit* m);
 /* full sampler: hoists + NFE Euler steps (+ final where) */
 int lemas_dit_sample(lemas_dit* m, const lemas_sample_args* a, void* stream);
 /* split form: prepare() runs the per-utterance hoists, solve() the step loop on the prepared state */

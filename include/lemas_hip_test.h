@@ -1,6 +1,7 @@
-/* liblemas_hip.so -- test and measurement entry points (lemas_k_*).
+/* liblemas_hip_test.so -- test and measurement entry points (lemas_k_*).
  *
- * NOT part of the drop-in surface (include/lemas_hip.h): thin drivers that feed fp32 device arrays through ONE production
+ * NOT part of the drop-in surface (include/lemas_hip.h) and NOT in the product library: liblemas_hip_test.so is engine_ktests.hip
+ * linked against liblemas_hip.so (one copy of every kernel and of the error state in the process).  Thin drivers that feed fp32 device arrays through ONE production
  * kernel so that the parity tests can localise a failure, plus a micro-benchmark.  They allocate scratch with hipMalloc
  * and synchronise the stream before returning.  Conventions as in lemas_hip.h: all pointers are device fp32 unless noted,
  * `stream` is a hipStream_t, return 0 or a negative code.
@@ -43,7 +44,7 @@ int lemas_k_convpos(const float* x, const float* w1, const float* b1, const floa
 
 /* one production bf16 GEMM launch with an explicit tile and epilogue in the engine's row space: rows = batch x pitch
  * (pitch % 128 == 0), `frames` valid rows per sample.  A [batch*pitch, K], W [N, K], bias [N] fp32 (rounded to bf16 inside).
- *   tile: 0 production choice | 16 = 256x128 | 17 = 128x128 | 18 = 128x64 | 19 = 64x64 | 22 = 256x256
+ *   tile: 0 production choice | 16 = 256x128 | 17 = 128x128 | 18 = 128x64 | 19 = 64x64 | 22 = 256x256 | 26 = 128x128 (4 waves)
  *   epi 0: out[M,N] = bf16(acc + bias)        1: out = bf16(gelu_tanh(acc + bias))       2: out = acc + bias (fp32)
  *   epi 3: out[M,N] += aux[n] * (acc + bias) for rows with pos < frames (and pos < seq_len[b] when given); aux = gate [N]
  *   epi 4: N = 2*H*64: +bias, RoPE with aux = [cos | sin] ([frames][32] each) -> out = q then k, each [batch][H][pitch][64]
@@ -52,10 +53,14 @@ int lemas_k_convpos(const float* x, const float* w1, const float* b1, const floa
 int lemas_k_gemm_epi(int32_t epi, int32_t tile, const float* A, const float* W, const float* bias, const float* aux,
                      const int32_t* seq_len, float* out, int32_t batch, int32_t pitch, int32_t frames, int32_t N, int32_t K, void* stream);
 
-/* measurement hook for A/B runs: force the tile shape the dispatch picks for bf16 GEMMs with N == 1024 / N == 2048 (ids as in
- * lemas_k_gemm_epi) and the XCD block grid of the tile order (8 = row-major, 4, 2, 1); 0 = production choice.  Process-global;
- * cached hipGraphs are NOT invalidated -- set it before sampling. */
-int lemas_k_tile_override(int32_t n1024, int32_t n2048, int32_t xcd_gx);
+/* the gate + residual GEMM (epi 3 above, N = 1024) WITH its LayerNorm-modulate tail, as the sampler launches it (gemm_bf16.hip ln_tail):
+ * x [batch*pitch, 1024] in/out = residual stream; h [batch*pitch, 1024] out = bf16(LN(x_new; eps 1e-6) * (1 + scale) + shift) widened;
+ * gate / scale / shift [1024].  tile: 17 / 18 / 19 / 26 (the tiles that carry the tail; 0 = production choice).  concurrent (1..4):
+ * that many independent copies of the launch run at once on separate streams (the two CFG lanes' situation); their results must
+ * be bit-identical, copy 0 is returned.  (modules.py:635-637) */
+int lemas_k_gemm_gate_ln(int32_t tile, const float* A, const float* W, const float* bias, const float* gate, const float* scale,
+                         const float* shift, const int32_t* seq_len, float* x, float* h, int32_t batch, int32_t pitch, int32_t frames,
+                         int32_t K, int32_t concurrent, void* stream);
 
 /* Measurement builds only (-DLEMAS_PHASE_TIMESTAMPS, tools/timeline_step.py): every block GEMM and attention launch the engines enqueue from now
  * on stamps its workgroups' start / end (100 MHz wall clock) into slot k of `buf` (u64 [slots][4096]: [workgroup][4]), k counting the
@@ -63,7 +68,7 @@ int lemas_k_tile_override(int32_t n1024, int32_t n2048, int32_t xcd_gx);
 int lemas_k_timeline(void* buf, int32_t slots);
 
 /* micro-benchmark of one step-loop kernel on synthetic operands: what = "gemm_gelu" | "gemm_gate" | "gemm_qk" | "gemm_v" |
- * "gemm_f32out" (M,N,K = GEMM shape; prefix "f8_" for the MXFP8 path) or "attention" (M = frames, N = batch*heads); returns
+ * "gemm_f32out" | "gemm_gate_ln" (gemm_gate with its LayerNorm tail, N = 1024) (M,N,K = GEMM shape; prefix "f8_" for the MXFP8 path) or "attention" (M = frames, N = batch*heads); returns
  * the average launch duration in microseconds over `iters` back-to-back launches (HIP events).  `variant` = GEMM tile as
  * in lemas_k_gemm_epi (0 = production choice). */
 int lemas_k_bench(const char* what, int32_t M, int32_t N, int32_t K, int32_t iters, int32_t variant, double* avg_us);

@@ -1,4 +1,5 @@
-"""ctypes binding of liblemas_hip.so (the C ABI declared in include/lemas_hip.h; test entry points in include/lemas_hip_test.h).
+"""ctypes binding of liblemas_hip.so (the C ABI declared in include/lemas_hip.h) and, for tests and measurement tools only, of
+liblemas_hip_test.so (the lemas_k_* entry points of include/lemas_hip_test.h; it links against the product library).
 
 There is NO CPU fallback: if the shared library is missing or no HIP device is present the
 product path raises.  PyTorch is used for device memory and streams only.
@@ -10,8 +11,10 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "liblemas_hip.so")
+TEST_LIB_PATH = os.path.join(_HERE, "lib", "liblemas_hip_test.so")
 
 _lib = None
+_testlib = None
 
 
 class DitConfig(C.Structure):
@@ -40,8 +43,15 @@ class LemasError(RuntimeError):
     pass
 
 
+def _bind(L, sig):
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+
+
 def lib():
-    """Load the library once.  Import torch first so the process-wide HIP runtime is torch's."""
+    """Load the PRODUCT library once.  Import torch first so the process-wide HIP runtime is torch's."""
     global _lib
     if _lib is not None:
         return _lib
@@ -49,7 +59,7 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise LemasError(f"{LIB_PATH} is missing: build it with `python -m lemas_tts_amd.build` "
                          "(there is no CPU fallback for the acoustic path)")
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)      # the test library resolves its references against this one
     vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
     sig = {
         "lemas_last_error": (C.c_char_p, []),
@@ -60,6 +70,7 @@ def lib():
         "lemas_dit_load_weight_device": (C.c_int, [vp, C.c_char_p, vp, C.POINTER(i64), i32]),
         "lemas_dit_finalize": (C.c_int, [vp]),
         "lemas_dit_set_option": (C.c_int, [vp, C.c_char_p, i64]),
+        "lemas_dit_health": (C.c_int, [vp]),
         "lemas_dit_sample": (C.c_int, [vp, C.POINTER(SampleArgs), vp]),
         "lemas_dit_prepare": (C.c_int, [vp, C.POINTER(SampleArgs), vp]),
         "lemas_dit_solve": (C.c_int, [vp, C.POINTER(SampleArgs), vp]),
@@ -85,6 +96,35 @@ def lib():
         "lemas_resample_destroy": (None, [vp]),
         "lemas_resample_out_len": (C.c_int64, [vp, C.c_int64]),
         "lemas_resample_forward": (C.c_int, [vp, vp, i32, i32, vp, vp]),
+    }
+    _bind(L, sig)
+    _lib = L
+    return L
+
+
+class _WithTests:
+    """The product library plus the lemas_k_* entry points of the TEST library under one handle, for tests and tools: attribute
+    lookups starting with ``lemas_k_`` go to liblemas_hip_test.so, everything else to liblemas_hip.so (whose error buffer the test
+    entry points share: the test library links against it)."""
+
+    def __init__(self, prod, test):
+        self._prod, self._test = prod, test
+
+    def __getattr__(self, name):
+        return getattr(self._test if name.startswith("lemas_k_") else self._prod, name)
+
+
+def testlib():
+    """Product + test entry points.  The product package never calls this; tests and tools/ do."""
+    global _testlib
+    if _testlib is not None:
+        return _testlib
+    prod = lib()
+    if not os.path.exists(TEST_LIB_PATH):
+        raise LemasError(f"{TEST_LIB_PATH} is missing: build it with `python -m lemas_tts_amd.build`")
+    T = C.CDLL(TEST_LIB_PATH)
+    vp, i32 = C.c_void_p, C.c_int32
+    sig = {
         "lemas_k_linear_bf16": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
         "lemas_k_linear_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
         "lemas_k_attention": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
@@ -94,30 +134,28 @@ def lib():
         "lemas_k_linear_f8": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]),
         "lemas_k_ln_mod": (C.c_int, [vp, vp, vp, vp, i32, i32, vp]),
         "lemas_k_convpos": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
-        "lemas_k_tile_override": (C.c_int, [i32, i32, i32]),
         "lemas_k_timeline": (C.c_int, [C.c_void_p, i32]),
         "lemas_k_gemm_epi": (C.c_int, [i32, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+        "lemas_k_gemm_gate_ln": (C.c_int, [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
         "lemas_k_bench": (C.c_int, [C.c_char_p, i32, i32, i32, i32, i32, C.POINTER(C.c_double)]),
     }
-    for name, (res, args) in sig.items():
-        fn = getattr(L, name)
-        fn.restype = res
-        fn.argtypes = args
-    _lib = L
-    return L
+    _bind(T, sig)
+    _testlib = _WithTests(prod, T)
+    return _testlib
 
 
-EXPORTED = [
+EXPORTED = [      # include/lemas_hip.h: the product library
     "lemas_last_error", "lemas_version", "lemas_dit_create", "lemas_dit_destroy", "lemas_dit_load_weight", "lemas_dit_load_weight_device", "lemas_vocos_load_weight_device",
-    "lemas_dit_finalize", "lemas_dit_set_option", "lemas_dit_sample", "lemas_dit_prepare", "lemas_dit_solve",
+    "lemas_dit_finalize", "lemas_dit_set_option", "lemas_dit_health", "lemas_dit_sample", "lemas_dit_prepare", "lemas_dit_solve",
     "lemas_dit_forward", "lemas_dit_profile_read", "lemas_vocos_create", "lemas_vocos_destroy",
     "lemas_vocos_load_weight", "lemas_vocos_finalize", "lemas_vocos_decode", "lemas_mel_create", "lemas_mel_destroy",
     "lemas_mel_forward", "lemas_resample_create", "lemas_resample_destroy", "lemas_resample_out_len", "lemas_resample_forward",
     "lemas_prosody_create", "lemas_prosody_destroy", "lemas_prosody_load_weight", "lemas_prosody_finalize", "lemas_prosody_fbank_frames",
     "lemas_prosody_fbank", "lemas_prosody_encode",
-    "lemas_k_linear_bf16",
-    "lemas_k_linear_f32", "lemas_k_attention", "lemas_k_ln_mod", "lemas_k_convpos", "lemas_k_bench", "lemas_k_gemm_epi", "lemas_k_tile_override", "lemas_k_timeline",
-    "lemas_k_mx_quant", "lemas_k_w_quant_f8", "lemas_k_ln_mod_f8", "lemas_k_linear_f8",
+]
+EXPORTED_TEST = [  # include/lemas_hip_test.h: the test library
+    "lemas_k_linear_bf16", "lemas_k_linear_f32", "lemas_k_attention", "lemas_k_ln_mod", "lemas_k_convpos", "lemas_k_bench", "lemas_k_gemm_epi",
+    "lemas_k_gemm_gate_ln", "lemas_k_timeline", "lemas_k_mx_quant", "lemas_k_w_quant_f8", "lemas_k_ln_mod_f8", "lemas_k_linear_f8",
 ]
 
 

@@ -1,4 +1,6 @@
-"""Build liblemas_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+"""Build liblemas_hip.so (the product: engines + kernels behind include/lemas_hip.h) and liblemas_hip_test.so (the lemas_k_* test and
+measurement entry points of include/lemas_hip_test.h: csrc/engine_ktests.hip linked AGAINST the product library, so the process holds
+one copy of every kernel) in-tree with hipcc for gfx950 (cross-compiles without a GPU).
 
     python -m lemas_tts_amd.build            # incremental
     python -m lemas_tts_amd.build --force
@@ -17,6 +19,8 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_build")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "liblemas_hip.so")
+TEST_LIB = os.path.join(LIBDIR, "liblemas_hip_test.so")
+TEST_ONLY = {"engine_ktests.hip"}          # sources that go into the test library, not the product
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -49,16 +53,26 @@ def _compile(src: str, force: bool) -> str:
     return obj
 
 
+def _link(out: str, objs, extra=()) -> None:
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs, *extra, "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+
+
 def build_library(force: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
+    srcs = _sources()
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
-        objs = list(ex.map(lambda s: _compile(s, force), _sources()))
-    if force or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-Wl,-rpath,/opt/rocm/lib"]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        objs = dict(zip(srcs, ex.map(lambda s: _compile(s, force), srcs)))
+    prod = [o for s, o in objs.items() if s not in TEST_ONLY]
+    test = [o for s, o in objs.items() if s in TEST_ONLY]
+    if force or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in prod):
+        _link(LIB, prod)
+    if force or not os.path.exists(TEST_LIB) or os.path.getmtime(LIB) > os.path.getmtime(TEST_LIB) or \
+            any(os.path.getmtime(o) > os.path.getmtime(TEST_LIB) for o in test):
+        _link(TEST_LIB, test, ["-L", LIBDIR, "-llemas_hip", "-Wl,-rpath,$ORIGIN"])
     return LIB
 
 

@@ -125,6 +125,18 @@ struct GemmParams {
   // XCD block grid of the tile order: the tile grid is cut into xcd_gx x (8 / xcd_gx) blocks, one per XCD (gemm_bf16.hip
   // tile_coords).  0 = let the launcher choose (minimises the fabric-side fetch gy * |A| + gx * |W|); 8 = the row-major order.
   int xcd_gx;
+  // explicit tile shape (ids as for launch_gemm_bf16_tile; 0 = the production choice).  Set per launch by whoever builds the
+  // parameters -- unit tests, kbench, the engine's per-engine measurement options -- never by process-global state.
+  int tile;
+  // LayerNorm-modulate tail of EPI_GATE_RES (ln_out != nullptr; bf16 path, N == ldc == 1024): the AdaLN-modulated LayerNorm that
+  // follows the residual update (modules.py:637 / the next block's :314 / the final :335) is computed by the SAME launch.  Every
+  // workgroup publishes its x_res tile (write-through stores, drained), bumps its row panel's arrival counter, waits until the
+  // panel's N / BN column tiles have arrived and then normalises BM / (N / BN) rows of the panel -> ln_out [M][1024] bf16.
+  // Needs every workgroup of the launch co-resident (gemm_bf16_ln_fusable); ln_cnt must be zero when the launch starts.
+  bf16_t* ln_out;
+  int ln_scale_off, ln_shift_off;   // offsets of the scale / shift vectors inside the AdaLN table row of the current step
+  unsigned int* ln_cnt;             // [ceil(M / BM)] arrival counters
+  unsigned int* ln_err;             // sticky error word (host-visible): set when a wait gives up instead of hanging
 #ifdef LEMAS_PHASE_TIMESTAMPS
   unsigned long long* dbg;   // measurement builds: per-workgroup phase timestamps [grid][4] (gemm_bf16.hip PHASE_STAMP)
 #endif
@@ -132,14 +144,18 @@ struct GemmParams {
 
 // ---- internal launchers (one per .hip translation unit) ----------------------------------------
 hipError_t launch_gemm_bf16(int epi, const GemmParams& p, hipStream_t s);
-// explicit tile shape (16 = 256x128, 17 = 128x128, 18 = 128x64, 19 = 64x64, 22 = 256x256; 0 = the production choice): unit tests and kbench
+// explicit tile shape (16 = 256x128, 17 = 128x128, 18 = 128x64, 19 = 64x64, 22 = 256x256, 26 = 128x128 with 4 waves; 0 = the production
+// choice): unit tests and kbench
 hipError_t launch_gemm_bf16_tile(int epi, const GemmParams& p, int tile, hipStream_t s);
 // one-time > 64 KB dynamic-LDS opt-in of every GEMM instantiation (called from lemas_kernels_init, never on a launch path)
 hipError_t gemm_bf16_init();
-// measurement hook: force the tile of the bf16 GEMMs with N == 1024 / N == 2048 and the XCD block grid (0 = production choice)
-void gemm_bf16_force_tiles(int n1024, int n2048, int xcd_gx);
 // one launch for a lane's QK (+RoPE) and V^T projections (same A, different W / bias / epilogue)
 hipError_t launch_gemm_qkv_fused(const GemmParams& pq, const GemmParams& pv, hipStream_t s);
+// EPI_GATE_RES with the LayerNorm-modulate tail (GemmParams::ln_out): number of workgroups the launch would have if the production
+// tile for this shape supports the tail, else 0.  The caller fuses only when all those workgroups (times the lanes running the
+// same kind of launch concurrently) are co-resident; *panels = arrival counters the launch needs, *per_cu = how many of its
+// workgroups share a CU.
+int gemm_bf16_ln_fusable(const GemmParams& p, int* panels, int* per_cu);
 
 struct AttnParams {
   const bf16_t* q;   // [B2, H, pitch, 64]

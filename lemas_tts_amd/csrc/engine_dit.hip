@@ -47,6 +47,12 @@ struct lemas_dit {
   bool qkv_fused = true;    // QK and V projections of a lane in one launch
   bool fp8 = false;         // block GEMMs on the MXFP8 path (BASELINE config 5); weights quantised on first use
   bool fp8_ready = false;
+  // measurement options (per engine; changing one drops the cached graphs): explicit tile ids for the block GEMMs with N == 1024 /
+  // N == 2048, for the fused QK+V launch, and the XCD block grid of the tile order; 0 = the production choice
+  int opt_tile_n1024 = 0, opt_tile_n2048 = 0, opt_tile_qkv = 0, opt_xcd_gx = 0;
+  bool ln_fused = true;     // the AdaLN LayerNorms behind the gated residual updates run as the tail of those GEMM launches (gemm_bf16.hip ln_tail)
+  unsigned int* ln_err_host = nullptr;   // pinned, device-visible: set by a device-side wait that gave up (checked at every entry point)
+  unsigned int* ln_err_dev = nullptr;
   hipStream_t s2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 
@@ -69,7 +75,9 @@ struct lemas_dit {
   DevBuf d_te, d_rowmask, d_t1, d_t2, d_t3, d_gx, d_ct;   // text embedding scratch
   DevBuf d_pconst, d_y, d_xres, d_hbf, d_q, d_k, d_vt, d_abf, d_ff, d_cmid, d_pred;
   DevBuf d_h8, d_hmx, d_a8, d_amx, d_ff8, d_ffmx;         // MXFP8 activations of the fp8 path (bytes + E8M0 scales)
+  DevBuf d_lncnt;                                         // arrival counters of the fused LayerNorm tails: [block][site][lane][panel]
   int tab_stride = 0;
+  int n_cus = 0;
 
   std::map<std::string, hipGraphExec_t> graphs;
   unsigned long long moved = 1;             // bumped by this engine's DevBufs when one of them is (re)allocated
@@ -82,7 +90,7 @@ struct lemas_dit {
     return {&wproj_out, &bproj_out, &d_tabW, &d_tabB, &wconv[0], &wconv[1], &d_step, &d_dt, &d_cfg, &d_t, &d_tab, &d_rope_cos,
             &d_rope_sin, &d_len, &d_sin, &d_h1, &d_temb, &d_st, &d_cond_eff, &d_step_cond, &d_pm, &d_pt, &d_te,
             &d_rowmask, &d_t1, &d_t2, &d_t3, &d_gx, &d_ct, &d_pconst, &d_y, &d_xres, &d_hbf, &d_q, &d_k, &d_vt,
-            &d_abf, &d_ff, &d_cmid, &d_pred, &d_h8, &d_hmx, &d_a8, &d_amx, &d_ff8, &d_ffmx};
+            &d_abf, &d_ff, &d_cmid, &d_pred, &d_h8, &d_hmx, &d_a8, &d_amx, &d_ff8, &d_ffmx, &d_lncnt};
   }
   static std::vector<DevBuf*> block_bufs(BlockW& b) {
     return {&b.wqkv, &b.wo, &b.w1, &b.w2, &b.bqkv, &b.wqkv8, &b.wo8, &b.w18, &b.w28, &b.sqkv, &b.so, &b.s1, &b.s2};
@@ -107,6 +115,16 @@ struct lemas_dit {
     for (auto& b : blocks)
       for (DevBuf* w : block_bufs(b)) w->release();
     ws.release();
+    if (ln_err_host) (void)hipHostFree(ln_err_host);
+  }
+  // a device-side wait that gave up left its mark in pinned host memory: every later call on this engine fails loudly
+  int health() const {
+    if (ln_err_host && *(volatile unsigned int*)ln_err_host) {
+      set_error("lemas_dit: a fused LayerNorm tail gave up waiting for its row panel (results since then are invalid); "
+                "set option ln_fused=0 and report the launch shape");
+      return LEMAS_E_STATE;
+    }
+    return 0;
   }
 
   int inner() const { return cfg.heads * cfg.dim_head; }
@@ -244,6 +262,7 @@ int lemas_dit::finalize() {
   RC_TRY(ws.check_complete());
   const int d = cfg.dim, in = inner(), ffd = cfg.ff_mult * d;
   hipStream_t s = nullptr;
+  HIP_TRY(hipDeviceSynchronize());   // a solve() may still be running on the caller's stream: nothing below may free memory under it
   drop_graphs();   // weights may have been reloaded: every cached graph baked the old tensors' addresses
   prepared = false;
   tgrid_cached.clear();
@@ -300,6 +319,16 @@ int lemas_dit::finalize() {
     HIP_TRY(hipMemcpy(d_tabB.p, hb.data(), (size_t)cfg.depth * sizeof(float*), hipMemcpyHostToDevice));
   }
   RC_TRY(d_step.ensure(64));
+  if (!ln_err_host) {
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&ln_err_host), 64, hipHostMallocMapped));
+    *ln_err_host = 0;
+    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&ln_err_dev), ln_err_host, 0));
+    int dev = 0;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    n_cus = prop.multiProcessorCount;
+  }
   if (!s2) {
     HIP_TRY(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
@@ -411,6 +440,7 @@ int lemas_dit::text_embed(const lemas_sample_args* a, hipStream_t s) {
 
 int lemas_dit::prepare(const lemas_sample_args* a, hipStream_t s) {
   if (!finalized) { set_error("lemas_dit_prepare: weights not finalized"); return LEMAS_E_STATE; }
+  RC_TRY(health());
   if (a->batch <= 0 || a->frames <= 0 || a->frames > 4096 || a->steps <= 0 || a->text_len <= 0 || !a->cond || !a->cond_mask ||
       !a->text || !a->t_grid || a->cond_frames <= 0 || a->cond_frames > a->frames) {
     set_error("lemas_dit_prepare: bad arguments (B=%d N=%d F=%d Nt=%d S=%d)", a->batch, a->frames, a->cond_frames, a->text_len, a->steps);
@@ -479,6 +509,7 @@ int lemas_dit::prepare(const lemas_sample_args* a, hipStream_t s) {
   RC_TRY(d_ff.ensure((size_t)rows * cfg.ff_mult * d * 2));
   RC_TRY(d_cmid.ensure((size_t)rows * d * 2));
   RC_TRY(d_pred.ensure((size_t)rows * md * 4));
+  RC_TRY(d_lncnt.ensure((size_t)cfg.depth * 2 * 2 * (rows / 64 + 1) * sizeof(unsigned int)));   // >= [block][site][lane][panel of >= 64 rows]
   if (fp8) {
     RC_TRY(quantize_fp8());
     RC_TRY(d_h8.ensure((size_t)rows * d));
@@ -492,14 +523,14 @@ int lemas_dit::prepare(const lemas_sample_args* a, hipStream_t s) {
   return 0;
 }
 
-#ifdef LEMAS_PHASE_TIMESTAMPS   // measurement builds: in-situ timeline of one forward pass (include/lemas_hip_test.h: lemas_k_timeline)
+#ifdef LEMAS_PHASE_TIMESTAMPS   // measurement builds: in-situ timeline of one forward pass (lemas_k_timeline of the test library, include/lemas_hip_test.h)
 static unsigned long long* g_tl = nullptr;
 static int g_tl_slots = 0, g_tl_next = 0;
-extern "C" int lemas_k_timeline(void* buf, int32_t slots) { g_tl = static_cast<unsigned long long*>(buf); g_tl_slots = slots; return 0; }
+int lemas_internal_timeline(void* buf, int slots) { g_tl = static_cast<unsigned long long*>(buf); g_tl_slots = slots; return 0; }
 #define TL_SLOT(P) do { (P).dbg = (g_tl && g_tl_next < g_tl_slots) ? g_tl + (size_t)(g_tl_next++) * 4096 : nullptr; } while (0)
 #define TL_RESET() do { g_tl_next = 0; } while (0)
 #else
-extern "C" int lemas_k_timeline(void*, int32_t) { set_error("lemas_k_timeline: not a measurement build"); return LEMAS_E_STATE; }
+int lemas_internal_timeline(void*, int) { set_error("lemas_k_timeline: not a measurement build"); return LEMAS_E_STATE; }
 #define TL_SLOT(P) do { } while (0)
 #define TL_RESET() do { } while (0)
 #endif
@@ -532,12 +563,32 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
   // around a launch time that kernel alone (two concurrent streams would add the other lane's queueing to it)
   const bool fork = lanes == 2 && !profile;
   hipStream_t st[2] = {s, fork ? s2 : s};
+  const int bh = BB / lanes;                 // samples (branch-rows) per lane
+  const int rows = bh * pitch;
+  // LayerNorm tails inside the gate + residual GEMM launches: only when every workgroup of such a launch -- of BOTH lanes, which
+  // run the same kind of launch at about the same time -- is resident at once (a tail waits for the other column tiles of its
+  // row panel).  configs[1]: 2 x 120 workgroups of 96 KB LDS on 256 CUs.  Batched shapes keep the separate ln_mod launches.
+  int ln_panels = 0;
+  bool fuse_ln = false;
+  if (ln_fused && !fp8) {
+    GemmParams t{};
+    t.M = rows; t.N = d; t.K = in; t.n_valid = d; t.ldc = d; t.concurrency = lanes; t.tile = d == 1024 ? opt_tile_n1024 : 0;
+    int per_cu = 1;
+    const int wgs = gemm_bf16_ln_fusable(t, &ln_panels, &per_cu);
+    fuse_ln = wgs > 0 && (long)lanes * wgs <= (long)n_cus * per_cu;
+  }
+  unsigned int* lncnt = nullptr;
+  if (fuse_ln) {
+    const size_t nb = (size_t)cfg.depth * 2 * lanes * ln_panels * sizeof(unsigned int);
+    if (nb > d_lncnt.bytes) { set_error("lemas_dit: LayerNorm-tail counters were not sized by prepare()"); return LEMAS_E_STATE; }
+    lncnt = d_lncnt.as<unsigned int>();
+    HIP_TRY(hipMemsetAsync(lncnt, 0, nb, s));      // ahead of the fork: both lanes start from zeroed counters (a memset node in the graph)
+  }
+  auto ln_site = [&](int l, int site, int ln) { return lncnt + ((size_t)(l * 2 + site) * lanes + ln) * ln_panels; };
   if (fork) {
     HIP_TRY(hipEventRecord(ev_fork, s));
     HIP_TRY(hipStreamWaitEvent(s2, ev_fork, 0));
   }
-  const int bh = BB / lanes;                 // samples (branch-rows) per lane
-  const int rows = bh * pitch;
 
   auto convpos = [&](int ln) -> int {        // conv position embedding + residual (dit.py:98)
     hipStream_t q = st[ln];
@@ -581,6 +632,8 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     uint8_t* ffmx = fp8 ? d_ffmx.as<uint8_t>() + r0 * (ffd / 32) : nullptr;
     g.f8 = fp8 ? 1 : 0;
     g.concurrency = lanes;
+    g.xcd_gx = opt_xcd_gx;
+    auto tile_for = [&](int n) { return fp8 ? 0 : n == 1024 ? opt_tile_n1024 : n == 2048 ? opt_tile_n2048 : 0; };
     // A / W / their scales for one GEMM: bf16 operands, or (fp8) MXFP8 activations x per-channel-scaled e4m3 weights
     auto operands = [&](const bf16_t* abf16, const uint8_t* af8, const uint8_t* afmx, const DevBuf& wb, const DevBuf& w8, const DevBuf& wsc,
                         size_t row_off, int K) {
@@ -591,10 +644,12 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
         g.A = abf16; g.W = wb.as<bf16_t>() + row_off * K;
       }
     };
-    RC_TRY(pbegin(PC_LN, q));
-    if (fp8) HIP_TRY(launch_ln_mod_f8(xres, h8, hmx, rows, d, tab, tab_stride, base + d, base, step, q));
-    else HIP_TRY(launch_ln_mod(xres, hbf, rows, d, tab, tab_stride, base + d, base, step, q));
-    RC_TRY(pend(q));
+    if (!(fuse_ln && l > 0)) {      // fused: block l's attn_norm rows were written by block l-1's FF2 launch
+      RC_TRY(pbegin(PC_LN, q));
+      if (fp8) HIP_TRY(launch_ln_mod_f8(xres, h8, hmx, rows, d, tab, tab_stride, base + d, base, step, q));
+      else HIP_TRY(launch_ln_mod(xres, hbf, rows, d, tab, tab_stride, base + d, base, step, q));
+      RC_TRY(pend(q));
+    }
     // one launch for QK and V only while all of its workgroups fit the chip in one round (128 + 64 at configs[1]); beyond that two
     // separately tiled launches pack better (measured: -5 % at N = 2814 and at batch 8 when fused regardless)
     const long qkv_wgs = (long)((rows + 255) / 256) * (3 * in / 128);
@@ -608,6 +663,7 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
       operands(hbf, h8, hmx, w.wqkv, w.wqkv8, w.sqkv, (size_t)2 * in, d);
       gv.A = g.A; gv.a_mx = g.a_mx; gv.W = g.W; gv.w_scale = g.w_scale;
       gv.bias = w.bqkv.as<float>() + 2 * in; gv.N = in; gv.K = d; gv.n_valid = in; gv.kv_len = nullptr;
+      gq.tile = gv.tile = opt_tile_qkv;
       TL_SLOT(gq);
 #ifdef LEMAS_PHASE_TIMESTAMPS
       gv.dbg = gq.dbg;
@@ -618,12 +674,12 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
       RC_TRY(pkernel(PC_GEMM_QK, &g.ev_start, &g.ev_stop));
       operands(hbf, h8, hmx, w.wqkv, w.wqkv8, w.sqkv, 0, d);
       g.bias = w.bqkv.as<float>(); g.N = 2 * in; g.K = d; g.n_valid = 2 * in;
-      g.kv_len = nullptr;
+      g.kv_len = nullptr; g.tile = tile_for(g.N);
       TL_SLOT(g);
       HIP_TRY(launch_gemm_bf16(EPI_QK_ROPE, g, q));
       RC_TRY(pkernel(PC_GEMM_V, &g.ev_start, &g.ev_stop));
       operands(hbf, h8, hmx, w.wqkv, w.wqkv8, w.sqkv, (size_t)2 * in, d);
-      g.bias = w.bqkv.as<float>() + 2 * in; g.N = in; g.n_valid = in;
+      g.bias = w.bqkv.as<float>() + 2 * in; g.N = in; g.n_valid = in; g.tile = tile_for(g.N);
       TL_SLOT(g);
       HIP_TRY(launch_gemm_bf16(EPI_V_T, g, q));
     }
@@ -634,25 +690,38 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     RC_TRY(pkernel(PC_GEMM_OUT, &g.ev_start, &g.ev_stop));
     operands(abf, a8, amx, w.wo, w.wo8, w.so, 0, in);
     g.bias = w.bo; g.N = d; g.K = in; g.n_valid = d;
-    g.out_f32 = xres; g.ldc = d; g.gate_off = base + 2 * d; g.kv_len = has_len ? d_len.as<int>() : nullptr;
+    g.out_f32 = xres; g.ldc = d; g.gate_off = base + 2 * d; g.kv_len = has_len ? d_len.as<int>() : nullptr; g.tile = tile_for(g.N);
+    if (fuse_ln) {   // ff_norm (modules.py:637) as the tail of the out-projection launch
+      g.ln_out = hbf; g.ln_scale_off = base + 4 * d; g.ln_shift_off = base + 3 * d; g.ln_cnt = ln_site(l, 0, ln); g.ln_err = ln_err_dev;
+    }
     TL_SLOT(g);
     HIP_TRY(launch_gemm_bf16(EPI_GATE_RES, g, q));
-    RC_TRY(pbegin(PC_LN, q));
-    if (fp8) HIP_TRY(launch_ln_mod_f8(xres, h8, hmx, rows, d, tab, tab_stride, base + 4 * d, base + 3 * d, step, q));
-    else HIP_TRY(launch_ln_mod(xres, hbf, rows, d, tab, tab_stride, base + 4 * d, base + 3 * d, step, q));
-    RC_TRY(pend(q));
+    g.ln_out = nullptr;
+    if (!fuse_ln) {
+      RC_TRY(pbegin(PC_LN, q));
+      if (fp8) HIP_TRY(launch_ln_mod_f8(xres, h8, hmx, rows, d, tab, tab_stride, base + 4 * d, base + 3 * d, step, q));
+      else HIP_TRY(launch_ln_mod(xres, hbf, rows, d, tab, tab_stride, base + 4 * d, base + 3 * d, step, q));
+      RC_TRY(pend(q));
+    }
     RC_TRY(pkernel(PC_GEMM_FF1, &g.ev_start, &g.ev_stop));
     operands(hbf, h8, hmx, w.w1, w.w18, w.s1, 0, d);
     g.bias = w.b1; g.N = ffd; g.K = d; g.n_valid = ffd;
-    g.out_bf16 = ffb; g.out_f8 = ff8; g.out_mx = ffmx; g.ldc = ffd; g.kv_len = nullptr;
+    g.out_bf16 = ffb; g.out_f8 = ff8; g.out_mx = ffmx; g.ldc = ffd; g.kv_len = nullptr; g.tile = tile_for(g.N);
     TL_SLOT(g);
     HIP_TRY(launch_gemm_bf16(fp8 ? EPI_BIAS_GELU_F8 : EPI_BIAS_GELU_BF16, g, q));
     RC_TRY(pkernel(PC_GEMM_FF2, &g.ev_start, &g.ev_stop));
     operands(ffb, ff8, ffmx, w.w2, w.w28, w.s2, 0, ffd);
     g.bias = w.b2; g.N = d; g.K = ffd; g.n_valid = d;
-    g.out_f32 = xres; g.ldc = d; g.gate_off = base + 5 * d;
+    g.out_f32 = xres; g.ldc = d; g.gate_off = base + 5 * d; g.tile = tile_for(g.N);
+    if (fuse_ln) {   // the next block's attn_norm (modules.py:314: shift, scale first), or the final norm (:335: scale, shift) after the last
+      const int nb = (l + 1) * 6 * d, fb = cfg.depth * 6 * d;
+      g.ln_out = hbf; g.ln_cnt = ln_site(l, 1, ln); g.ln_err = ln_err_dev;
+      if (l + 1 < cfg.depth) { g.ln_scale_off = nb + d; g.ln_shift_off = nb; }
+      else { g.ln_scale_off = fb; g.ln_shift_off = fb + d; }
+    }
     TL_SLOT(g);
     HIP_TRY(launch_gemm_bf16(EPI_GATE_RES, g, q));
+    g.ln_out = nullptr;
     return 0;
   };
 
@@ -660,9 +729,11 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     hipStream_t q = st[ln];
     const size_t r0 = (size_t)ln * rows;
     const int fb = cfg.depth * 6 * d;
-    RC_TRY(pbegin(PC_LN, q));
-    HIP_TRY(launch_ln_mod(d_xres.as<float>() + r0 * d, d_hbf.as<bf16_t>() + r0 * d, rows, d, tab, tab_stride, fb, fb + d, step, q));
-    RC_TRY(pend(q));
+    if (!fuse_ln) {                // fused: the last block's FF2 launch wrote the final norm's rows
+      RC_TRY(pbegin(PC_LN, q));
+      HIP_TRY(launch_ln_mod(d_xres.as<float>() + r0 * d, d_hbf.as<bf16_t>() + r0 * d, rows, d, tab, tab_stride, fb, fb + d, step, q));
+      RC_TRY(pend(q));
+    }
     RC_TRY(pbegin(PC_GEMM_FINAL, q));
     GemmParams g{};
     g.M = rows; g.seq_pitch = pitch; g.seq_valid = N; g.batch = B; g.heads = cfg.heads; g.npad = npad;
@@ -699,6 +770,7 @@ int lemas_dit::enqueue_update(float* traj, hipStream_t s) {
 
 int lemas_dit::solve(const lemas_sample_args* a, hipStream_t s) {
   if (!finalized || !prepared) { set_error("lemas_dit_solve: prepare() has not run on the finalized weights"); return LEMAS_E_STATE; }
+  RC_TRY(health());
   if (a->batch != B || a->frames != N || a->steps != S || !a->y) { set_error("lemas_dit_solve: arguments differ from prepare()"); return LEMAS_E_ARG; }
   const size_t ybytes = (size_t)B * N * cfg.mel_dim * 4;
   const size_t yw = (size_t)N * cfg.mel_dim * 4, ypitch = (size_t)pitch * cfg.mel_dim * 4;
@@ -714,7 +786,7 @@ int lemas_dit::solve(const lemas_sample_args* a, hipStream_t s) {
       graph_generation = moved;
     }
     char key[96];
-    snprintf(key, sizeof key, "B%d_N%d_cfg%d_len%d_dual%d_f8%d", B, N, (int)use_cfg, (int)has_len, (int)dual, (int)fp8);
+    snprintf(key, sizeof key, "B%d_N%d_cfg%d_len%d_dual%d_f8%d_ln%d", B, N, (int)use_cfg, (int)has_len, (int)dual, (int)fp8, (int)ln_fused);
     auto it = graphs.find(key);
     if (it == graphs.end()) {
       if (graphs.size() >= 32) drop_graphs();   // a serving process sees a new length almost every utterance: bound the cache (a capture costs ~3 ms)
@@ -768,6 +840,7 @@ static int dit_load(lemas_dit* m, const char* name, const float* src, const int6
   // loaded-but-unused tensors of the reference checkpoint (cfm.py:171 accent classifier) are accepted and dropped
   if (strncmp(name, "accent_classifier.", 18) == 0) return 0;
   // a (re)loaded tensor lives at a new address: nothing prepared or captured on the old weights may be replayed
+  if (m->finalized || !m->graphs.empty()) HIP_TRY(hipDeviceSynchronize());   // a reload while a solve() is in flight: wait before touching what it uses
   m->finalized = false;
   m->prepared = false;
   m->drop_graphs();
@@ -792,6 +865,20 @@ int lemas_dit_set_option(lemas_dit* m, const char* key, int64_t value) {
   }
   if (!strcmp(key, "qkv_fused")) {
     m->qkv_fused = value != 0;
+    m->drop_graphs();
+    return 0;
+  }
+  {
+    int* slot = !strcmp(key, "tile_n1024") ? &m->opt_tile_n1024 : !strcmp(key, "tile_n2048") ? &m->opt_tile_n2048
+              : !strcmp(key, "tile_qkv") ? &m->opt_tile_qkv : !strcmp(key, "xcd_gx") ? &m->opt_xcd_gx : nullptr;
+    if (slot) {
+      *slot = (int)value;
+      m->drop_graphs();     // a captured graph baked the kernels of the old choice
+      return 0;
+    }
+  }
+  if (!strcmp(key, "ln_fused")) {
+    m->ln_fused = value != 0;
     m->drop_graphs();
     return 0;
   }
@@ -836,6 +923,12 @@ int lemas_dit_forward(lemas_dit* m, const float* x, int32_t step_index, float* p
   RC_TRY(m->enqueue_forward(s));
   HIP_TRY(hipMemcpy2DAsync(pred, w, m->d_pred.p, wp, w, m->BB, hipMemcpyDeviceToDevice, s));
   return 0;
+}
+
+int lemas_dit_health(lemas_dit* m) {
+  if (!m) return LEMAS_E_ARG;
+  HIP_TRY(hipDeviceSynchronize());
+  return m->health();
 }
 
 int lemas_dit_profile_read(lemas_dit* m, char (*names)[32], double* total_ms, int64_t* launches, int32_t cap) {

@@ -4,12 +4,16 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstring>
+#include <string>
 #include <vector>
 
 #include "engine_common.h"
 #include "../../include/lemas_hip_test.h"
 
 using namespace lemas;
+
+int lemas_internal_timeline(void* buf, int slots);   // engine_dit.hip: live in a -DLEMAS_PHASE_TIMESTAMPS build, an error otherwise
 
 namespace {
 
@@ -75,7 +79,7 @@ __global__ void fill_pattern_kernel(bf16_t* p, size_t n, unsigned seed) {
 
 extern "C" {
 
-int lemas_k_tile_override(int32_t n1024, int32_t n2048, int32_t xcd_gx) { gemm_bf16_force_tiles(n1024, n2048, xcd_gx); return 0; }
+int lemas_k_timeline(void* buf, int32_t slots) { return lemas_internal_timeline(buf, slots); }
 
 int lemas_k_linear_bf16(const float* A, const float* W, const float* bias, float* out, int32_t M, int32_t N, int32_t K,
                         int32_t act, void* stream) {
@@ -159,6 +163,83 @@ int lemas_k_gemm_epi(int32_t epi, int32_t tile, const float* A, const float* W, 
     set_error("lemas_k_gemm_epi: unknown epilogue %d", epi);
     return LEMAS_E_ARG;
   }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(s));
+  return 0;
+}
+
+// The gate + residual GEMM with its LayerNorm-modulate tail (GemmParams::ln_out): x (in/out) is the residual stream [batch*pitch, 1024],
+// h (out) the modulated LayerNorm of the UPDATED rows, widened to fp32.  `concurrent` > 1 launches that many independent copies on
+// as many streams at once (what the two CFG lanes do), each with its own operands' copies and counters.
+int lemas_k_gemm_gate_ln(int32_t tile, const float* A, const float* W, const float* bias, const float* gate, const float* scale,
+                         const float* shift, const int32_t* seq_len, float* x, float* h, int32_t batch, int32_t pitch, int32_t frames,
+                         int32_t K, int32_t concurrent, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  RC_TRY(kernels_init());
+  const int N = 1024;
+  if (batch <= 0 || pitch % 128 != 0 || frames <= 0 || frames > pitch || K % 64 != 0 || concurrent < 1 || concurrent > 4) {
+    set_error("lemas_k_gemm_gate_ln: need pitch %% 128 == 0, frames <= pitch, K %% 64 == 0, 1 <= concurrent <= 4");
+    return LEMAS_E_ARG;
+  }
+  const int M = batch * pitch;
+  Scratch sc;
+  bf16_t* a = sc.get<bf16_t>((size_t)M * K);
+  bf16_t* w = sc.get<bf16_t>((size_t)N * K);
+  float* tab = sc.get<float>((size_t)3 * N);
+  int* step = sc.get<int>(16);
+  unsigned int* cnt = sc.get<unsigned int>((size_t)concurrent * (M / 64 + 1));
+  float* xs = sc.get<float>((size_t)concurrent * M * N);          // one residual stream per concurrent copy
+  bf16_t* hs = sc.get<bf16_t>((size_t)concurrent * M * N);
+  unsigned int* err_host = nullptr;
+  unsigned int* err_dev = nullptr;
+  if (!a || !w || !tab || !step || !cnt || !xs || !hs) { set_error("lemas_k_gemm_gate_ln: out of memory"); return LEMAS_E_STATE; }
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&err_host), 64, hipHostMallocMapped));
+  *err_host = 0;
+  HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&err_dev), err_host, 0));
+  HIP_TRY(launch_f32_to_bf16(A, a, (size_t)M * K, s));
+  HIP_TRY(launch_f32_to_bf16(W, w, (size_t)N * K, s));
+  HIP_TRY(hipMemcpyAsync(tab, gate, (size_t)N * 4, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipMemcpyAsync(tab + N, scale, (size_t)N * 4, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipMemcpyAsync(tab + 2 * N, shift, (size_t)N * 4, hipMemcpyDeviceToDevice, s));
+  for (int c = 0; c < concurrent; ++c) HIP_TRY(hipMemcpyAsync(xs + (size_t)c * M * N, x, (size_t)M * N * 4, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  GemmParams p{};
+  p.A = a; p.W = w; p.bias = bias; p.M = M; p.N = N; p.K = K; p.n_valid = N; p.ldc = N;
+  p.seq_pitch = pitch; p.seq_valid = frames; p.batch = batch; p.step_idx = step;
+  p.tab = tab; p.tab_stride = 0; p.gate_off = 0; p.kv_len = seq_len;
+  p.ln_scale_off = N; p.ln_shift_off = 2 * N; p.ln_err = err_dev; p.concurrency = concurrent;
+  std::vector<hipStream_t> st(concurrent, nullptr);
+  int rc = 0;
+  for (int c = 0; c < concurrent && rc == 0; ++c)
+    if (hipStreamCreateWithFlags(&st[c], hipStreamNonBlocking) != hipSuccess) rc = LEMAS_E_STATE;
+  for (int c = 0; c < concurrent && rc == 0; ++c) {
+    p.out_f32 = xs + (size_t)c * M * N; p.ln_out = hs + (size_t)c * M * N; p.ln_cnt = cnt + (size_t)c * (M / 64 + 1);
+    hipError_t e = launch_gemm_bf16_tile(EPI_GATE_RES, p, tile, st[c]);
+    if (e != hipSuccess) rc = hip_fail(e, "launch_gemm_bf16_tile(gate + LayerNorm tail)", __FILE__, __LINE__);
+  }
+  for (int c = 0; c < concurrent; ++c)
+    if (st[c]) { (void)hipStreamSynchronize(st[c]); (void)hipStreamDestroy(st[c]); }
+  const unsigned int gave_up = *err_host;
+  (void)hipHostFree(err_host);
+  if (rc != 0) return rc;
+  if (gave_up) { set_error("lemas_k_gemm_gate_ln: a LayerNorm tail gave up waiting for its row panel"); return LEMAS_E_STATE; }
+  // every concurrent copy computed the same thing: compare them bit for bit, return copy 0
+  if (concurrent > 1) {
+    std::vector<float> h0((size_t)M * N), hc((size_t)M * N);
+    std::vector<unsigned short> b0((size_t)M * N), bc((size_t)M * N);
+    HIP_TRY(hipMemcpy(h0.data(), xs, h0.size() * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(b0.data(), hs, b0.size() * 2, hipMemcpyDeviceToHost));
+    for (int c = 1; c < concurrent; ++c) {
+      HIP_TRY(hipMemcpy(hc.data(), xs + (size_t)c * M * N, hc.size() * 4, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(bc.data(), hs + (size_t)c * M * N, bc.size() * 2, hipMemcpyDeviceToHost));
+      if (memcmp(h0.data(), hc.data(), h0.size() * 4) != 0 || memcmp(b0.data(), bc.data(), b0.size() * 2) != 0) {
+        set_error("lemas_k_gemm_gate_ln: concurrent copy %d differs from copy 0", c);
+        return LEMAS_E_STATE;
+      }
+    }
+  }
+  HIP_TRY(hipMemcpyAsync(x, xs, (size_t)M * N * 4, hipMemcpyDeviceToDevice, s));
+  hipLaunchKernelGGL(widen_kernel, dim3(2048), dim3(256), 0, s, hs, h, (size_t)M * N);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(s));
   return 0;
@@ -323,6 +404,8 @@ extern "C" int lemas_k_bench(const char* what, int32_t M, int32_t N, int32_t K, 
     HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
     return 0;
   };
+  const bool with_ln = w == "gemm_gate_ln";    // the gate + residual GEMM with its LayerNorm tail (N = 1024)
+  if (with_ln) w = "gemm_gate";
   if (w == "gemm_gelu" || w == "gemm_gelu8" || w == "gemm_gate" || w == "gemm_qk" || w == "gemm_v" || w == "gemm_f32out") {
     const int Np = (N + 127) & ~127;
     bf16_t* a = sc.get<bf16_t>((size_t)M * K);
@@ -357,9 +440,26 @@ extern "C" int lemas_k_bench(const char* what, int32_t M, int32_t N, int32_t K, 
     }
     const int epi = w == "gemm_gelu8" ? EPI_BIAS_GELU_F8 : w == "gemm_gelu" ? EPI_BIAS_GELU_BF16 : w == "gemm_gate" ? EPI_GATE_RES : w == "gemm_qk" ? EPI_QK_ROPE : w == "gemm_v" ? EPI_V_T : EPI_BIAS_F32;
     if ((epi == EPI_QK_ROPE && N != 2048) || (epi == EPI_V_T && N != 1024)) { set_error("bench: gemm_qk needs N = 2048, gemm_v N = 1024"); return LEMAS_E_ARG; }
+    unsigned int* err_host = nullptr;
+    if (with_ln) {
+      if (f8 || N != 1024) { set_error("bench: gemm_gate_ln is the bf16 N = 1024 launch"); return LEMAS_E_ARG; }
+      float* tab3 = sc.get<float>(3 * 1024);
+      bf16_t* lnout = sc.get<bf16_t>((size_t)M * 1024);
+      unsigned int* cnt = sc.get<unsigned int>((size_t)M / 64 + 1);
+      if (!tab3 || !lnout || !cnt) { set_error("bench: out of memory"); return LEMAS_E_STATE; }
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&err_host), 64, hipHostMallocMapped));
+      *err_host = 0;
+      unsigned int* err_dev = nullptr;
+      HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&err_dev), err_host, 0));
+      p.tab = tab3; p.ln_out = lnout; p.ln_scale_off = 1024; p.ln_shift_off = 2048; p.ln_cnt = cnt; p.ln_err = err_dev;
+      const size_t cb = ((size_t)M / 64 + 1) * 4;
+      rc = time_it([&]() { hipError_t e = hipMemsetAsync(cnt, 0, cb, s); return e != hipSuccess ? e : launch_gemm_bf16_tile(epi, p, variant, s); });
+      if (rc == 0 && *err_host) { set_error("bench: a LayerNorm tail gave up"); rc = LEMAS_E_STATE; }
+      (void)hipHostFree(err_host);
+    } else
     rc = time_it([&]() { return launch_gemm_bf16_tile(epi, p, variant, s); });
 #ifdef LEMAS_PHASE_TIMESTAMPS
-    if (rc == 0 && variant >= 16) {   // phase timestamps of one more launch
+    if (rc == 0 && variant >= 16 && !with_ln) {   // phase timestamps of one more launch
       const int bm_ = variant == 17 || variant == 18 ? 128 : variant == 19 ? 64 : 256, bn_ = variant == 22 ? 256 : variant == 16 || variant == 17 ? 128 : 64;
       const int grid = ((M + bm_ - 1) / bm_) * (Np / bn_);
       unsigned long long* d = sc.get<unsigned long long>((size_t)grid * 4);

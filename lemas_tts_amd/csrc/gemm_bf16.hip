@@ -28,6 +28,7 @@
 #include <mutex>
 
 #include "common.h"
+#include "ln_core.h"
 
 namespace {
 
@@ -36,7 +37,8 @@ constexpr int BK = 64;
 // Measurement builds only (-DLEMAS_PHASE_TIMESTAMPS, see profiles/r02_kbench_phases.txt): thread 0 of every workgroup stamps the 100 MHz
 // wall clock at entry, after the prologue, after the K loop and after its last store has drained.  Compiled out of the product.
 #ifdef LEMAS_PHASE_TIMESTAMPS
-#define PHASE_STAMP(k) do { if (p.dbg && threadIdx.x == 0) p.dbg[blockIdx.x * 4 + (k)] = wall_clock64(); } while (0)
+// a timeline slot holds 1024 workgroups x 4 stamps (engine_dit.hip TL_SLOT): larger grids stamp their first 1024 workgroups only
+#define PHASE_STAMP(k) do { if (p.dbg && threadIdx.x == 0 && blockIdx.x < 1024) p.dbg[blockIdx.x * 4 + (k)] = wall_clock64(); } while (0)
 #define PHASE_STAMP_END() do { if (p.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); PHASE_STAMP(3); } } while (0)
 #else
 #define PHASE_STAMP(k) do { } while (0)
@@ -566,6 +568,90 @@ constexpr int slab_bytes() {
                                                       : SlabBf16<WTM, WTN>::BYTES;
 }
 
+// ---------------------------------------------------------------- LayerNorm-modulate tail of the gate + residual GEMM
+// The AdaLN-modulated LayerNorm behind every gated residual update (modules.py:635-637, :639 -> the next block's :314, the final
+// :335) needs whole rows of x_res; a 128-column tile holds an eighth of one.  As its own launch it costs a lane's chain 9-13 us per
+// site (5 us of latency-bound kernel between two ~2 us dependent-launch boundaries: profiles/r02_timeline_step.txt) for 0.4 % of the
+// FLOPs.  Here the GEMM launch finishes the job itself: the TILES_N workgroups that share a row panel meet at the panel's arrival
+// counter once their x_res tiles are out (write-through stores, drained by every wave before the one arrival per workgroup), and
+// each then normalises R = BM / TILES_N rows of the panel.  Visibility follows the recipe of the hardware guide (producer: sc1
+// payload stores -> s_waitcnt vmcnt(0) in every storing wave -> barrier -> relaxed agent-scope arrival; consumer: relaxed poll by
+// one lane -> barrier -> sc1 loads, which bypass this CU's L1; no XCD's L2 holds a line of x_res that another workgroup wrote in
+// this launch, because a workgroup only ever read the columns it then overwrote and sc1 stores drop the line).
+// Progress: a waiting workgroup depends only on workgroups of the SAME launch; the caller fuses only when all of them (and the
+// other lane's) fit the chip at once (gemm_bf16_ln_fusable), kernels that do not wait always drain, and the wait gives up after
+// ~50 ms with the sticky error word set instead of hanging the queue.
+typedef __attribute__((address_space(1))) unsigned int gu32;
+
+__device__ __forceinline__ void ln_load_row_sc1(const float* row, int lane, u32x4 (&v)[LN_PER][2]) {
+  static_assert(LN_PER == 2, "row image");
+  const char* p0 = reinterpret_cast<const char*>(row) + lane * 32;   // float4 index (lane + 64 i) * 2 + h -> byte lane * 32 + i * 2048 + h * 16
+  const char* p1 = p0 + 2048;
+  asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
+               "global_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
+               "global_load_dwordx4 %2, %5, off sc1\n\t"
+               "global_load_dwordx4 %3, %5, off offset:16 sc1"
+               : "=&v"(v[0][0]), "=&v"(v[0][1]), "=&v"(v[1][0]), "=&v"(v[1][1]) : "v"(p0), "v"(p1) : "memory");
+}
+// retire the asm loads above: the wait names every destination, so no consumer can be scheduled ahead of it
+__device__ __forceinline__ void ln_wait_row(u32x4 (&v)[LN_PER][2]) {
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0][0]), "+v"(v[0][1]), "+v"(v[1][0]), "+v"(v[1][1]) : : "memory");
+}
+
+template <int TBM, int TBN, int NW>
+__device__ __forceinline__ void ln_tail(const GemmParams& p, int m0, int n0) {
+  constexpr int TILES_N = LN_D / TBN, R = TBM / TILES_N, RW = R / NW;
+  static_assert(TILES_N * TBN == LN_D && R * TILES_N == TBM && RW * NW == R && RW >= 1, "rows of a panel must divide over its workgroups and waves");
+  constexpr int ROWS = RW >= 2 ? 2 : 1;     // rows in flight per wave (as the stand-alone kernel)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tm = m0 / TBM, tn = n0 / TBN;
+  // publish this workgroup's x_res tile
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  gu32* cnt = (gu32*)(p.ln_cnt + tm);
+  if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // the modulation vectors do not depend on the panel: in flight while the other tiles arrive
+  const float* base = p.tab + (size_t)p.step_idx[0] * p.tab_stride;
+  float4 a[LN_PER][2], b[LN_PER][2];
+  ln_load_vec(base + p.ln_scale_off, lane, a);
+  ln_load_vec(base + p.ln_shift_off, lane, b);
+  if (tid == 0) {
+    unsigned spins = 0;
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)TILES_N) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > (1u << 16)) {
+        __hip_atomic_store((gu32*)p.ln_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  const int row0 = m0 + tn * R + wave * RW;
+#pragma unroll
+  for (int r = 0; r < RW; r += ROWS) {
+    u32x4 raw[ROWS][LN_PER][2];
+#pragma unroll
+    for (int q = 0; q < ROWS; ++q) {
+      int row = row0 + r + q;
+      row = row < p.M ? row : p.M - 1;
+      ln_load_row_sc1(p.out_f32 + (size_t)row * LN_D, lane, raw[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < ROWS; ++q) ln_wait_row(raw[q]);
+#pragma unroll
+    for (int q = 0; q < ROWS; ++q) {
+      float4 v[LN_PER][2];
+#pragma unroll
+      for (int i = 0; i < LN_PER; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) v[i][h] = __builtin_bit_cast(float4, raw[q][i][h]);
+      const int row = row0 + r + q;
+      ln_row_store(v, a, b, p.ln_out + (size_t)row * LN_D, lane, row < p.M);
+    }
+  }
+}
+
 template <bool F8> struct FragT { using type = bf16x8; };
 template <> struct FragT<true> { using type = i32x8; };
 
@@ -772,6 +858,9 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, int m
       if (SWAP) epilogue_rows<EPI, 1, TJ>(p, blk, slab, m0 + wm * WTM + 32 * i, n0 + wn * WTN, lane);
       else epilogue_vt<1, TJ>(p, blk, slab, m0 + wm * WTM + 32 * i, n0 + wn * WTN, lane);
     }
+  }
+  if constexpr (EPI == EPI_GATE_RES && SWAP && !F8) {
+    if (p.ln_out) ln_tail<TBM, TBN, NW>(p, m0, n0);
   }
   PHASE_STAMP_END();
 }
@@ -1200,11 +1289,8 @@ struct Launch {
 
 // Largest tile that still yields about one workgroup per CU (measured at M = 1920 / 3840 / 18432 with tools/kbench.py).
 // With two CFG lanes in flight each launch only needs half the chip (p.concurrency = 2: +1.8 % end to end for the larger tiles).
-int g_force_n1024 = 0, g_force_n2048 = 0, g_force_gx = 0, g_force_qkv = 0;   // measurement hook (lemas_k_tile_override, include/lemas_hip_test.h); 0 = off
-
 int pick_tile(const GemmParams& p) {
-  if (!p.f8 && p.N == 1024 && g_force_n1024) return g_force_n1024;
-  if (!p.f8 && p.N == 2048 && g_force_n2048) return g_force_n2048;
+  if (p.tile) return p.tile;      // explicit tile: unit tests, kbench, the engine's measurement options (per engine, never process-global)
   const long conc = p.concurrency > 1 ? p.concurrency : 1;
   const long t256 = (long)((p.M + 255) / 256) * (p.N / 128), t128 = (long)((p.M + 127) / 128) * (p.N / 128);
   const long want = 200 / conc;
@@ -1308,19 +1394,12 @@ struct LaunchQkv {
 
 // tile of the fused QK+V launch: the largest whose QK part alone still gives ~100 workgroups per lane (two lanes share the chip)
 int pick_qkv_tile(const GemmParams& pq) {
-  if (g_force_qkv) return g_force_qkv;
-  if (g_force_n2048 == T256x128 || g_force_n2048 == T128x128 || g_force_n2048 == T128x64) return g_force_n2048;
+  if (pq.tile == T256x128 || pq.tile == T128x128 || pq.tile == T128x64 || pq.tile == T128x128W4) return pq.tile;
   const long t256 = (long)((pq.M + 255) / 256) * (pq.N / 128), t128 = (long)((pq.M + 127) / 128) * (pq.N / 128);
   return t256 >= 100 ? T256x128 : t128 >= 100 ? T128x128 : T128x64;
 }
 
 }  // namespace
-
-void gemm_bf16_force_tiles(int n1024, int n2048, int xcd_gx) {
-  g_force_qkv = 0;
-  if (xcd_gx >= 100) { g_force_qkv = xcd_gx - 100; xcd_gx = 0; }     // measurement hook: tile of the fused QK+V launch
-  g_force_n1024 = n1024; g_force_n2048 = n2048; g_force_gx = xcd_gx;
-}
 
 hipError_t gemm_bf16_init() {
   hipError_t e;
@@ -1343,7 +1422,6 @@ hipError_t gemm_bf16_init() {
 
 // XCD block grid (gx x 8/gx, see tile_coords): fabric-side fetch ~ gy * |A| + gx * |W| -> minimise gy * M + gx * N
 static int pick_xcd_gx(int M, int N) {
-  if (g_force_gx) return g_force_gx;
   int best = 8;
   long cost = -1;
   for (int gx : {8, 4, 2, 1}) {
@@ -1355,8 +1433,9 @@ static int pick_xcd_gx(int M, int N) {
 
 hipError_t launch_gemm_qkv_fused(const GemmParams& pq_in, const GemmParams& pv_in, hipStream_t s) {
   GemmParams pq = pq_in, pv = pv_in;
-  if (pq.xcd_gx <= 0) pq.xcd_gx = pick_xcd_gx(pq.M, pq.N);
-  if (pv.xcd_gx <= 0) pv.xcd_gx = pick_xcd_gx(pv.M, pv.N);
+  // only {8, 4, 2, 1} cut the tile grid into 8 XCD blocks (anything else would make tile_coords divide by zero or skip tiles)
+  if (pq.xcd_gx != 8 && pq.xcd_gx != 4 && pq.xcd_gx != 2 && pq.xcd_gx != 1) pq.xcd_gx = pick_xcd_gx(pq.M, pq.N);
+  if (pv.xcd_gx != 8 && pv.xcd_gx != 4 && pv.xcd_gx != 2 && pv.xcd_gx != 1) pv.xcd_gx = pick_xcd_gx(pv.M, pv.N);
   if (pq.K % 128 != 0 || pq.N % 128 != 0 || pv.N % 128 != 0 || pq.M != pv.M || pq.f8 != pv.f8 || pq.M <= 0) return hipErrorInvalidValue;
   if (pq.f8 && (!pq.a_mx || !pq.w_scale || !pv.w_scale)) return hipErrorInvalidValue;
   switch (pick_qkv_tile(pq)) {
@@ -1367,10 +1446,35 @@ hipError_t launch_gemm_qkv_fused(const GemmParams& pq_in, const GemmParams& pv_i
   }
 }
 
+// tiles whose gate + residual kernel carries the LayerNorm tail (the lock-step body; the ping-pong tiles serve batched shapes,
+// whose grids do not fit the chip at once anyway): rows x columns of the tile and how many of its workgroups share a CU
+static bool ln_tile_shape(int tile, int* bm, int* bn, int* per_cu) {
+  switch (tile) {
+    case T128x128: case T128x128W4: *bm = 128; *bn = 128; *per_cu = 1; return true;   // 96 KB of LDS each
+    case T128x64: *bm = 128; *bn = 64; *per_cu = 2; return true;                      // 72 KB
+    case T64x64: *bm = 64; *bn = 64; *per_cu = 2; return true;                        // 48 KB (3 would fit: counted as 2)
+    default: return false;
+  }
+}
+
+int gemm_bf16_ln_fusable(const GemmParams& p, int* panels, int* per_cu) {
+  int bm, bn;
+  if (p.f8 || p.N != LN_D || p.ldc != LN_D || p.n_valid != LN_D || p.M <= 0) return 0;
+  if (!ln_tile_shape(pick_tile(p), &bm, &bn, per_cu) || p.M % bm != 0) return 0;
+  *panels = p.M / bm;
+  return (p.M / bm) * (p.N / bn);
+}
+
 hipError_t launch_gemm_bf16_tile(int epi, const GemmParams& p_in, int tile, hipStream_t s) {
   GemmParams p = p_in;
   if (p.xcd_gx != 8 && p.xcd_gx != 4 && p.xcd_gx != 2 && p.xcd_gx != 1) p.xcd_gx = pick_xcd_gx(p.M, p.N);
   if (p.K % BK != 0 || p.N % 128 != 0 || p.M <= 0 || p.seq_pitch <= 0) return hipErrorInvalidValue;
+  if (p.ln_out) {   // LayerNorm tail: only on the tiles that carry it, with complete row panels and the counters in place
+    int bm, bn, per_cu;
+    if (epi != EPI_GATE_RES || p.f8 || p.N != LN_D || p.ldc != LN_D || p.n_valid != LN_D || !p.ln_cnt || !p.ln_err || !p.tab || !p.step_idx)
+      return hipErrorInvalidValue;
+    if (!ln_tile_shape(tile ? tile : pick_tile(p), &bm, &bn, &per_cu) || p.M % bm != 0) return hipErrorInvalidValue;
+  }
   // the row-wise epilogues store whole 16-B chunks: 4 fp32 / 8 bf16 / 16 e4m3 columns, so the stored width and the row
   // pitch must be multiples of that (every shape of the path is: 100, 1024, 2048)
   if (epi == EPI_BIAS_F32 || epi == EPI_GATE_RES) { if ((p.n_valid > 0 && p.n_valid % 4) || p.ldc % 4) return hipErrorInvalidValue; }
@@ -1399,4 +1503,4 @@ hipError_t launch_gemm_bf16_tile(int epi, const GemmParams& p_in, int tile, hipS
   return hipErrorInvalidValue;
 }
 
-hipError_t launch_gemm_bf16(int epi, const GemmParams& p, hipStream_t s) { return launch_gemm_bf16_tile(epi, p, 0, s); }
+hipError_t launch_gemm_bf16(int epi, const GemmParams& p, hipStream_t s) { return launch_gemm_bf16_tile(epi, p, p.tile, s); }

@@ -5,17 +5,19 @@
 //   misc          fp32->bf16 conversion / weight re-layout used when weights are loaded
 #include "common.h"
 #include "kernels.h"
+#include "ln_core.h"
 
 namespace {
 
 // one wave per ROWS rows; D = 1024 -> 16 elements per lane and row as 2 groups of 8 consecutive columns (2 x float4 loads each), so the
 // bf16 result leaves as 16-B write-through (sc1) stores: the next kernel (a GEMM on other XCDs) reads it from memory anyway and
-// the launch does not end on an L2 write-back of 3.9 MB
+// the launch does not end on an L2 write-back of 3.9 MB.  The row arithmetic is ln_core.h's (shared with the GEMM's LN tail).
 template <int D, int ROWS>
 __global__ __launch_bounds__(256) void ln_mod_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, int M,
                                                      const float* __restrict__ tab, int tab_stride, int scale_off,
                                                      int shift_off, const int* __restrict__ step_idx) {
-  constexpr int PER = D / 512;  // groups of 8 columns per lane
+  static_assert(D == LN_D, "row width");
+  constexpr int PER = LN_PER;
   const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS;
   if (row0 >= M) return;
   const int lane = threadIdx.x & 63;
@@ -32,46 +34,11 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const float* __restrict__ x
 #pragma unroll
       for (int h = 0; h < 2; ++h) v[r][i][h] = xr[(lane + 64 * i) * 2 + h];
   }
-  const float4* sc = reinterpret_cast<const float4*>(base + scale_off);
-  const float4* sh = reinterpret_cast<const float4*>(base + shift_off);
   float4 a[PER][2], b[PER][2];
+  ln_load_vec(base + scale_off, lane, a);
+  ln_load_vec(base + shift_off, lane, b);
 #pragma unroll
-  for (int i = 0; i < PER; ++i)
-#pragma unroll
-    for (int h = 0; h < 2; ++h) { a[i][h] = sc[(lane + 64 * i) * 2 + h]; b[i][h] = sh[(lane + 64 * i) * 2 + h]; }
-#pragma unroll
-  for (int r = 0; r < ROWS; ++r) {
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < PER; ++i)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) s += v[r][i][h].x + v[r][i][h].y + v[r][i][h].z + v[r][i][h].w;
-    const float mean = wave_sum(s) * (1.0f / D);
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < PER; ++i)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const float c0 = v[r][i][h].x - mean, c1 = v[r][i][h].y - mean, c2 = v[r][i][h].z - mean, c3 = v[r][i][h].w - mean;
-        q += c0 * c0 + c1 * c1 + c2 * c2 + c3 * c3;
-      }
-    const float rstd = rsqrtf(wave_sum(q) * (1.0f / D) + 1e-6f);
-    if (row0 + r < M) {
-      bf16_t* orow = out + (size_t)(row0 + r) * D;
-#pragma unroll
-      for (int i = 0; i < PER; ++i) {
-        bf16x8 o;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          o[4 * h + 0] = (bf16_t)((v[r][i][h].x - mean) * rstd * (1.0f + a[i][h].x) + b[i][h].x);
-          o[4 * h + 1] = (bf16_t)((v[r][i][h].y - mean) * rstd * (1.0f + a[i][h].y) + b[i][h].y);
-          o[4 * h + 2] = (bf16_t)((v[r][i][h].z - mean) * rstd * (1.0f + a[i][h].z) + b[i][h].z);
-          o[4 * h + 3] = (bf16_t)((v[r][i][h].w - mean) * rstd * (1.0f + a[i][h].w) + b[i][h].w);
-        }
-        store_wt_b128(orow + (lane + 64 * i) * 8, __builtin_bit_cast(u32x4, o));
-      }
-    }
-  }
+  for (int r = 0; r < ROWS; ++r) ln_row_store(v[r], a, b, out + (size_t)(row0 + r) * D, lane, row0 + r < M);
 }
 
 // Same row pass, written as MXFP8 for the fp8 GEMMs: e4m3 bytes + one E8M0 scale per 32 columns.  A 32-column block is

@@ -108,6 +108,10 @@ class DiTEngine(_Streamed):
     def set_option(self, key: str, value: int):
         _lib.check(_lib.lib().lemas_dit_set_option(self._h, key.encode(), int(value)), f"set_option({key})")
 
+    def check_health(self):
+        """Synchronise and raise if a device-side wait of this engine gave up (results since then would be invalid)."""
+        _lib.check(_lib.lib().lemas_dit_health(self._h), "lemas_dit_health")
+
     # ------------------------------------------------------------------------------------------
     def _args(self, cond, cond_mask, text, seq_len, prosody, t_grid, cfg_strength, cond_frames, y, out, traj, step_cond=None):
         B, N, _ = cond.shape

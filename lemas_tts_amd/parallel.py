@@ -88,3 +88,41 @@ def run_sharded(utterances: Sequence, lengths: Sequence[int], fn, dist) -> Optio
         for i, r in part:
             out[i] = r
     return out
+
+
+def gpu_numa_cpus(device_index: int):
+    """(numa_node, cpu list) of the host NUMA node GPU ``device_index`` hangs off, from sysfs
+    (``/sys/bus/pci/devices/<bdf>/{numa_node,local_cpulist}``); (None, None) when the platform does not say."""
+    import os
+    try:
+        p = torch.cuda.get_device_properties(device_index)
+        bdf = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        base = f"/sys/bus/pci/devices/{bdf}"
+        node = int(open(os.path.join(base, "numa_node")).read().strip())
+        cpus = []
+        for part in open(os.path.join(base, "local_cpulist")).read().strip().split(","):
+            if not part:
+                continue
+            lo, _, hi = part.partition("-")
+            cpus.extend(range(int(lo), int(hi or lo) + 1))
+        return (node if node >= 0 else None), (cpus or None)
+    except (OSError, ValueError, AttributeError, RuntimeError, AssertionError):
+        return None, None
+
+
+def pin_to_gpu_numa_node(device_index: int):
+    """One process per GPU: keep this rank's host threads (launch path, pinned-buffer copies) on the cores of the GPU's own NUMA
+    node, intersected with what the process may use.  Returns a small record for the report, or None when nothing was done."""
+    import os
+    node, cpus = gpu_numa_cpus(device_index)
+    if not cpus or not hasattr(os, "sched_setaffinity"):
+        return None
+    allowed = os.sched_getaffinity(0)
+    want = sorted(allowed.intersection(cpus))
+    if not want:
+        return None
+    try:
+        os.sched_setaffinity(0, want)
+    except OSError:
+        return None
+    return {"numa_node": node, "cpus": len(want), "first_cpu": want[0], "last_cpu": want[-1]}

@@ -3,6 +3,7 @@ to run without a HIP device (no CPU fallback)."""
 import ctypes as C
 import os
 import re
+import subprocess
 
 import pytest
 import torch
@@ -12,18 +13,28 @@ from lemas_tts_amd import _lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _declared(header):
+    return set(re.findall(r"\b(lemas_[a-z0-9_]+)\s*\(", open(os.path.join(ROOT, "include", header)).read()))
+
+
 def test_header_symbols_are_exported():
-    declared = set()
-    for h in sorted(os.listdir(os.path.join(ROOT, "include"))):
-        if h.endswith(".h"):
-            declared |= set(re.findall(r"\b(lemas_[a-z0-9_]+)\s*\(", open(os.path.join(ROOT, "include", h)).read()))
-    assert {"lemas_dit_sample", "lemas_vocos_decode", "lemas_k_gemm_epi"} <= declared, "declarations not parsed"
-    product = set(re.findall(r"\b(lemas_[a-z0-9_]+)\s*\(", open(os.path.join(ROOT, "include", "lemas_hip.h")).read()))
+    """include/lemas_hip.h is the product library's surface, include/lemas_hip_test.h the test library's; neither library exports
+    the other's entry points (no lemas_k_* -- and no process-global dispatch switch -- in the product)."""
+    product, tests = _declared("lemas_hip.h"), _declared("lemas_hip_test.h")
+    assert {"lemas_dit_sample", "lemas_vocos_decode", "lemas_dit_health"} <= product and "lemas_k_gemm_epi" in tests, "declarations not parsed"
     assert not any(n.startswith("lemas_k_") for n in product), "test entry points belong in lemas_hip_test.h"
-    L = _lib.lib()
-    for name in sorted(declared):
-        assert hasattr(L, name), f"{name} declared in include/*.h but not exported"
-    assert set(_lib.EXPORTED) == declared, (set(_lib.EXPORTED) ^ declared)
+    assert all(n.startswith("lemas_k_") for n in tests)
+    P = C.CDLL(_lib.LIB_PATH)
+    _lib.lib()
+    T = C.CDLL(_lib.TEST_LIB_PATH)
+    for name in sorted(product):
+        assert hasattr(P, name), f"{name} declared in lemas_hip.h but not exported by liblemas_hip.so"
+    for name in sorted(tests):
+        assert hasattr(T, name), f"{name} declared in lemas_hip_test.h but not exported by liblemas_hip_test.so"
+    exported = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "lemas_k_" not in exported and "force_tiles" not in exported, "the product library must not carry test hooks"
+    assert set(_lib.EXPORTED) == product, (set(_lib.EXPORTED) ^ product)
+    assert set(_lib.EXPORTED_TEST) == tests, (set(_lib.EXPORTED_TEST) ^ tests)
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="only meaningful on a box without a GPU")
@@ -51,6 +62,6 @@ def test_product_does_not_import_oracle():
 
 def test_measurement_hooks_are_compiled_out_of_the_product_build():
     """the in-situ timeline (tools/timeline_step.sh) exists only in a -DLEMAS_PHASE_TIMESTAMPS build: the in-tree library refuses it"""
-    L = _lib.lib()
+    L = _lib.testlib()
     assert L.lemas_k_timeline(None, 0) != 0
     assert b"not a measurement build" in L.lemas_last_error()

@@ -125,6 +125,28 @@ def test_dual_lane_is_bit_identical_to_single_lane(golden_dir, name):
         np.testing.assert_array_equal(v, ref, err_msg=str(k))
 
 
+@pytest.mark.parametrize("name", ["mini_plain", "mini_batch", "full_plain"])
+def test_fused_layernorm_tail_is_bit_identical_to_separate_launches(golden_dir, name):
+    """Option ln_fused: the AdaLN LayerNorms behind the gated residual updates as the tail of the out-projection / FF2 launches
+    (gemm_bf16.hip ln_tail) -- the same row arithmetic as the stand-alone kernel (csrc/ln_core.h), so not a bit may change, with one
+    lane or two, eager or replayed."""
+    fx, arch, sd = _load(golden_dir, name)
+    m = _model(arch, int(fx["vocab"]), int(fx["wseed"]), bool(fx["prosody"]), sd)
+    outs = {}
+    for ln in (0, 1):
+        m.engine.set_option("ln_fused", ln)
+        for dual in (0, 1):
+            m.engine.set_option("dual", dual)
+            for graph in (False, True):
+                outs[(ln, dual, graph)] = _run_case(fx, arch, sd, graph=graph, traj=False)[0]
+    m.engine.set_option("dual", 1)
+    m.engine.set_option("ln_fused", 1)
+    m.engine.check_health()
+    ref = outs[(0, 0, False)]
+    for k, v in outs.items():
+        np.testing.assert_array_equal(v, ref, err_msg=str(k))
+
+
 def test_dit_forward_vs_oracle(golden_dir):
     """One DiT forward (both CFG branches) against the fp32 oracle: localises step-loop errors."""
     from oracle import lemas_oracle as O

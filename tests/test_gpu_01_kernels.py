@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 def _lib():
     from lemas_tts_amd import _lib as L
-    return L, L.lib()
+    return L, L.testlib()
 
 
 def _dev(t):
@@ -263,6 +263,83 @@ def test_gemm_production_choice_matches_explicit_tiles():
     """tile 0 (the dispatch heuristic) must give the same numbers as the tile it picks: bit-identical to one of them"""
     _gemm_epi_case(0, EPI_GELU, 8, 1900, 2048, 1024, seed=7)
     _gemm_epi_case(0, EPI_GATE, 1, 375, 1024, 1024, seed=8)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The gate + residual GEMM with its LayerNorm-modulate tail (gemm_bf16.hip ln_tail): x must equal the plain epilogue-3 launch bit for
+# bit, h must equal the stand-alone ln_mod kernel run on that x bit for bit (same row arithmetic, ln_core.h), and both must match fp32
+# torch.  `concurrent` copies run at once on separate streams (the two CFG lanes) and must agree with each other.
+def _gate_ln_case(tile, batch, frames, K, seed, concurrent=1, ragged=False):
+    L, lib = _lib()
+    dev = "cuda:0"
+    N = 1024
+    pitch = (frames + 127) // 128 * 128
+    M = batch * pitch
+    g = torch.Generator(device=dev).manual_seed(seed)
+    A = torch.randn(M, K, generator=g, device=dev)
+    W = torch.randn(N, K, generator=g, device=dev) * 0.05
+    bias = torch.randn(N, generator=g, device=dev)
+    gate = torch.randn(N, generator=g, device=dev)
+    sc, sh = torch.randn(N, generator=g, device=dev) * 0.3, torch.randn(N, generator=g, device=dev) * 0.3
+    x0 = torch.randn(M, N, generator=g, device=dev) * 2 + 0.25
+    lens_d = None
+    if ragged:
+        lens_d = torch.randint(1, frames + 1, (batch,), generator=g, device=dev, dtype=torch.int32)
+        lens_d[-1] = frames
+    lp = lens_d.data_ptr() if lens_d is not None else None
+    # (a) the fused launch
+    x, h = x0.clone(), torch.zeros(M, N, device=dev)
+    L.check(lib.lemas_k_gemm_gate_ln(tile, A.data_ptr(), W.data_ptr(), bias.data_ptr(), gate.data_ptr(), sc.data_ptr(), sh.data_ptr(), lp,
+                                     x.data_ptr(), h.data_ptr(), batch, pitch, frames, K, concurrent, None), f"gate_ln tile {tile}")
+    # (b) the same tile without the tail, then the stand-alone LayerNorm kernel on its result
+    x2, h2 = x0.clone(), torch.zeros(M, N, device=dev)
+    L.check(lib.lemas_k_gemm_epi(EPI_GATE, tile, A.data_ptr(), W.data_ptr(), bias.data_ptr(), gate.data_ptr(), lp, x2.data_ptr(),
+                                 batch, pitch, frames, N, K, None))
+    L.check(lib.lemas_k_ln_mod(x2.data_ptr(), sc.data_ptr(), sh.data_ptr(), h2.data_ptr(), M, N, None))
+    assert torch.equal(x, x2), (tile, float((x - x2).abs().max()))
+    assert torch.equal(h, h2), (tile, float((h - h2).abs().max()), int((h != h2).any(dim=1).sum()))
+    # (c) fp32 torch on the bf16-rounded operands
+    acc = (_bf(A).double() @ _bf(W).double().T).float() + bias
+    pos, sample = torch.arange(M, device=dev) % pitch, torch.arange(M, device=dev) // pitch
+    live = pos < frames
+    if lens_d is not None:
+        live = live & (pos < lens_d[sample])
+    xr = torch.where(live[:, None], x0 + gate * acc, x0)
+    assert float((x - xr).abs().max()) < 4e-3 * math.sqrt(K / 64)
+    hr = torch.nn.functional.layer_norm(x, (N,), eps=1e-6) * (1 + sc) + sh       # on the kernel's own x: isolates the tail
+    assert float(((h - _bf(hr)).abs() / hr.abs().clamp(min=1.0)).max()) < 1.01 / 128
+
+
+@pytest.mark.parametrize("tile", [17, 18, 19, 26])
+@pytest.mark.parametrize("K", [1024, 2048])
+def test_gemm_gate_with_layernorm_tail_every_tile(tile, K):
+    """one CFG lane of configs[1] (1875 frames in a 1920-row pitch): out-projection (K = 1024) and FF2 (K = 2048)"""
+    _gate_ln_case(tile, 1, 1875, K, seed=tile * 7 + K)
+
+
+@pytest.mark.parametrize("tile,batch,frames", [(17, 1, 1875), (19, 1, 750), (18, 1, 750), (17, 2, 900)])
+def test_gemm_gate_with_layernorm_tail_two_concurrent_lanes(tile, batch, frames):
+    """two launches at once on two streams, as the CFG lanes run them: each waits only for its own panels; identical results"""
+    _gate_ln_case(tile, batch, frames, 2048, seed=tile + frames, concurrent=2, ragged=batch > 1)
+
+
+def test_gemm_gate_with_layernorm_tail_repeated_under_load():
+    """the tail's hand-off (write-through stores, drained, one arrival per workgroup, relaxed poll, L1-bypassing loads) repeated with
+    fresh data while a second pair of launches keeps the chip busy: a stale row would show as a bit difference against the
+    stand-alone kernel"""
+    for it in range(12):
+        _gate_ln_case(17, 1, 1875, 1024 if it % 2 else 2048, seed=1000 + it, concurrent=2 + (it % 2))
+
+
+def test_gemm_gate_layernorm_tail_refuses_tiles_without_it():
+    L, lib = _lib()
+    dev = "cuda:0"
+    z = torch.zeros(256 * 1024, device=dev)
+    v = torch.zeros(1024, device=dev)
+    for tile in (16, 22):
+        rc = lib.lemas_k_gemm_gate_ln(tile, z.data_ptr(), z.data_ptr(), v.data_ptr(), v.data_ptr(), v.data_ptr(), v.data_ptr(), None,
+                                      z.data_ptr(), z.data_ptr(), 1, 256, 256, 1024, 1, None)
+        assert rc != 0, tile
 
 
 @pytest.mark.parametrize("B,H,N", [(8, 16, 1900), (16, 16, 1875), (3, 16, 2814)])

@@ -17,7 +17,7 @@ DEV = "cuda:0"
 
 def _lib():
     from lemas_tts_amd import _lib as L
-    return L, L.lib()
+    return L, L.testlib()
 
 
 def _dev(t):

@@ -4,7 +4,8 @@
 
     python tools/e2e_ab.py --workload configs1 --arms default n1024=18 n1024=18,qkv_fused=0 [--rounds 3] [--steps 6]
 
-Arm syntax: comma-separated key=value with keys n1024 / n2048 / gx (GEMM tile ids and XCD block grid, lemas_k_tile_override), qkv_fused, dual, fp8."""
+Arm syntax: comma-separated key=value with keys n1024 / n2048 / qkv / gx (GEMM tile ids and XCD block grid: the engine's per-engine
+measurement options tile_n1024 / tile_n2048 / tile_qkv / xcd_gx), qkv_fused, dual, fp8, ln_fused, overlap (vocoder on a side stream)."""
 import argparse
 import os
 import sys
@@ -14,7 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 import bench as Bn  # noqa: E402
-from lemas_tts_amd import _lib, synth  # noqa: E402
+from lemas_tts_amd import synth  # noqa: E402
 from lemas_tts_amd.engine import VocosEngine  # noqa: E402
 from lemas_tts_amd.model.cfm import CFM  # noqa: E402
 from lemas_tts_amd.model.layout import DiTArch  # noqa: E402
@@ -37,7 +38,6 @@ def main():
     sd = synth.synth_cfm_state_dict(arch, Bn.VOCAB, 1234)
     vocoder = VocosEngine(synth.synth_vocos_state_dict(1234), device=dev)
     cond, text, y0, _ = Bn.build_inputs(w, 1, dev)
-    L = _lib.lib()
     host = torch.empty((B, Bn.HOP * (N - F)), dtype=torch.float32).pin_memory()
     # ONE engine for every arm: separate engines differ by up to 3 % among IDENTICAL arms (buffer placement / graph instance; measured with
     # four equal arms), which is more than most of the effects this tool is asked about.  Switching arms re-captures the graphs.
@@ -47,30 +47,46 @@ def main():
 
     def select(arm):
         opts = parsed[arm]
-        L.lemas_k_tile_override(int(opts.get("n1024", 0)), int(opts.get("n2048", 0)), int(opts.get("gx", 0)))
+        m.engine.set_option("tile_n1024", int(opts.get("n1024", 0)))
+        m.engine.set_option("tile_n2048", int(opts.get("n2048", 0)))
+        m.engine.set_option("tile_qkv", int(opts.get("qkv", 0)))
+        m.engine.set_option("xcd_gx", int(opts.get("gx", 0)))
+        m.engine.set_option("ln_fused", int(opts.get("ln_fused", 1)))
         m.engine.set_option("fp8", int(opts.get("fp8", 0)))
         m.engine.set_option("qkv_fused", int(opts.get("qkv_fused", 1)))
         m.engine.set_option("dual", int(opts.get("dual", 1)))          # drops the cached graphs: the next sample captures under this arm's choices
 
-    def run(n):
+    side = torch.cuda.Stream(dev)
+    text_h = text.cpu().pin_memory()
+
+    def run(n, overlap):
         for _ in range(n):
-            out, _ = m.sample(cond, text, N, steps=Bn.NFE, cfg_strength=Bn.CFG, sway_sampling_coef=Bn.SWAY, y0=y0, use_acc_grl=False)
-            host.copy_(vocoder.decode(out[:, F - 1:, :].permute(0, 2, 1)), non_blocking=True)
+            out, _ = m.sample(cond, text_h, N, steps=Bn.NFE, cfg_strength=Bn.CFG, sway_sampling_coef=Bn.SWAY, y0=y0, use_acc_grl=False)
+            if overlap:                       # bench.py --overlap 1: decode + D2H under the next utterance's step loop
+                done = torch.cuda.Event()
+                done.record()
+                with torch.cuda.stream(side):
+                    side.wait_event(done)
+                    out.record_stream(side)
+                    host.copy_(vocoder.decode(out[:, F - 1:, :].permute(0, 2, 1)), non_blocking=True)
+            else:
+                host.copy_(vocoder.decode(out[:, F - 1:, :].permute(0, 2, 1)), non_blocking=True)
         torch.cuda.synchronize()
 
     res = {arm: [] for arm in a.arms}
     for r in range(a.rounds):
         for arm in a.arms:
             select(arm)
-            run(2)                                   # capture + warm
+            ov = int(parsed[arm].get("overlap", 1))
+            run(2, ov)                               # capture + warm
             t0 = time.perf_counter()
-            run(a.steps)
+            run(a.steps, ov)
             res[arm].append((time.perf_counter() - t0) / a.steps)
     audio = B * Bn.HOP * (N - F) / Bn.SR
     for arm in a.arms:
         best, med = min(res[arm]), sorted(res[arm])[len(res[arm]) // 2]
         print(f"{a.workload:9s} {arm:28s} median {1e3 * med:8.2f} ms = {audio / med:7.1f} audio-s/s   best {1e3 * best:8.2f} ms = {audio / best:7.1f}")
-    L.lemas_k_tile_override(0, 0, 0)
+    m.engine.check_health()
 
 
 if __name__ == "__main__":

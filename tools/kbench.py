@@ -41,7 +41,7 @@ def main():
     o.add_argument("tile", type=int, nargs="?", default=0)
     o.add_argument("--iters", type=int, default=20)
     args = ap.parse_args()
-    L = _lib.lib()
+    L = _lib.testlib()
     if args.cmd == "gemm":
         for M in args.M:
             print(f"M={M}; columns = tiles {args.tiles}; cells = us (TFLOP/s)")
@@ -59,7 +59,7 @@ def main():
     else:
         us = bench(L, args.what, args.M, args.N, args.K, args.iters, args.tile)
         if us is None:
-            raise SystemExit(_lib.lib().lemas_last_error().decode())
+            raise SystemExit(_lib.testlib().lemas_last_error().decode())
         print(f"{args.what} M={args.M} N={args.N} K={args.K} tile={args.tile}: {us:.2f} us")
 
 

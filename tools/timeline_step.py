@@ -38,7 +38,7 @@ def main():
     arch = DiTArch()
     sd = synth.synth_cfm_state_dict(arch, Bn.VOCAB, 1234)
     cond, text, y0, _ = Bn.build_inputs(w, 1, dev)
-    L = _lib.lib()
+    L = _lib.testlib()
     pitch = (N + 127) // 128 * 128
     if ((B * pitch + 255) // 256) * (3 * 1024 // 128) > 250:
         NAMES = NAMES_UNFUSED
