@@ -103,10 +103,11 @@ int lemas_dit_finalize(lemas_dit* m);
  *        takes effect at the next prepare()/sample()),
  * "ln_fused" (1 = the AdaLN LayerNorms that follow the gated residual updates (modules.py:637, the next block's :314, the final
  *        :335) run as the tail of the out-projection / FF2 launches whenever all workgroups of those launches fit the chip at
- *        once, default 1; 0 = always separate launches),
+ *        once; default 0 = separate ln_mod launches: the fused form measured slower),
  * measurement options (0 = the production choice; each drops the cached graphs): "tile_n1024", "tile_n2048", "tile_qkv" = explicit
  *        GEMM tile ids (include/lemas_hip_test.h) for the block GEMMs of that width / the fused QK+V launch, "xcd_gx" = XCD block
- *        grid of the tile order (8, 4, 2, 1).  Per engine: there is no process-global dispatch switch. */
+ *        grid of the tile order (8, 4, 2, 1), "attn_variant" = schedule variant of the attention kernel (csrc/attention.hip; default
+ *        19, 0 = classical online softmax).  Per engine: there is no process-global dispatch switch. */
 int lemas_dit_set_option(lemas_dit* m, const char* key, int64_t value);
 /* synchronises the device and returns 0, or LEMAS_E_STATE when a device-side wait of this engine gave up (fused LayerNorm tail):
  * every result since then is invalid and prepare() / solve() refuse to run */

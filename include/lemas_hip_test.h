@@ -36,6 +36,9 @@ int lemas_k_linear_f8(const float* A, const float* W, const float* bias, float* 
 /* q,k,v [B,H,N,64] (already rotated) -> out [B,N,H*64]; seq_len device int32 [B] or NULL (modules.py:483-491) */
 int lemas_k_attention(const float* q, const float* k, const float* v, const int32_t* seq_len, float* out, int32_t B,
                       int32_t H, int32_t N, void* stream);
+/* the same through schedule variant `variant` of the attention kernel (csrc/attention.hip; 0 = lemas_k_attention) */
+int lemas_k_attention_variant(const float* q, const float* k, const float* v, const int32_t* seq_len, float* out, int32_t B,
+                              int32_t H, int32_t N, int32_t variant, void* stream);
 /* out = LayerNorm(x; eps 1e-6) * (1 + scale) + shift, rows of 1024; result rounded to bf16 then widened */
 int lemas_k_ln_mod(const float* x, const float* scale, const float* shift, float* out, int32_t M, int32_t D, void* stream);
 /* out = conv_pos_embed(x) + x for x [B,N,C]; w1,w2 [C, C/groups, taps], b1,b2 [C] */

@@ -128,6 +128,7 @@ def testlib():
         "lemas_k_linear_bf16": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
         "lemas_k_linear_f32": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
         "lemas_k_attention": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+        "lemas_k_attention_variant": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
         "lemas_k_mx_quant": (C.c_int, [vp, i32, i32, vp, vp, vp]),
         "lemas_k_w_quant_f8": (C.c_int, [vp, i32, i32, vp, vp, vp]),
         "lemas_k_ln_mod_f8": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, vp]),
@@ -154,7 +155,7 @@ EXPORTED = [      # include/lemas_hip.h: the product library
     "lemas_prosody_fbank", "lemas_prosody_encode",
 ]
 EXPORTED_TEST = [  # include/lemas_hip_test.h: the test library
-    "lemas_k_linear_bf16", "lemas_k_linear_f32", "lemas_k_attention", "lemas_k_ln_mod", "lemas_k_convpos", "lemas_k_bench", "lemas_k_gemm_epi",
+    "lemas_k_linear_bf16", "lemas_k_linear_f32", "lemas_k_attention", "lemas_k_attention_variant", "lemas_k_ln_mod", "lemas_k_convpos", "lemas_k_bench", "lemas_k_gemm_epi",
     "lemas_k_gemm_gate_ln", "lemas_k_timeline", "lemas_k_mx_quant", "lemas_k_w_quant_f8", "lemas_k_ln_mod_f8", "lemas_k_linear_f8",
 ]
 

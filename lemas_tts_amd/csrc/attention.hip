@@ -81,8 +81,26 @@ __device__ __forceinline__ void wait_lgkm_frags(u32x4& a, u32x4& b) {
 // Ring: 2 stages of [K0 | V0^T | K1 | V1^T] (32 KiB each), one barrier per tile pair.
 constexpr int STAGE2 = 4 * TILE;
 
-__global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_fwd_splitkv_kernel(const AttnParams p) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE2];
+// VAR (bit mask), variants kept selectable for A/B measurements (AttnParams::variant; 0 = the original schedule):
+//   1  max-free softmax: a wave's FIRST tile goes the classical way and fixes the running max m of each query; every later tile is
+//      P = exp2(s c - m) with no max tree, no cross-half exchange, no deferral logic and no rescale of l and O (fp32 and bf16 keep
+//      their RELATIVE precision at any magnitude, so P = 2^40 is as exact as P = 1 after the division by l; scores far below m
+//      underflow to the zero weight they deserve).  What can go wrong is overflow -- a score more than ~127 octaves (88 nats) above
+//      the first tile's maximum, or P.V beyond 3.4e38 -- and it cannot go unnoticed: l or O is then inf / NaN.  The workgroup
+//      checks that once, after its key loop, and if any wave saw it the whole workgroup runs the loop again classically.  (A
+//      per-tile guard on the row sum was measured first: correct, but the branch sits between the exponentials and the P.V MFMAs
+//      and stops the compiler from overlapping them -- no faster than the classical kernel.)
+//  16  (with 1) NO running max at all: the caller hands q already multiplied by scale * log2(e) (the QK GEMM epilogue does it in
+//      fp32 before the bf16 rounding, GemmParams::q_scale) and P = exp2(S) is taken as it comes out of the MFMA -- softmax is
+//      invariant to the per-query offset, so the offset only ever served the number range.  The range is checked once per workgroup
+//      on the merged rows: l and O finite and l >= 2^-90 (a row whose largest weight sits near the bottom of the fp32 range would
+//      lose its small weights to underflow); otherwise the workgroup runs the loop again classically.  |logit| < ~60 nats never
+//      trips it.  Per tile this leaves 32 v_exp + 16 v_cvt_pk + the row-sum adds: no multiply-add, no max tree, no exchange.
+//   2  static priority for the younger half of the workgroup (waves 4-7), no per-cluster flips
+//   4  s_setprio 1 around the MFMA clusters
+template <int VAR>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_fwd_splitkv_kernel(const AttnParams p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE2 + 64];   // ring + 8 per-wave flags (VAR & 1)
   ATTN_STAMP(0);
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
 
@@ -97,7 +115,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(4, 4))) 
   const int N = p.n;
   const int kvlen = p.kv_len ? p.kv_len[b2 % p.batch] : N;
   const int ntiles = (kvlen + KB - 1) / KB, nsup = (ntiles + 1) >> 1;
-  const float c = p.scale * 1.4426950408889634f;
+  const float c = (VAR & 16) != 0 ? 1.0f : p.scale * 1.4426950408889634f;    // VAR & 16: q arrives prescaled
   const char* kg = reinterpret_cast<const char*>(p.k + (size_t)bh * p.pitch * 64);
   const char* vg = reinterpret_cast<const char*>(p.vt + (size_t)bh * 64 * p.npad);
   const int q_base = qblk * QB + wq * 32;
@@ -110,7 +128,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     koff = (unsigned)((r * 64 + cc) * 2);
     voff = (unsigned)((r * p.npad + cc) * 2);
   }
-  auto issue = [&](int stage, int i) {
+  auto issue = [&](int stage, int i) __attribute__((always_inline)) {
     char* base = smem + stage * STAGE2 + wave * 1024;
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
@@ -142,23 +160,34 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(4, 4))) 
 #pragma unroll
   for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
   float m_run = -INFINITY, l_run = 0.f;
+  if constexpr ((VAR & 2) != 0) { if (wave >= 4) __builtin_amdgcn_s_setprio(1); }
+  auto prio_rest = [&]() __attribute__((always_inline)) {     // priority outside the MFMA clusters (s_setprio takes an immediate)
+    if ((VAR & 2) != 0 && wave >= 4) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+  };
 
   // the ring stage is a compile-time constant inside `pair` (the loop below is unrolled by the ring depth), so every
   // LDS address is base register + immediate
-  auto pair = [&](int i, auto stage_c) {
-    constexpr int SG = decltype(stage_c)::value;
+  // One pair of the ring = sync (the pair's DMA has landed for every wave; the next pair is requested) + compute (this wave's tile).
+  auto sync = [&](int i, int sg) __attribute__((always_inline)) {
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
-    if (i + 1 < nsup) issue(SG ^ 1, i + 1);
+    if (i + 1 < nsup) issue(sg ^ 1, i + 1);
+  };
+  // sg_c: ring stage, an integral_constant inside the unrolled loops (every LDS address is then base register + immediate) or a
+  // plain int.  fast_c: true = max-free softmax against the running max the wave's first tile fixed (see VAR & 1).
+  auto compute = [&](int i, auto sg_c, auto fast_c) __attribute__((always_inline)) -> bool {
+    const int SG = sg_c;
+    constexpr bool FAST = decltype(fast_c)::value;
     const int j = 2 * i + grp;
-    if (j < ntiles) {
-      // K fragment schedule (2 x ds_read_b128 per k-step, double-buffered in fk[2][2]): the reads of step kk+1 are in flight
-      // under the MFMAs of step kk.  Left to the compiler every step was read -> s_waitcnt lgkmcnt(0) -> MFMA.
-      const unsigned sKa = lds_base + SG * STAGE2 + grp * 2 * TILE;
+    if (j >= ntiles) return true;
+    const unsigned ka = lds_base + SG * STAGE2 + grp * 2 * TILE + kx0;
+    f32x16 s[2];
+    {
+      // S^T = K . Q^T of this tile.  K fragment schedule (2 x ds_read_b128 per k-step, double-buffered in fk[2][2]): the reads of step
+      // kk+1 are in flight under the MFMAs of step kk.  Left to the compiler every step was read -> s_waitcnt lgkmcnt(0) -> MFMA.
       u32x4 fk[2][2];
-      f32x16 s[2];
       const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      const unsigned ka = sKa + kx0;
       lds_read_kstep<0>(fk[0][0], fk[0][1], ka);
       lds_read_kstep<32>(fk[1][0], fk[1][1], ka);
 #pragma unroll
@@ -166,9 +195,11 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         u32x4 (&f)[2] = fk[kk & 1];
         if (kk < 3) wait_lgkm_frags<2>(f[0], f[1]);      // the two youngest outstanding reads are the next step's
         else wait_lgkm_frags<0>(f[0], f[1]);
+        if constexpr ((VAR & 4) != 0) { if (kk == 0) __builtin_amdgcn_s_setprio(1); }
 #pragma unroll
         for (int t = 0; t < 2; ++t)   // first k-step accumulates onto the inline constant 0: no register zeroing
           s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f[t]), qf[kk], kk == 0 ? zero : s[t], 0, 0, 0);
+        if constexpr ((VAR & 4) != 0) { if (kk == 3) prio_rest(); }
         if (kk == 0) lds_read_kstep<64>(f[0], f[1], ka);
         if (kk == 1) lds_read_kstep<96>(f[0], f[1], ka);
         __builtin_amdgcn_sched_barrier(0);   // keep wait -> MFMAs -> refill in this order (sinking the MFMAs costs a third buffer)
@@ -185,6 +216,44 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             if (key >= kvlen) s[t][r] = -INFINITY;
           }
       }
+    }
+    const f32x2 c2 = {c, c};
+    bf16x8 pb[2][2];
+    // P = exp2(s c - m) as bf16 B-operand fragments; returns this lane's partial row sum (the other 32 keys sit in lane ^ 32)
+    auto exps = [&](float m) __attribute__((always_inline)) -> float {
+      const f32x2 m2 = {m, m};
+      f32x2 ps = {0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          f32x2 e = {s[t][r], s[t][r + 1]};
+          e = e * c2 - m2;
+          f32x2 pv = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+          ps += pv;
+          pb[t][r >> 3][r & 7] = (bf16_t)pv[0];
+          pb[t][r >> 3][(r & 7) + 1] = (bf16_t)pv[1];
+        }
+      return ps[0] + ps[1];
+    };
+    if constexpr ((VAR & 8) != 0) {         // ABLATION ONLY (wrong on large scores): no running max at all
+      l_run += exps(0.f);
+      m_run = 0.f;
+    } else if constexpr (FAST && (VAR & 16) != 0) {
+      f32x2 ps = {0.f, 0.f};                // P = exp2(S): see VAR & 16
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          f32x2 pv = {__builtin_amdgcn_exp2f(s[t][r]), __builtin_amdgcn_exp2f(s[t][r + 1])};
+          ps += pv;
+          pb[t][r >> 3][r & 7] = (bf16_t)pv[0];
+          pb[t][r >> 3][(r & 7) + 1] = (bf16_t)pv[1];
+        }
+      l_run += ps[0] + ps[1];
+    } else if constexpr (FAST) {
+      l_run += exps(m_run);
+    } else {
       float mx = s[0][0];
 #pragma unroll
       for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
@@ -201,68 +270,118 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(4, 4))) 
       const float alpha = defer ? 1.0f : __builtin_amdgcn_exp2f(m_run - m_new);
       const bool grew = m_new > m_run;
       m_run = m_new;
-      const f32x2 c2 = {c, c}, m2 = {m_new, m_new};
-      f32x2 ps = {0.f, 0.f};
-      bf16x8 pb[2][2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          f32x2 e = {s[t][r], s[t][r + 1]};
-          e = e * c2 - m2;
-          f32x2 pv = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
-          ps += pv;
-          pb[t][r >> 3][r & 7] = (bf16_t)pv[0];
-          pb[t][r >> 3][(r & 7) + 1] = (bf16_t)pv[1];
-        }
-      l_run = l_run * alpha + (ps[0] + ps[1]);
+      l_run = l_run * alpha + exps(m_new);
       if (__any(grew)) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
       }
-      // P.V keeps the compiler's schedule (single-buffered V^T fragments, softmax tail interleaved with the MFMAs): a second
-      // fragment buffer here lifts the kernel to 138 VGPRs and costs the fourth wave per SIMD (measured 51.8 vs 45.7 us)
-      const char* sV = smem + SG * STAGE2 + grp * 2 * TILE + TILE;
+    }
+    // P.V keeps the compiler's schedule (single-buffered V^T fragments, softmax tail interleaved with the MFMAs): a second
+    // fragment buffer here lifts the kernel to 138 VGPRs and costs the fourth wave per SIMD (measured 51.8 vs 45.7 us)
+    const char* sV = smem + SG * STAGE2 + grp * 2 * TILE + TILE;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        bf16x8 a[2];
+    for (int e = 0; e < 4; ++e) {
+      bf16x8 a[2];
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) a[dt] = *reinterpret_cast<const bf16x8*>(sV + dt * 4096 + vx[e]);
+      for (int dt = 0; dt < 2; ++dt) a[dt] = *reinterpret_cast<const bf16x8*>(sV + dt * 4096 + vx[e]);
+      if constexpr ((VAR & 4) != 0) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[dt], pb[e >> 1][e & 1], o[dt], 0, 0, 0);
+      for (int dt = 0; dt < 2; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[dt], pb[e >> 1][e & 1], o[dt], 0, 0, 0);
+      if constexpr ((VAR & 4) != 0) prio_rest();
+    }
+    return true;
+  };
+  using c0_t = std::integral_constant<int, 0>;
+  using c1_t = std::integral_constant<int, 1>;
+  ATTN_STAMP(1);
+  // the key loop: pairs of tiles through the 2-stage ring, unrolled by the ring depth.  first_fast_c / later_fast_c: the wave's first
+  // tile / every later one on the max-free path
+  auto key_loop = [&](auto first_fast_c, auto later_fast_c) __attribute__((always_inline)) {
+    issue(0, 0);
+    sync(0, 0);
+    compute(0, c0_t{}, first_fast_c);
+    for (int i = 1; i < nsup; i += 2) {
+      sync(i, 1);
+      compute(i, c1_t{}, later_fast_c);
+      if (i + 1 < nsup) { sync(i + 1, 0); compute(i + 1, c0_t{}, later_fast_c); }
+    }
+    __syncthreads();                                   // every wave is done with the ring
+  };
+  // merge the two key-parity partials: group 1 parks (m, l, O^T) in LDS, group 0 folds it in
+  float* xch = reinterpret_cast<float*>(smem) + (size_t)wq * 64 * 36 + lane * 36;   // 34 floats used per lane, 36 pitch
+  auto merge = [&]() __attribute__((always_inline)) {
+    if (grp == 1) {
+      xch[0] = m_run;
+      xch[1] = l_run;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { xch[2 + r] = o[0][r]; xch[18 + r] = o[1][r]; }
+    }
+    __syncthreads();
+    if (grp == 0) {
+      const float m2 = xch[0], l2 = xch[1];
+      const float m = fmaxf(m_run, m2);
+      const float a1 = __builtin_amdgcn_exp2f(m_run - m), a2 = __builtin_amdgcn_exp2f(m2 - m);   // m2 = -inf (no odd tile) -> a2 = 0
+      l_run = l_run * a1 + l2 * a2;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        o[0][r] = o[0][r] * a1 + xch[2 + r] * a2;
+        o[1][r] = o[1][r] * a1 + xch[18 + r] * a2;
       }
     }
   };
-  ATTN_STAMP(1);
-  issue(0, 0);
-  for (int i = 0; i < nsup; i += 2) {
-    pair(i, std::integral_constant<int, 0>{});
-    if (i + 1 < nsup) pair(i + 1, std::integral_constant<int, 1>{});
-  }
-
-  // ---- merge the two key-parity partials: group 1 parks (m, l, O^T) in LDS, group 0 folds it in
-  __syncthreads();
-  ATTN_STAMP(2);
-  float* xch = reinterpret_cast<float*>(smem) + (size_t)wq * 64 * 36 + lane * 36;   // 34 floats used per lane, 36 pitch
-  if (grp == 1) {
-    xch[0] = m_run;
-    xch[1] = l_run;
+  auto restart = [&]() __attribute__((always_inline)) {
+    asm volatile("" ::: "memory");
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { xch[2 + r] = o[0][r]; xch[18 + r] = o[1][r]; }
-  }
-  __syncthreads();
-  if (grp == 0) {
-    const float m2 = xch[0], l2 = xch[1];
-    const float m = fmaxf(m_run, m2);
-    const float a1 = __builtin_amdgcn_exp2f(m_run - m), a2 = __builtin_amdgcn_exp2f(m2 - m);   // m2 = -inf (no odd tile) -> a2 = 0
-    l_run = l_run * a1 + l2 * a2;
+    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+    m_run = -INFINITY;
+    l_run = 0.f;
+  };
+  int* flags = reinterpret_cast<int*>(smem + 2 * STAGE2);      // behind the ring: no wave's tile reads reach here
+  if constexpr ((VAR & 17) == 17) {
+    m_run = 0.f;                                       // P = exp2(S) for every tile, the first included (see VAR & 16)
+    key_loop(std::true_type{}, std::true_type{});
+    ATTN_STAMP(2);
+    merge();
+    if (grp == 0) {                                    // range check on the merged rows
+      const float lt = l_run + __shfl_xor(l_run, 32, 64);
+      float t = lt;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      o[0][r] = o[0][r] * a1 + xch[2 + r] * a2;
-      o[1][r] = o[1][r] * a1 + xch[18 + r] * a2;
+      for (int r = 0; r < 16; ++r) t += fabsf(o[0][r]) + fabsf(o[1][r]);
+      const bool bad = __any(!(t < 3.0e38f) || !(lt >= 8.0e-28f));     // 2^-90
+      if (lane == 0) flags[wq] = bad ? 1 : 0;
     }
+    __syncthreads();                                   // xch consumed, flags visible
+    if (__builtin_expect((flags[0] | flags[1] | flags[2] | flags[3]) != 0, 0)) {
+      restart();
+      key_loop(std::false_type{}, std::false_type{});
+      merge();
+      __syncthreads();
+    }
+  } else if constexpr ((VAR & 1) != 0) {
+    key_loop(std::false_type{}, std::true_type{});
+    ATTN_STAMP(2);
+    // overflow check of the max-free pass (see VAR & 1): anything non-finite in l or O of any wave sends the WORKGROUP round again
+    float t = l_run;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += fabsf(o[0][r]) + fabsf(o[1][r]);
+    const bool bad = __any(!(t < 3.0e38f));
+    if (lane == 0) flags[wave] = bad ? 1 : 0;
+    __syncthreads();
+    int redo = 0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) redo |= flags[w];
+    if (__builtin_expect(redo != 0, 0)) {
+      restart();
+      key_loop(std::false_type{}, std::false_type{});
+    }
+    merge();
+    __syncthreads();   // xch fully consumed before the slabs below reuse the LDS
+  } else {
+    key_loop(std::false_type{}, std::false_type{});
+    ATTN_STAMP(2);
+    merge();
+    __syncthreads();   // xch fully consumed before the slabs below reuse the LDS
   }
-  __syncthreads();   // xch fully consumed before the slabs below reuse the LDS
   if (grp == 0) {
     // normalise, park O as [32 q][64 d] bf16 (144-B pitch) and write whole 128-B rows
     const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32, 64));
@@ -323,7 +442,16 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
   if (p.npad % 64 != 0 || p.n <= 0 || p.pitch < ((p.n + 63) & ~63) || p.npad < ((p.n + 63) & ~63)) return hipErrorInvalidValue;
   if (p.out8 && !p.out_mx) return hipErrorInvalidValue;
   dim3 grid(((p.n + QB - 1) / QB) * p.b2 * p.heads);
-  if (p.ev_start) hipExtLaunchKernelGGL(attn_fwd_splitkv_kernel, grid, dim3(512), 0, s, p.ev_start, p.ev_stop, 0, p);
-  else hipLaunchKernelGGL(attn_fwd_splitkv_kernel, grid, dim3(512), 0, s, p);
+#define LEMAS_ATTN_LAUNCH(V)                                                                                                   \
+  case V:                                                                                                                      \
+    if (p.ev_start) hipExtLaunchKernelGGL(attn_fwd_splitkv_kernel<V>, grid, dim3(512), 0, s, p.ev_start, p.ev_stop, 0, p);    \
+    else hipLaunchKernelGGL(attn_fwd_splitkv_kernel<V>, grid, dim3(512), 0, s, p);                                             \
+    break;
+  switch (p.variant) {
+    LEMAS_ATTN_LAUNCH(0) LEMAS_ATTN_LAUNCH(1) LEMAS_ATTN_LAUNCH(2) LEMAS_ATTN_LAUNCH(3) LEMAS_ATTN_LAUNCH(4) LEMAS_ATTN_LAUNCH(5)
+    LEMAS_ATTN_LAUNCH(7) LEMAS_ATTN_LAUNCH(8) LEMAS_ATTN_LAUNCH(10) LEMAS_ATTN_LAUNCH(17) LEMAS_ATTN_LAUNCH(19)
+    default: return hipErrorInvalidValue;
+  }
+#undef LEMAS_ATTN_LAUNCH
   return hipGetLastError();
 }

@@ -109,6 +109,8 @@ struct GemmParams {
   const float* rope_cos;  // [seq_valid, 32]
   const float* rope_sin;
   int heads, npad;
+  float q_scale;          // EPI_QK_ROPE: the q half is multiplied by this in fp32 before the bf16 rounding (0 = 1.0): the attention
+                          // kernel's "prescaled q" variants take softmax_scale * log2(e) here (attention.hip VAR & 16)
   // fp8 path (f8 != 0): A and W point at e4m3 bytes (same [rows][K] layouts, K % 128 == 0); activations carry MX block
   // scales, weights one fp32 scale per output channel (applied in the epilogue)
   int f8;
@@ -169,6 +171,7 @@ struct AttnParams {
   uint8_t* out8;     // fp8 path: when set, the output is written as MXFP8 here ([B2*pitch, H*64] e4m3) instead of `out`
   uint8_t* out_mx;   //           [B2*pitch, H*2] E8M0
   hipEvent_t ev_start, ev_stop;   // profiling: kernel begin / end stamps (see GemmParams)
+  int variant;       // schedule variant (attention.hip, bit mask); set per launch by the engine / kbench
 #ifdef LEMAS_PHASE_TIMESTAMPS
   unsigned long long* dbg;   // measurement builds: per-workgroup phase timestamps [grid][4]
 #endif

@@ -50,7 +50,14 @@ struct lemas_dit {
   // measurement options (per engine; changing one drops the cached graphs): explicit tile ids for the block GEMMs with N == 1024 /
   // N == 2048, for the fused QK+V launch, and the XCD block grid of the tile order; 0 = the production choice
   int opt_tile_n1024 = 0, opt_tile_n2048 = 0, opt_tile_qkv = 0, opt_xcd_gx = 0;
-  bool ln_fused = true;     // the AdaLN LayerNorms behind the gated residual updates run as the tail of those GEMM launches (gemm_bf16.hip ln_tail)
+  // attention schedule variant (attention.hip VAR).  19 = no running max (P = exp2(S) on q prescaled by the QK epilogue, one range check
+  // per workgroup with a classical second pass if it trips) + static priority for the younger half-workgroup: 25.9 -> 22.5 us per lane
+  // launch at configs[1], +4.6 % end to end (profiles/r03_attention_variants.txt); 0 = the classical online softmax
+  int attn_variant = 19;
+  // the AdaLN LayerNorms behind the gated residual updates as the tail of those GEMM launches (gemm_bf16.hip ln_tail).  OFF: measured on
+  // configs[1] it is 1.5x SLOWER end to end (88.9 -> 59.8 audio-s/s, profiles/r03_ln_tail_experiment.txt): with two lanes sharing the chip a
+  // panel's column tiles do not run at the same time, so finished workgroups sit on their CUs waiting for panel-mates that have not started
+  bool ln_fused = false;
   unsigned int* ln_err_host = nullptr;   // pinned, device-visible: set by a device-side wait that gave up (checked at every entry point)
   unsigned int* ln_err_dev = nullptr;
   hipStream_t s2 = nullptr;
@@ -617,11 +624,13 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     GemmParams g{};
     g.M = rows; g.tab = tab; g.tab_stride = tab_stride; g.step_idx = step; g.seq_pitch = pitch; g.seq_valid = N; g.batch = B;
     g.heads = cfg.heads; g.npad = npad; g.rope_cos = d_rope_cos.as<float>(); g.rope_sin = d_rope_sin.as<float>();
+    // attention variants with bit 16 take q already multiplied by softmax_scale * log2(e): the QK epilogue does it before rounding
+    g.q_scale = (attn_variant & 16) ? (1.0f / sqrtf((float)cfg.dim_head)) * 1.4426950408889634f : 0.f;
     g.q = d_q.as<bf16_t>() + r0 * in; g.k = d_k.as<bf16_t>() + r0 * in; g.vt = d_vt.as<bf16_t>() + r0 * in;
     AttnParams at{};
     at.q = g.q; at.k = g.k; at.vt = g.vt; at.out = abf;
     at.kv_len = has_len ? d_len.as<int>() : nullptr; at.b2 = bh; at.batch = B; at.heads = cfg.heads; at.n = N; at.npad = npad; at.pitch = pitch;
-    at.scale = 1.0f / sqrtf((float)cfg.dim_head);
+    at.scale = 1.0f / sqrtf((float)cfg.dim_head); at.variant = attn_variant;
     const BlockW& w = blocks[l];
     const int base = l * 6 * d;  // [shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp] (modules.py:312)
     uint8_t* h8 = fp8 ? d_h8.as<uint8_t>() + r0 * d : nullptr;
@@ -870,7 +879,8 @@ int lemas_dit_set_option(lemas_dit* m, const char* key, int64_t value) {
   }
   {
     int* slot = !strcmp(key, "tile_n1024") ? &m->opt_tile_n1024 : !strcmp(key, "tile_n2048") ? &m->opt_tile_n2048
-              : !strcmp(key, "tile_qkv") ? &m->opt_tile_qkv : !strcmp(key, "xcd_gx") ? &m->opt_xcd_gx : nullptr;
+              : !strcmp(key, "tile_qkv") ? &m->opt_tile_qkv : !strcmp(key, "xcd_gx") ? &m->opt_xcd_gx
+              : !strcmp(key, "attn_variant") ? &m->attn_variant : nullptr;
     if (slot) {
       *slot = (int)value;
       m->drop_graphs();     // a captured graph baked the kernels of the old choice

@@ -42,14 +42,14 @@ __global__ void transpose_v_kernel(const float* v, bf16_t* vt, int BH, int N, in
     vt[((size_t)bh * 64 + d) * npad + n] = (bf16_t)v[i];
   }
 }
-// [BH][N][64] fp32 -> [BH][pitch][64] bf16 (rows >= N stay zero)
-__global__ void pad_rows_kernel(const float* src, bf16_t* dst, int BH, int N, int pitch) {
+// [BH][N][64] fp32 -> [BH][pitch][64] bf16 (rows >= N stay zero), scaled in fp32 before the rounding
+__global__ void pad_rows_kernel(const float* src, bf16_t* dst, int BH, int N, int pitch, float scale = 1.0f) {
   const size_t total = (size_t)BH * N * 64;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int d = (int)(i % 64);
     const int n = (int)((i / 64) % N);
     const int bh = (int)(i / ((size_t)64 * N));
-    dst[((size_t)bh * pitch + n) * 64 + d] = (bf16_t)src[i];
+    dst[((size_t)bh * pitch + n) * 64 + d] = (bf16_t)(src[i] * scale);
   }
 }
 // [B][pitch][C] bf16 -> [B][N][C] fp32
@@ -321,6 +321,11 @@ int lemas_k_linear_f8(const float* A, const float* W, const float* bias, float* 
 
 int lemas_k_attention(const float* q, const float* k, const float* v, const int32_t* seq_len, float* out, int32_t B,
                       int32_t H, int32_t N, void* stream) {
+  return lemas_k_attention_variant(q, k, v, seq_len, out, B, H, N, 0, stream);
+}
+
+int lemas_k_attention_variant(const float* q, const float* k, const float* v, const int32_t* seq_len, float* out, int32_t B,
+                              int32_t H, int32_t N, int32_t variant, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   Scratch sc;
   const int pitch = (N + 127) & ~127, npad = pitch;
@@ -330,12 +335,13 @@ int lemas_k_attention(const float* q, const float* k, const float* v, const int3
   bf16_t* vt = sc.get<bf16_t>((size_t)B * H * 64 * npad);
   bf16_t* ob = sc.get<bf16_t>(np);
   if (!qb || !kb || !vt || !ob) { set_error("lemas_k_attention: out of memory"); return LEMAS_E_STATE; }
-  hipLaunchKernelGGL(pad_rows_kernel, dim3(2048), dim3(256), 0, s, q, qb, B * H, N, pitch);
-  hipLaunchKernelGGL(pad_rows_kernel, dim3(2048), dim3(256), 0, s, k, kb, B * H, N, pitch);
+  // the "prescaled q" variants (attention.hip VAR & 16) take q * softmax_scale * log2(e), as the QK GEMM epilogue hands it over
+  hipLaunchKernelGGL(pad_rows_kernel, dim3(2048), dim3(256), 0, s, q, qb, B * H, N, pitch, (variant & 16) ? 0.125f * 1.4426950408889634f : 1.0f);
+  hipLaunchKernelGGL(pad_rows_kernel, dim3(2048), dim3(256), 0, s, k, kb, B * H, N, pitch, 1.0f);
   hipLaunchKernelGGL(transpose_v_kernel, dim3(2048), dim3(256), 0, s, v, vt, B * H, N, npad);
   AttnParams p{};
   p.q = qb; p.k = kb; p.vt = vt; p.out = ob; p.kv_len = seq_len; p.b2 = B; p.batch = B; p.heads = H; p.n = N; p.npad = npad; p.pitch = pitch;
-  p.scale = 0.125f;
+  p.scale = 0.125f; p.variant = variant;
   HIP_TRY(launch_attention(p, s));
   hipLaunchKernelGGL(unpad_widen_kernel, dim3(2048), dim3(256), 0, s, ob, out, B, N, pitch, H * 64);
   HIP_TRY(hipStreamSynchronize(s));
@@ -494,7 +500,7 @@ extern "C" int lemas_k_bench(const char* what, int32_t M, int32_t N, int32_t K, 
     hipLaunchKernelGGL(fill_pattern_kernel, dim3(1024), dim3(256), 0, s, vt, (size_t)bh * 64 * npad, 5u);
     AttnParams p{};
     p.q = q; p.k = k; p.vt = vt; p.out = o; p.kv_len = nullptr; p.b2 = bh / 16; p.batch = bh / 16; p.heads = 16; p.n = n; p.npad = npad; p.pitch = pitch;
-    p.scale = 0.125f;
+    p.scale = 0.125f; p.variant = variant;
     rc = time_it([&]() { return launch_attention(p, s); });
 #ifdef LEMAS_PHASE_TIMESTAMPS
     if (rc == 0) {   // phase timestamps of one more launch

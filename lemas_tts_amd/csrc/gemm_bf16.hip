@@ -225,6 +225,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x16 (&acc)
     const int inner = p.heads * 64, n = nw + ch * 8;
     const int which = n / inner, head = (n % inner) >> 6, d = n & 63;
     bf16_t* base = (which == 0 ? p.q : p.k) + (size_t)head * p.seq_pitch * 64 + d;
+    const float qs = (which == 0 && p.q_scale != 0.f) ? p.q_scale : 1.0f;
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
       const int m = mw + it * RPI + rr;
@@ -236,10 +237,10 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x16 (&acc)
       const float4 a = *reinterpret_cast<const float4*>(slab + (it * RPI + rr) * S::PITCH + ch * 32);
       const float4 b = *reinterpret_cast<const float4*>(slab + (it * RPI + rr) * S::PITCH + ch * 32 + 16);
       bf16x8 o;
-      o[0] = (bf16_t)(a.x * c.x - a.y * sn.x); o[1] = (bf16_t)(a.y * c.x + a.x * sn.x);
-      o[2] = (bf16_t)(a.z * c.y - a.w * sn.y); o[3] = (bf16_t)(a.w * c.y + a.z * sn.y);
-      o[4] = (bf16_t)(b.x * c.z - b.y * sn.z); o[5] = (bf16_t)(b.y * c.z + b.x * sn.z);
-      o[6] = (bf16_t)(b.z * c.w - b.w * sn.w); o[7] = (bf16_t)(b.w * c.w + b.z * sn.w);
+      o[0] = (bf16_t)((a.x * c.x - a.y * sn.x) * qs); o[1] = (bf16_t)((a.y * c.x + a.x * sn.x) * qs);
+      o[2] = (bf16_t)((a.z * c.y - a.w * sn.y) * qs); o[3] = (bf16_t)((a.w * c.y + a.z * sn.y) * qs);
+      o[4] = (bf16_t)((b.x * c.z - b.y * sn.z) * qs); o[5] = (bf16_t)((b.y * c.z + b.x * sn.z) * qs);
+      o[6] = (bf16_t)((b.z * c.w - b.w * sn.w) * qs); o[7] = (bf16_t)((b.w * c.w + b.z * sn.w) * qs);
       if (live) store_wt_b128(base + ((size_t)b2 * p.heads * p.seq_pitch + pos) * 64, __builtin_bit_cast(u32x4, o));
     }
   } else if (EPI == EPI_BIAS_GELU_F8) {
@@ -441,6 +442,7 @@ __device__ __forceinline__ void epilogue_row_blocks(const GemmParams& p, f32x16 
     const int inner = p.heads * 64, n = nw + ch * 8;
     const int which = n / inner, head = (n % inner) >> 6, d = n & 63;
     bf16_t* base = (which == 0 ? p.q : p.k) + (size_t)head * p.seq_pitch * 64 + d;
+    const float qs = (which == 0 && p.q_scale != 0.f) ? p.q_scale : 1.0f;
     float4 cnext[ITERS], snext[ITERS];
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
@@ -467,10 +469,10 @@ __device__ __forceinline__ void epilogue_row_blocks(const GemmParams& p, f32x16 
         const float4 a = *reinterpret_cast<const float4*>(slab + (it * RPI + rr) * S::PITCH + ch * 32);
         const float4 b = *reinterpret_cast<const float4*>(slab + (it * RPI + rr) * S::PITCH + ch * 32 + 16);
         bf16x8 o;
-        o[0] = (bf16_t)(a.x * c.x - a.y * sv.x); o[1] = (bf16_t)(a.y * c.x + a.x * sv.x);
-        o[2] = (bf16_t)(a.z * c.y - a.w * sv.y); o[3] = (bf16_t)(a.w * c.y + a.z * sv.y);
-        o[4] = (bf16_t)(b.x * c.z - b.y * sv.z); o[5] = (bf16_t)(b.y * c.z + b.x * sv.z);
-        o[6] = (bf16_t)(b.z * c.w - b.w * sv.w); o[7] = (bf16_t)(b.w * c.w + b.z * sv.w);
+        o[0] = (bf16_t)((a.x * c.x - a.y * sv.x) * qs); o[1] = (bf16_t)((a.y * c.x + a.x * sv.x) * qs);
+        o[2] = (bf16_t)((a.z * c.y - a.w * sv.y) * qs); o[3] = (bf16_t)((a.w * c.y + a.z * sv.y) * qs);
+        o[4] = (bf16_t)((b.x * c.z - b.y * sv.z) * qs); o[5] = (bf16_t)((b.y * c.z + b.x * sv.z) * qs);
+        o[6] = (bf16_t)((b.z * c.w - b.w * sv.w) * qs); o[7] = (bf16_t)((b.w * c.w + b.z * sv.w) * qs);
         if (live) store_wt_b128(base + ((size_t)b2 * p.heads * p.seq_pitch + pos) * 64, __builtin_bit_cast(u32x4, o));
       }
     }

@@ -140,7 +140,7 @@ def test_fused_layernorm_tail_is_bit_identical_to_separate_launches(golden_dir, 
             for graph in (False, True):
                 outs[(ln, dual, graph)] = _run_case(fx, arch, sd, graph=graph, traj=False)[0]
     m.engine.set_option("dual", 1)
-    m.engine.set_option("ln_fused", 1)
+    m.engine.set_option("ln_fused", 0)
     m.engine.check_health()
     ref = outs[(0, 0, False)]
     for k, v in outs.items():

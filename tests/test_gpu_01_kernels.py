@@ -3,6 +3,8 @@ plain fp32 torch reference of the same op.  Tolerances are stated per test; bf16
 against fp32 math on bf16-ROUNDED inputs so that only accumulation order / output rounding remain."""
 import math
 
+import numpy as np
+
 import pytest
 import torch
 
@@ -334,11 +336,12 @@ def test_gemm_gate_with_layernorm_tail_repeated_under_load():
 def test_gemm_gate_layernorm_tail_refuses_tiles_without_it():
     L, lib = _lib()
     dev = "cuda:0"
-    z = torch.zeros(256 * 1024, device=dev)
+    a, w = torch.zeros(256, 1024, device=dev), torch.zeros(1024, 1024, device=dev)
+    x, h = torch.zeros(256, 1024, device=dev), torch.zeros(256, 1024, device=dev)
     v = torch.zeros(1024, device=dev)
     for tile in (16, 22):
-        rc = lib.lemas_k_gemm_gate_ln(tile, z.data_ptr(), z.data_ptr(), v.data_ptr(), v.data_ptr(), v.data_ptr(), v.data_ptr(), None,
-                                      z.data_ptr(), z.data_ptr(), 1, 256, 256, 1024, 1, None)
+        rc = lib.lemas_k_gemm_gate_ln(tile, a.data_ptr(), w.data_ptr(), v.data_ptr(), v.data_ptr(), v.data_ptr(), v.data_ptr(), None,
+                                      x.data_ptr(), h.data_ptr(), 1, 256, 256, 1024, 1, None)
         assert rc != 0, tile
 
 
@@ -362,3 +365,59 @@ def test_attention_large_ragged_batches(B, H, N):
         ref = (torch.softmax(s, -1) @ vb[b, :, :n]).transpose(0, 1).reshape(n, H * 64)
         worst = max(worst, float((out[b, :n] - ref).abs().max()))
     assert worst < 3e-2, worst
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Attention schedule variants (csrc/attention.hip VAR): same contract as the original kernel, plus inputs that FORCE the rare paths of
+# the sum-checked softmax (variant bit 1): a key whose score jumps far above the running max in a late tile (the overflow guard must
+# send that tile through the classical path), scores so large that exp2 overflows to inf, and rows whose later scores sit far BELOW
+# the first tile's maximum (everything after underflows: must equal the reference, not NaN).
+def _attn_ref(q, k, v, lens, prescaled=False):
+    """fp64 softmax attention on the operands as the kernel sees them: q, k, v rounded to bf16 -- for the "prescaled q" variants q is
+    multiplied by softmax_scale * log2(e) in fp32 BEFORE the rounding (what the QK GEMM epilogue does), and the scores are base-2"""
+    kb, vb = _bf(k), _bf(v)
+    B, H, N, _ = q.shape
+    out = torch.zeros(B, N, H * 64, device=q.device)
+    c = float(np.float32(0.125) * np.float32(1.4426950408889634))
+    qb = _bf(q * c) if prescaled else _bf(q)
+    for b in range(B):
+        n = int(lens[b]) if lens is not None else N
+        s = (qb[b, :, :, :].double() @ kb[b, :, :n].double().transpose(-1, -2))
+        s = s * math.log(2.0) if prescaled else s / 8.0
+        out[b] = (torch.softmax(s, -1) @ vb[b, :, :n].double()).float().transpose(0, 1).reshape(N, H * 64)
+    return out
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 7, 17, 19])
+@pytest.mark.parametrize("case", ["plain", "late_spike", "overflow", "early_peak", "ragged", "deep_negative"])
+def test_attention_variants(variant, case):
+    L, lib = _lib()
+    dev = "cuda:0"
+    B, H, N = (3, 16, 777) if case == "ragged" else (1, 16, 1000)
+    g = torch.Generator(device=dev).manual_seed(("plain", "late_spike", "overflow", "early_peak", "ragged", "deep_negative").index(case) * 100 + variant)
+    q, k, v = (torch.randn(B, H, N, 64, generator=g, device=dev) for _ in range(3))
+    lens = None
+    if case == "late_spike":        # one key in a late tile scores ~40 nats above everything before it, for a quarter of the queries
+        k[:, :, 900] = q[:, :, 100] * 5.0
+        q[:, :, 100:350] = q[:, :, 100:101] + 0.05 * q[:, :, 100:350]
+    elif case == "overflow":        # |score| in the hundreds: exp2 of the difference to the first tile's max overflows fp32
+        q[:, :, :64] *= 12.0
+        k[:, :, 700:708] *= 12.0
+    elif case == "early_peak":      # the first tile holds a huge score, everything later underflows against it
+        k[:, :, 3] = q[:, :, 500] * 6.0
+    elif case == "ragged":
+        lens = torch.tensor([777, 64, 391], device=dev, dtype=torch.int32)
+    elif case == "deep_negative":   # some rows score around -100 nats everywhere: exp2 of the raw score underflows (the no-max variant must notice)
+        k[:, :, :, 0] = 0.0
+        q[:, :, 200:232, 0] = -1.0e4
+        k[:, :, :, 0] = 0.125 * (1.0 + 0.01 * torch.randn(B, H, N, generator=g, device=dev))
+    out = torch.empty(B, N, H * 64, device=dev)
+    L.check(lib.lemas_k_attention_variant(q.data_ptr(), k.data_ptr(), v.data_ptr(), lens.data_ptr() if lens is not None else None,
+                                          out.data_ptr(), B, H, N, variant, None))
+    ref = _attn_ref(q, k, v, lens, prescaled=bool(variant & 16))
+    assert torch.isfinite(out).all()
+    for b in range(B):
+        n = int(lens[b]) if lens is not None else N
+        # bf16 output: half an ulp is 2^-9 relative (1.6e-2 absolute in [4, 8), where a row that locks onto one key can land)
+        err = float(((out[b, :n] - ref[b, :n]).abs() / ref[b, :n].abs().clamp(min=1.0)).max())
+        assert err < 2e-2, (variant, case, b, err)

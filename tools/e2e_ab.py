@@ -21,6 +21,9 @@ from lemas_tts_amd.model.cfm import CFM  # noqa: E402
 from lemas_tts_amd.model.layout import DiTArch  # noqa: E402
 
 
+DEFAULT_ATTN = 19
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="configs1")
@@ -51,7 +54,8 @@ def main():
         m.engine.set_option("tile_n2048", int(opts.get("n2048", 0)))
         m.engine.set_option("tile_qkv", int(opts.get("qkv", 0)))
         m.engine.set_option("xcd_gx", int(opts.get("gx", 0)))
-        m.engine.set_option("ln_fused", int(opts.get("ln_fused", 1)))
+        m.engine.set_option("ln_fused", int(opts.get("ln_fused", 0)))
+        m.engine.set_option("attn_variant", int(opts.get("attn", DEFAULT_ATTN)))
         m.engine.set_option("fp8", int(opts.get("fp8", 0)))
         m.engine.set_option("qkv_fused", int(opts.get("qkv_fused", 1)))
         m.engine.set_option("dual", int(opts.get("dual", 1)))          # drops the cached graphs: the next sample captures under this arm's choices
