@@ -77,6 +77,9 @@ typedef struct {
                                * not `cond` (+ prosody projection) itself -- the accent-GRL path conditions on cond_grl, built
                                * from the RAW prompt mel before the prosody projection / no_ref_audio substitution and
                                * optionally clipped-and-shuffled (cfm.py:266-283, 329-330, 387-388).  `out` still uses `cond`. */
+  int32_t prosody_text_only;  /* != 0: `prosody` conditions the TEXT side only (dit.py:225-233) and `cond` is final as given.  The
+                               * no_ref_audio path of the reference overwrites the prosody-shifted mel with its random conditioning
+                               * (cfm.py:313-324), so the prosody-to-mel projection has no effect there. */
 } lemas_sample_args;
 
 const char* lemas_last_error(void);

@@ -36,6 +36,7 @@ class SampleArgs(C.Structure):
         ("cond", C.c_void_p), ("cond_mask", C.c_void_p), ("text", C.c_void_p), ("seq_len", C.c_void_p),
         ("prosody", C.c_void_p), ("t_grid", C.POINTER(C.c_float)),
         ("y", C.c_void_p), ("out", C.c_void_p), ("trajectory", C.c_void_p), ("step_cond", C.c_void_p),
+        ("prosody_text_only", C.c_int32),
     ]
 
 

@@ -68,6 +68,31 @@ def set_frontend_factory(factory) -> None:
     FRONTEND_FACTORY = factory
 
 
+def resolve_frontend_factory(spec: str):
+    """``"package.module:callable"`` -> the callable (e.g. ``lemas_tts.infer.frontend:TextNorm`` called as ``TextNorm(dtype=...)``).
+    This is how the command-line entry points and the ``LEMAS_FRONTEND_FACTORY`` environment variable name a frontend without this
+    package importing one."""
+    import importlib
+    mod, sep, attr = spec.partition(":")
+    if not sep or not mod or not attr:
+        raise ValueError(f"frontend factory {spec!r}: expected 'package.module:callable'")
+    obj = importlib.import_module(mod)
+    for part in attr.split("."):
+        obj = getattr(obj, part)
+    if not callable(obj):
+        raise TypeError(f"frontend factory {spec!r} is not callable")
+    return lambda dtype, _f=obj: _f(dtype=dtype)
+
+
+def _registered_frontend_factory():
+    """the factory set with :func:`set_frontend_factory`, else the one ``LEMAS_FRONTEND_FACTORY=module:callable`` names"""
+    import os
+    if FRONTEND_FACTORY is not None:
+        return FRONTEND_FACTORY
+    spec = os.environ.get("LEMAS_FRONTEND_FACTORY")
+    return resolve_frontend_factory(spec) if spec else None
+
+
 class TTS:
     def __init__(self, model="multilingual_grl", ckpt_file="", vocab_file="", ode_method="euler", use_ema=False,
                  vocoder_local_path=None, use_prosody_encoder=False, prosody_cfg_path="", prosody_ckpt_path="",
@@ -91,11 +116,13 @@ class TTS:
             # api.py:140-151 builds TextNorm(dtype=frontend) from the reference's own host-side frontend package (espeak / jieba /
             # langid).  The text frontend is out of this build's scope and the product does not import the reference package:
             # the integrator registers a factory once, or hands the OBJECT over.
-            if FRONTEND_FACTORY is None:
+            factory = _registered_frontend_factory()
+            if factory is None:
                 raise TypeError(f"frontend={frontend!r}: no text frontend is registered.  Call lemas_tts_amd.api.set_frontend_factory("
-                                "lambda dtype: TextNorm(dtype=dtype)) once, or pass a frontend OBJECT with text2phn() / text2norm() "
-                                "and a .dtype of 'phone' or 'char', or frontend=None with phone-token lists")
-            frontend = FRONTEND_FACTORY(frontend)
+                                "lambda dtype: TextNorm(dtype=dtype)) once, set LEMAS_FRONTEND_FACTORY=package.module:callable (the "
+                                "command-line entry points take --frontend_factory), or pass a frontend OBJECT with text2phn() / "
+                                "text2norm() and a .dtype of 'phone' or 'char', or frontend=None with phone-token lists")
+            frontend = factory(frontend)
         self.frontend = frontend
         self.ema_model = load_model(None, cfg["arch"], ckpt_file, self.mel_spec_type, vocab_file, self.ode_method,
                                     self.use_ema, self.device, use_prosody_encoder=use_prosody_encoder,

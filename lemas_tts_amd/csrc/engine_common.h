@@ -80,6 +80,9 @@ struct Tensor {
 struct WeightStore {
   std::map<std::string, std::vector<int64_t>> schema;
   std::map<std::string, Tensor> t;
+  char* arena = nullptr;                       // one allocation for every declared tensor (WeightStore::load)
+  size_t arena_bytes = 0;
+  std::map<std::string, size_t> slot;          // byte offset of each tensor's slot in the arena
   void declare(const std::string& name, std::vector<int64_t> shape) { schema[name] = std::move(shape); }
   // `src` is host memory, or (on_device) a device address on the current device, e.g. a view of the flat buffer that arrived
   // by RCCL broadcast (parallel.py): then the tensor never touches the host

@@ -54,12 +54,24 @@ int WeightStore::load(const char* name, const float* src, const int64_t* shape, 
     set_error("tensor '%s' has the wrong shape (ndim %d)", name, ndim);
     return LEMAS_E_WEIGHT;
   }
+  // ONE device allocation for the whole schema, made (and zero-filled, once) when the first tensor arrives: a checkpoint is ~370
+  // tensors, and a hipMalloc + a synchronised fill each was most of the load time.  Every tensor owns a fixed 256-B aligned slot
+  // with 64 floats of slack behind it (the fp32 GEMM reads whole float4 groups of offset sub-matrices: input_embed.proj columns);
+  // a reload writes the same slot.
+  if (!arena) {
+    size_t total = 0;
+    for (const auto& kv : schema) {
+      size_t n = 1;
+      for (int64_t d : kv.second) n *= (size_t)d;
+      slot[kv.first] = total;
+      total += ((n + 64) * sizeof(float) + 255) & ~(size_t)255;
+    }
+    HIP_TRY(hipMalloc((void**)&arena, total));
+    HIP_TRY(zero_fill_sync(arena, total));
+    arena_bytes = total;
+  }
   Tensor& x = t[name];
-  if (x.dev) HIP_TRY(hipFree(x.dev));
-  x.dev = nullptr;
-  // +64 floats of slack: the fp32 GEMM reads whole float4 groups of offset sub-matrices (input_embed.proj columns)
-  HIP_TRY(hipMalloc((void**)&x.dev, (numel + 64) * sizeof(float)));
-  HIP_TRY(zero_fill_sync(x.dev, (numel + 64) * sizeof(float)));
+  x.dev = reinterpret_cast<float*>(arena + slot[name]);
   // synchronous on the NULL stream in both cases; a device source written on another stream must be complete before the call
   HIP_TRY(hipMemcpy(x.dev, src, numel * sizeof(float), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
   if (on_device) HIP_TRY(hipStreamSynchronize(nullptr));
@@ -78,8 +90,10 @@ int WeightStore::check_complete() const {
 }
 
 void WeightStore::release() {
-  for (auto& kv : t)
-    if (kv.second.dev) (void)hipFree(kv.second.dev);
+  if (arena) (void)hipFree(arena);
+  arena = nullptr;
+  arena_bytes = 0;
+  slot.clear();
   t.clear();
 }
 

@@ -480,7 +480,7 @@ int lemas_dit::prepare(const lemas_sample_args* a, hipStream_t s) {
   RC_TRY(d_cond_eff.ensure((size_t)B * N * md * 4));
   RC_TRY(d_step_cond.ensure((size_t)B * N * md * 4));
   const float* pm = nullptr;
-  if (a->prosody && cfg.has_prosody) {
+  if (a->prosody && cfg.has_prosody && !a->prosody_text_only) {   // text-only: cond is final as given (cfm.py:320-324 overwrote the shifted mel)
     RC_TRY(d_pm.ensure((size_t)B * md * 4));
     GemmF32Params g{};
     g.A = a->prosody; g.lda = 512; g.W = ws.ptr("prosody_to_mel.weight"); g.ldw = 512; g.bias = nullptr;

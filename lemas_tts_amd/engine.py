@@ -113,7 +113,8 @@ class DiTEngine(_Streamed):
         _lib.check(_lib.lib().lemas_dit_health(self._h), "lemas_dit_health")
 
     # ------------------------------------------------------------------------------------------
-    def _args(self, cond, cond_mask, text, seq_len, prosody, t_grid, cfg_strength, cond_frames, y, out, traj, step_cond=None):
+    def _args(self, cond, cond_mask, text, seq_len, prosody, t_grid, cfg_strength, cond_frames, y, out, traj, step_cond=None,
+              prosody_text_only=False):
         B, N, _ = cond.shape
         tg = np.ascontiguousarray(np.asarray(t_grid, dtype=np.float32))
         self._tg_keep = tg
@@ -128,6 +129,7 @@ class DiTEngine(_Streamed):
         a.out = out.data_ptr() if out is not None else None
         a.trajectory = traj.data_ptr() if traj is not None else None
         a.step_cond = step_cond.data_ptr() if step_cond is not None else None
+        a.prosody_text_only = 1 if prosody_text_only else 0
         return a
 
     def _canon(self, cond, cond_mask, text, seq_len, prosody):
@@ -141,7 +143,7 @@ class DiTEngine(_Streamed):
 
     def sample(self, cond, cond_mask, text, t_grid, y0, *, cond_frames: int, cfg_strength: float,
                seq_len: Optional[torch.Tensor] = None, prosody: Optional[torch.Tensor] = None,
-               want_trajectory: bool = False, step_cond: Optional[torch.Tensor] = None):
+               want_trajectory: bool = False, step_cond: Optional[torch.Tensor] = None, prosody_text_only: bool = False):
         """cond [B,N,mel] zero-padded mel; cond_mask [B,N] bool; text [B,Nt] int64 (-1 pad); y0 [B,N,mel];
         step_cond [B,N,mel] or None: the accent-GRL conditioning (cfm.py:387-388) when it differs from cond.
         Returns (out, y_final, trajectory|None) as device tensors."""
@@ -152,7 +154,8 @@ class DiTEngine(_Streamed):
             out = torch.empty_like(y)
             S = len(t_grid) - 1
             traj = torch.empty((S + 1,) + tuple(y.shape), device=self.device, dtype=torch.float32) if want_trajectory else None
-            a = self._args(cond, cond_mask, text, seq_len, prosody, t_grid, cfg_strength, cond_frames, y, out, traj, step_cond)
+            a = self._args(cond, cond_mask, text, seq_len, prosody, t_grid, cfg_strength, cond_frames, y, out, traj, step_cond,
+                           prosody_text_only)
             s = self._enter(cond, cond_mask, text, seq_len, prosody, y, out, traj, step_cond)
             _lib.check(_lib.lib().lemas_dit_sample(self._h, C.byref(a), s), "lemas_dit_sample")
             self._exit()

@@ -170,10 +170,9 @@ class CFM:
         pros = prosody_embeds if (use_prosody_encoder and self.use_prosody_encoder) else None
         if no_ref_audio:
             # cfm.py:320-324: the conditioning becomes noise around the prompt's mean (the draw is an explicit input here,
-            # ``cond_noise``; the reference takes it from the global RNG).  It overwrites cond AFTER the prosody-to-mel
-            # projection was added (:313-318), which the engine adds inside prepare(): that combination is not built.
-            if pros is not None:
-                raise NotImplementedError("no_ref_audio together with the prosody encoder is not built")
+            # ``cond_noise``; the reference takes it from the global RNG).  It OVERWRITES cond after the prosody-to-mel projection
+            # was added (:313-318): with the prosody encoder on, the embedding then acts through the text side only
+            # (dit.py:225-233) -- the engine is told not to add its mel projection (prosody_text_only).
             if cond_noise is None:
                 cond_noise = torch.randn(batch, n, self.num_channels, dtype=torch.float32)   # host generator, like the y0 draw below
             rc = cond_noise.to(dev, torch.float32) * 0.1 + cond_mean
@@ -201,7 +200,8 @@ class CFM:
         out, y_final, traj = self.engine.sample(
             cond, cond_mask, text, t.numpy(), y0, cond_frames=min(cond_seq_len, n), cfg_strength=float(cfg_strength),   # F.pad above CROPS the
             # prompt when `lens` lets the duration fall below the prompt length (negative pad, as cfm.py:311 does)
-            seq_len=seq_len, prosody=pros, want_trajectory=return_trajectory, step_cond=step_cond)
+            seq_len=seq_len, prosody=pros, want_trajectory=return_trajectory, step_cond=step_cond,
+            prosody_text_only=bool(no_ref_audio and pros is not None))
         if no_ref_audio:                                                     # cfm.py:464-466: re-centre the generated part
             gen = out[:, cond_seq_len:, :]
             out[:, cond_seq_len:, :] = gen - (gen.mean(dim=1, keepdim=True) - cond_mean)

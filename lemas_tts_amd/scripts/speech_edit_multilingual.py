@@ -195,6 +195,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--use_prosody_encoder", default=False, action="store_true")
     p.add_argument("--seed", type=int, default=-1)
     p.add_argument("--vocoder_local_path", type=str, default="", help="addition: vocos directory (config.yaml + pytorch_model.bin)")
+    p.add_argument("--frontend_factory", type=str, default=None,
+                   help="addition: 'package.module:callable' building the text frontend for --frontend phone|char (called as "
+                        "callable(dtype=...)); default: the LEMAS_FRONTEND_FACTORY environment variable")
     return p
 
 
@@ -203,6 +206,9 @@ def main(argv=None, tts=None) -> int:
     args = build_parser().parse_args(argv)
     if tts is None:
         from ..api import CKPTS_ROOT, TTS
+        if args.frontend_factory:
+            from ..api import resolve_frontend_factory, set_frontend_factory
+            set_frontend_factory(resolve_frontend_factory(args.frontend_factory))
         tts = TTS(model=args.model, ckpt_file=args.ckpt_file, vocab_file=args.vocab_file, device=args.device, use_ema=args.use_ema,
                   frontend=None if args.frontend == "none" else args.frontend, use_prosody_encoder=args.enable_prosody_encoder,
                   prosody_cfg_path=args.prosody_cfg_path, prosody_ckpt_path=args.prosody_ckpt_path,

@@ -94,6 +94,10 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--phones", type=str, default=None, help="text to generate, already phonemised; '\\n' separates lines")
     p.add_argument("--vocoder_local_path", type=str, default="", help="vocos directory (config.yaml + pytorch_model.bin)")
     p.add_argument("--device", type=str, default=None, help="cuda:N (default cuda:0)")
+    p.add_argument("--frontend_factory", type=str, default=None,
+                   help="'package.module:callable' building the text frontend for --frontend phone|char, called as callable(dtype=...): "
+                        "e.g. lemas_tts.infer.frontend:TextNorm.  Default: the LEMAS_FRONTEND_FACTORY environment variable.  The text "
+                        "frontend (espeak / jieba / langid) is host Python outside this package")
     return p
 
 
@@ -117,6 +121,9 @@ def main(argv=None) -> int:
     if not os.path.isfile(args.ref_audio):
         raise FileNotFoundError(f"Reference audio not found: {args.ref_audio}")
 
+    if args.frontend_factory:
+        from ..api import resolve_frontend_factory, set_frontend_factory
+        set_frontend_factory(resolve_frontend_factory(args.frontend_factory))
     tts = build_tts(args.model, ckpt_file, vocab_file, args.device, args.use_ema, None if phones_given else args.frontend,
                     args.enable_prosody_encoder, args.prosody_cfg_path, args.prosody_ckpt_path, args.vocoder_local_path)
     if phones_given:

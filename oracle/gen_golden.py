@@ -41,6 +41,8 @@ def _reference_y0(seed: int, durations) -> torch.Tensor:
 
 def run_case(name, arch, *, wseed, B, F, lens, Nt, duration, steps, cfg, coef, noise_seed,
              edit_spans=None, prosody=False, use_acc_grl=False, no_ref_audio=False, ref_ratio=1, pyseed=None, store_traj=True):
+    if ONLY is not None and name not in ONLY:
+        return
     sd_np = synth.synth_cfm_state_dict(arch, VOCAB, wseed, prosody=prosody)
     sd = {k: torch.from_numpy(v) for k, v in sd_np.items()}
     cfm = ref_shims.build_reference_cfm(arch.reference_kwargs(), VOCAB, sd, use_prosody=prosody)
@@ -204,9 +206,15 @@ def run_full_size_cases(which=None):
         run_case(name, arch, store_traj=False, **kw)
 
 
+ONLY = None      # --only name ...: regenerate just these sampler fixtures
+
+
 def main():
+    global ONLY
     os.makedirs(GOLDEN, exist_ok=True)
     torch.set_num_threads(8)
+    if "--only" in sys.argv:
+        ONLY = set(sys.argv[sys.argv.index("--only") + 1:])
     if "--full-size" in sys.argv:
         run_full_size_cases([a for a in sys.argv[1:] if not a.startswith("--")] or None)
         return
@@ -224,11 +232,16 @@ def main():
              cfg=2.0, coef=5, noise_seed=107, no_ref_audio=True)
     run_case("mini_grl_prosody", DiTArch(depth=2), wseed=20, B=2, F=48, lens=None, Nt=[18, 25], duration=[120, 131], steps=3,
              cfg=2.0, coef=5, noise_seed=108, prosody=True, use_acc_grl=True)
+    # no_ref_audio together with the prosody encoder: the random conditioning OVERWRITES the prosody-shifted mel (cfm.py:313-324), so
+    # the prosody embedding acts through the text side only (dit.py:225-233)
+    run_case("mini_noref_prosody", DiTArch(depth=2), wseed=22, B=1, F=56, lens=None, Nt=[24], duration=150, steps=3,
+             cfg=2.0, coef=5, noise_seed=110, prosody=True, no_ref_audio=True)
     run_case("mini_grl_shuffle", MINI, wseed=21, B=1, F=230, lens=None, Nt=[40], duration=400, steps=3,
              cfg=2.0, coef=5, noise_seed=109, use_acc_grl=True, ref_ratio=0.5, pyseed=4242)
-    run_edit_mask_cases()
-    run_prosody_case("prosody_enc_short", 17, 41)
-    run_prosody_case("prosody_enc_10s", 18, 998)
+    if ONLY is None:
+        run_edit_mask_cases()
+        run_prosody_case("prosody_enc_short", 17, 41)
+        run_prosody_case("prosody_enc_10s", 18, 998)
     run_case("full_plain", FULL, wseed=16, B=1, F=150, lens=None, Nt=[60], duration=400, steps=3,
              cfg=2.0, coef=5, noise_seed=106)
 

@@ -15,7 +15,7 @@ from lemas_tts_amd.model.layout import DiTArch
 pytestmark = pytest.mark.gpu
 
 MSE_TOL = 1e-4
-GOLDEN_CASES = ["mini_plain", "mini_nocfg_nosway", "mini_batch", "mini_edit", "mini_prosody", "mini_noref", "mini_grl_prosody", "mini_grl_shuffle", "full_plain"]
+GOLDEN_CASES = ["mini_plain", "mini_nocfg_nosway", "mini_batch", "mini_edit", "mini_prosody", "mini_noref", "mini_noref_prosody", "mini_grl_prosody", "mini_grl_shuffle", "full_plain"]
 
 
 def _load(golden_dir, name):

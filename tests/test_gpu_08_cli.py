@@ -96,3 +96,57 @@ def test_string_frontend_needs_a_registered_factory(tmp_path, monkeypatch):
         assert isinstance(tts.frontend, _FE) and tts.frontend.dtype == "phone"
     finally:
         A.set_frontend_factory(None)
+
+
+def test_cli_default_usage_reaches_the_string_frontend_through_a_named_factory(tmp_path, monkeypatch):
+    """The reference's default usage is ``--ref_text ... --text ...`` with ``--frontend phone`` (scripts/tts_multilingual.py:175-296,
+    api.py:140-151).  The text frontend is host Python outside this package, so the entry point takes its factory by NAME
+    (``--frontend_factory module:callable`` or LEMAS_FRONTEND_FACTORY): with one, plain text in -> wav out; the result is what the same
+    phones give through ``--ref_phones/--phones``."""
+    import sys
+    import lemas_tts_amd.api as A
+    import lemas_tts_amd.scripts.tts_multilingual as M
+    from lemas_tts_amd.infer.audio_io import load_wav, save_wav
+    depth = 1
+    root = _assets(tmp_path, depth)
+    monkeypatch.setattr(M, "PRETRAINED_ROOT", root)
+    monkeypatch.setattr(M, "CKPTS_ROOT", root / "ckpts")
+    real_cfg = A.load_arch_config
+    monkeypatch.setattr(A, "load_arch_config", lambda m: {**real_cfg(m), "arch": {**real_cfg(m)["arch"], "depth": depth}})
+    monkeypatch.setattr(A, "FRONTEND_FACTORY", None)
+    # a stand-in frontend in its own module: words -> phone tokens of the synthetic vocabulary ("p<len(word)>" per word, "p1" for '.')
+    (tmp_path / "fake_frontend.py").write_text(
+        "class Norm:\n"
+        "    def __init__(self, dtype):\n"
+        "        self.dtype = dtype\n"
+        "    def text2phn(self, text):\n"
+        "        toks = []\n"
+        "        for w in text.replace('.', ' . ').split():\n"
+        "            toks.append('p1' if w == '.' else 'p%d' % (2 + len(w) % 50))\n"
+        "        return '|'.join(toks)\n")
+    monkeypatch.syspath_prepend(str(tmp_path))
+    t = np.arange(int(1.2 * 24000)) / 24000.0
+    save_wav(tmp_path / "ref.wav", 0.05 * np.sin(2 * np.pi * 200 * t)[:, None], 24000, "PCM_16")
+    common = ["--ref_audio", str(tmp_path / "ref.wav"), "--nfe_step", "2", "--cfg_strength", "2.0", "--sway_sampling_coef", "5",
+              "--seed", "7", "--use_ema"]
+    try:
+        # no factory anywhere: the reference's default command line fails loudly, naming the remedy
+        monkeypatch.delenv("LEMAS_FRONTEND_FACTORY", raising=False)
+        with pytest.raises(TypeError, match="frontend_factory"):
+            M.main(common + ["--ref_text", "hello there", "--text", "good morning everyone", "--output_wave", str(tmp_path / "x.wav")])
+        rc = M.main(common + ["--ref_text", "hello there", "--text", "good morning everyone", "--output_wave", str(tmp_path / "a.wav"),
+                              "--frontend_factory", "fake_frontend:Norm"])
+        assert rc == 0
+        A.set_frontend_factory(None)
+        monkeypatch.setenv("LEMAS_FRONTEND_FACTORY", "fake_frontend:Norm")          # the environment form
+        assert M.main(common + ["--ref_text", "hello there", "--text", "good morning everyone", "--output_wave", str(tmp_path / "b.wav")]) == 0
+    finally:
+        A.set_frontend_factory(None)
+        sys.modules.pop("fake_frontend", None)
+    import fake_frontend
+    fe = fake_frontend.Norm("phone")
+    rc = M.main(common + ["--ref_phones", fe.text2phn("hello there. "), "--phones", fe.text2phn("good morning everyone. "),
+                          "--output_wave", str(tmp_path / "c.wav")])
+    assert rc == 0
+    a, b, c = (load_wav(tmp_path / n)[0].numpy() for n in ("a.wav", "b.wav", "c.wav"))
+    assert a.shape[1] > 2400 and np.array_equal(a, b) and np.array_equal(a, c)

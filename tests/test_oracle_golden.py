@@ -14,7 +14,7 @@ from lemas_tts_amd import synth
 from lemas_tts_amd.model.layout import DiTArch
 from oracle import lemas_oracle as O
 
-CASES = ["mini_plain", "mini_nocfg_nosway", "mini_batch", "mini_edit", "mini_prosody", "mini_noref", "mini_grl_prosody", "mini_grl_shuffle", "full_plain"]
+CASES = ["mini_plain", "mini_nocfg_nosway", "mini_batch", "mini_edit", "mini_prosody", "mini_noref", "mini_noref_prosody", "mini_grl_prosody", "mini_grl_shuffle", "full_plain"]
 ATOL = 5e-5   # measured max |err| 3.7e-6 (fp32 vs fp32, different summation order); |out| ~ 1.8
 
 
