@@ -193,6 +193,12 @@ def main():
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         sys.exit(spawn_ranks(a.gpus))
 
+    # stdout carries ONE line, the JSON record: everything else that lands on file descriptor 1 from here on (the RCCL / Gloo banners
+    # are printed by C code) goes to stderr, and the record is written to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -449,11 +455,13 @@ def main():
                                       "note": "launch-/latency-bound at batch 1: ~60 small fp32 launches for 25 GFLOP"}
         if not a.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(sd_host, vsd_host, arch, w)
-    if rank == 0:
-        print(json.dumps(result), flush=True)
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    if rank == 0:
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
+    os.close(json_fd)
 
 
 if __name__ == "__main__":

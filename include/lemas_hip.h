@@ -103,7 +103,8 @@ int lemas_dit_finalize(lemas_dit* m);
  * "dual" (1 = run the two CFG branches as concurrent lanes on two streams / graph branches, default 1),
  * "fp8" (1 = the DiT block GEMMs run on fp8-e4m3 MFMA: e4m3 weights with one fp32 scale per output channel, MXFP8
  *        activations (one E8M0 scale per 32 K); attention, norms, residual stream and ODE state unchanged; default 0;
- *        takes effect at the next prepare()/sample()),
+ *        takes effect at the next prepare()/sample().  2 = accuracy point, not a speed path: the same e4m3 weights with bf16
+ *        ACTIVATIONS (weights-only fp8), computed by the bf16 kernels on the dequantised weights),
  * "ln_fused" (1 = the AdaLN LayerNorms that follow the gated residual updates (modules.py:637, the next block's :314, the final
  *        :335) run as the tail of the out-projection / FF2 launches whenever all workgroups of those launches fit the chip at
  *        once; default 0 = separate ln_mod launches: the fused form measured slower),

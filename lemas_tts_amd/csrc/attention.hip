@@ -96,6 +96,8 @@ constexpr int STAGE2 = 4 * TILE;
 //      on the merged rows: l and O finite and l >= 2^-90 (a row whose largest weight sits near the bottom of the fp32 range would
 //      lose its small weights to underflow); otherwise the workgroup runs the loop again classically.  |logit| < ~60 nats never
 //      trips it.  Per tile this leaves 32 v_exp + 16 v_cvt_pk + the row-sum adds: no multiply-add, no max tree, no exchange.
+//  32 / 64 / 128 / 256 / 512  ABLATIONS for measurement only (wrong results): no v_exp (one FMA instead) / no P.V MFMAs / no K,V DMA after
+//      the first pair / no s_barrier in the pair hand-off / no vmcnt wait either.  What each removes is that resource's share of the loop.
 //   2  static priority for the younger half of the workgroup (waves 4-7), no per-cluster flips
 //   4  s_setprio 1 around the MFMA clusters
 template <int VAR>
@@ -170,8 +172,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   // LDS address is base register + immediate
   // One pair of the ring = sync (the pair's DMA has landed for every wave; the next pair is requested) + compute (this wave's tile).
   auto sync = [&](int i, int sg) __attribute__((always_inline)) {
-    wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
+    if constexpr ((VAR & 512) == 0) wait_vmcnt<0>();
+    if constexpr ((VAR & (256 | 512)) == 0) __builtin_amdgcn_s_barrier();
+    if constexpr ((VAR & 128) != 0) { if (i >= 1) return; }
     if (i + 1 < nsup) issue(sg ^ 1, i + 1);
   };
   // sg_c: ring stage, an integral_constant inside the unrolled loops (every LDS address is then base register + immediate) or a
@@ -245,7 +248,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-          f32x2 pv = {__builtin_amdgcn_exp2f(s[t][r]), __builtin_amdgcn_exp2f(s[t][r + 1])};
+          f32x2 pv;
+          if constexpr ((VAR & 32) != 0) pv = f32x2{s[t][r] * 1.0e-3f + 1.0f, s[t][r + 1] * 1.0e-3f + 1.0f};
+          else pv = f32x2{__builtin_amdgcn_exp2f(s[t][r]), __builtin_amdgcn_exp2f(s[t][r + 1])};
           ps += pv;
           pb[t][r >> 3][r & 7] = (bf16_t)pv[0];
           pb[t][r >> 3][(r & 7) + 1] = (bf16_t)pv[1];
@@ -279,6 +284,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // P.V keeps the compiler's schedule (single-buffered V^T fragments, softmax tail interleaved with the MFMAs): a second
     // fragment buffer here lifts the kernel to 138 VGPRs and costs the fourth wave per SIMD (measured 51.8 vs 45.7 us)
     const char* sV = smem + SG * STAGE2 + grp * 2 * TILE + TILE;
+    if constexpr ((VAR & 64) != 0) {       // ablation: P stays live, no V reads, no P.V MFMAs
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) asm volatile("" ::"v"(pb[t][h]));
+      return true;
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       bf16x8 a[2];
@@ -450,6 +462,8 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
   switch (p.variant) {
     LEMAS_ATTN_LAUNCH(0) LEMAS_ATTN_LAUNCH(1) LEMAS_ATTN_LAUNCH(2) LEMAS_ATTN_LAUNCH(3) LEMAS_ATTN_LAUNCH(4) LEMAS_ATTN_LAUNCH(5)
     LEMAS_ATTN_LAUNCH(7) LEMAS_ATTN_LAUNCH(8) LEMAS_ATTN_LAUNCH(10) LEMAS_ATTN_LAUNCH(17) LEMAS_ATTN_LAUNCH(19)
+    LEMAS_ATTN_LAUNCH(17 + 32) LEMAS_ATTN_LAUNCH(17 + 64) LEMAS_ATTN_LAUNCH(17 + 128) LEMAS_ATTN_LAUNCH(17 + 256) LEMAS_ATTN_LAUNCH(17 + 256 + 512)
+    LEMAS_ATTN_LAUNCH(17 + 128 + 256 + 512)
     default: return hipErrorInvalidValue;
   }
 #undef LEMAS_ATTN_LAUNCH

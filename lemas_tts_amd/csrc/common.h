@@ -189,6 +189,8 @@ hipError_t launch_ln_mod_f8(const float* x, uint8_t* out8, uint8_t* mx, int M, i
 hipError_t launch_mx_quant_rows(const float* x, int M, int K, uint8_t* out8, uint8_t* mx, hipStream_t s);
 // weights [N][K] fp32 -> e4m3 with one fp32 scale per row (scale = amax / 448; 0-rows get scale 1)
 hipError_t launch_w_quant_f8(const float* w, int N, int K, uint8_t* out8, float* scale, hipStream_t s);
+// and back: bf16(e4m3 * scale[row]) -- the weights-only-fp8 accuracy point runs the bf16 kernels on these
+hipError_t launch_f8_to_bf16(const uint8_t* w8, const float* scale, int N, int K, bf16_t* out, hipStream_t s);
 
 struct ConvPosParams {
   const float* in_f32;    // conv1 input  [B2*N, C] fp32 (nullptr when in_bf16 is used)

@@ -27,6 +27,7 @@ static const char* kProfNames[PC_COUNT] = {"inproj_f32", "convpos", "ln_mod", "g
 struct BlockW {
   DevBuf wqkv, wo, w1, w2;  // bf16
   DevBuf wqkv8, wo8, w18, w28;   // e4m3 copies for the fp8 path (built on first use of option "fp8")
+  DevBuf wqkvq, woq, w1q, w2q;   // option "fp8" = 2: the e4m3 weights dequantised back to bf16 (weights-only fp8, bf16 activations)
   DevBuf sqkv, so, s1, s2;       // fp32 per-output-channel scales
   DevBuf bqkv;              // fp32 [3*inner]
   const float *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
@@ -47,6 +48,10 @@ struct lemas_dit {
   bool qkv_fused = true;    // QK and V projections of a lane in one launch
   bool fp8 = false;         // block GEMMs on the MXFP8 path (BASELINE config 5); weights quantised on first use
   bool fp8_ready = false;
+  // option "fp8" = 2 (an ACCURACY point, not a speed path): BASELINE configs[4] read literally -- "fp8 MFMA weights": the block GEMM weights
+  // are e4m3 with one fp32 scale per output channel, the activations stay bf16.  Run as the bf16 kernels on the dequantised weights: the
+  // same numbers a weights-only fp8 kernel would produce, next to the MXFP8 path that also quantises the activations
+  bool fp8_wonly = false, fp8_wonly_ready = false;
   // measurement options (per engine; changing one drops the cached graphs): explicit tile ids for the block GEMMs with N == 1024 /
   // N == 2048, for the fused QK+V launch, and the XCD block grid of the tile order; 0 = the production choice
   int opt_tile_n1024 = 0, opt_tile_n2048 = 0, opt_tile_qkv = 0, opt_xcd_gx = 0;
@@ -100,7 +105,7 @@ struct lemas_dit {
             &d_abf, &d_ff, &d_cmid, &d_pred, &d_h8, &d_hmx, &d_a8, &d_amx, &d_ff8, &d_ffmx, &d_lncnt};
   }
   static std::vector<DevBuf*> block_bufs(BlockW& b) {
-    return {&b.wqkv, &b.wo, &b.w1, &b.w2, &b.bqkv, &b.wqkv8, &b.wo8, &b.w18, &b.w28, &b.sqkv, &b.so, &b.s1, &b.s2};
+    return {&b.wqkv, &b.wo, &b.w1, &b.w2, &b.bqkv, &b.wqkv8, &b.wo8, &b.w18, &b.w28, &b.sqkv, &b.so, &b.s1, &b.s2, &b.wqkvq, &b.woq, &b.w1q, &b.w2q};
   }
   void drop_graphs() {
     for (auto& g : graphs) (void)hipGraphExecDestroy(g.second);
@@ -140,6 +145,7 @@ struct lemas_dit {
   void declare_schema();
   int finalize();
   int quantize_fp8();
+  int dequantize_fp8();
   int prepare(const lemas_sample_args* a, hipStream_t s);
   int solve(const lemas_sample_args* a, hipStream_t s);
   int enqueue_forward(hipStream_t s);
@@ -265,6 +271,27 @@ int lemas_dit::quantize_fp8() {
   return 0;
 }
 
+// option "fp8" = 2: bf16 images of the e4m3-quantised weights (value = e4m3 * per-channel scale, rounded to bf16)
+int lemas_dit::dequantize_fp8() {
+  if (fp8_wonly_ready) return 0;
+  RC_TRY(quantize_fp8());
+  const int d = cfg.dim, in = inner(), ffd = cfg.ff_mult * d;
+  hipStream_t s = nullptr;
+  for (auto& b : blocks) {
+    RC_TRY(b.wqkvq.ensure((size_t)3 * in * d * 2));
+    HIP_TRY(launch_f8_to_bf16(b.wqkv8.as<uint8_t>(), b.sqkv.as<float>(), 3 * in, d, b.wqkvq.as<bf16_t>(), s));
+    RC_TRY(b.woq.ensure((size_t)d * in * 2));
+    HIP_TRY(launch_f8_to_bf16(b.wo8.as<uint8_t>(), b.so.as<float>(), d, in, b.woq.as<bf16_t>(), s));
+    RC_TRY(b.w1q.ensure((size_t)ffd * d * 2));
+    HIP_TRY(launch_f8_to_bf16(b.w18.as<uint8_t>(), b.s1.as<float>(), ffd, d, b.w1q.as<bf16_t>(), s));
+    RC_TRY(b.w2q.ensure((size_t)d * ffd * 2));
+    HIP_TRY(launch_f8_to_bf16(b.w28.as<uint8_t>(), b.s2.as<float>(), d, ffd, b.w2q.as<bf16_t>(), s));
+  }
+  HIP_TRY(hipStreamSynchronize(s));
+  fp8_wonly_ready = true;
+  return 0;
+}
+
 int lemas_dit::finalize() {
   RC_TRY(ws.check_complete());
   const int d = cfg.dim, in = inner(), ffd = cfg.ff_mult * d;
@@ -280,6 +307,7 @@ int lemas_dit::finalize() {
   for (auto& b : blocks)
     for (DevBuf* w : block_bufs(b)) w->moved = &moved;
   fp8_ready = false;
+  fp8_wonly_ready = false;
   for (int i = 0; i < cfg.depth; ++i) {
     const std::string p = T("transformer_blocks." + std::to_string(i) + ".");
     BlockW& b = blocks[i];
@@ -517,6 +545,7 @@ int lemas_dit::prepare(const lemas_sample_args* a, hipStream_t s) {
   RC_TRY(d_cmid.ensure((size_t)rows * d * 2));
   RC_TRY(d_pred.ensure((size_t)rows * md * 4));
   RC_TRY(d_lncnt.ensure((size_t)cfg.depth * 2 * 2 * (rows / 64 + 1) * sizeof(unsigned int)));   // >= [block][site][lane][panel of >= 64 rows]
+  if (fp8_wonly) RC_TRY(dequantize_fp8());
   if (fp8) {
     RC_TRY(quantize_fp8());
     RC_TRY(d_h8.ensure((size_t)rows * d));
@@ -645,12 +674,12 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     auto tile_for = [&](int n) { return fp8 ? 0 : n == 1024 ? opt_tile_n1024 : n == 2048 ? opt_tile_n2048 : 0; };
     // A / W / their scales for one GEMM: bf16 operands, or (fp8) MXFP8 activations x per-channel-scaled e4m3 weights
     auto operands = [&](const bf16_t* abf16, const uint8_t* af8, const uint8_t* afmx, const DevBuf& wb, const DevBuf& w8, const DevBuf& wsc,
-                        size_t row_off, int K) {
+                        const DevBuf& wq, size_t row_off, int K) {
       if (fp8) {
         g.A = reinterpret_cast<const bf16_t*>(af8); g.a_mx = afmx;
         g.W = reinterpret_cast<const bf16_t*>(w8.as<uint8_t>() + row_off * K); g.w_scale = wsc.as<float>() + row_off;
       } else {
-        g.A = abf16; g.W = wb.as<bf16_t>() + row_off * K;
+        g.A = abf16; g.W = (fp8_wonly ? wq.as<bf16_t>() : wb.as<bf16_t>()) + row_off * K;
       }
     };
     if (!(fuse_ln && l > 0)) {      // fused: block l's attn_norm rows were written by block l-1's FF2 launch
@@ -666,10 +695,10 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     if (fuse_qkv) {
       GemmParams gq = g, gv = g;
       RC_TRY(pkernel(PC_GEMM_QKV, &gq.ev_start, &gq.ev_stop));
-      operands(hbf, h8, hmx, w.wqkv, w.wqkv8, w.sqkv, 0, d);
+      operands(hbf, h8, hmx, w.wqkv, w.wqkv8, w.sqkv, w.wqkvq, 0, d);
       gq.A = g.A; gq.a_mx = g.a_mx; gq.W = g.W; gq.w_scale = g.w_scale;
       gq.bias = w.bqkv.as<float>(); gq.N = 2 * in; gq.K = d; gq.n_valid = 2 * in; gq.kv_len = nullptr;
-      operands(hbf, h8, hmx, w.wqkv, w.wqkv8, w.sqkv, (size_t)2 * in, d);
+      operands(hbf, h8, hmx, w.wqkv, w.wqkv8, w.sqkv, w.wqkvq, (size_t)2 * in, d);
       gv.A = g.A; gv.a_mx = g.a_mx; gv.W = g.W; gv.w_scale = g.w_scale;
       gv.bias = w.bqkv.as<float>() + 2 * in; gv.N = in; gv.K = d; gv.n_valid = in; gv.kv_len = nullptr;
       gq.tile = gv.tile = opt_tile_qkv;
@@ -681,13 +710,13 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
       g.K = d;
     } else {
       RC_TRY(pkernel(PC_GEMM_QK, &g.ev_start, &g.ev_stop));
-      operands(hbf, h8, hmx, w.wqkv, w.wqkv8, w.sqkv, 0, d);
+      operands(hbf, h8, hmx, w.wqkv, w.wqkv8, w.sqkv, w.wqkvq, 0, d);
       g.bias = w.bqkv.as<float>(); g.N = 2 * in; g.K = d; g.n_valid = 2 * in;
       g.kv_len = nullptr; g.tile = tile_for(g.N);
       TL_SLOT(g);
       HIP_TRY(launch_gemm_bf16(EPI_QK_ROPE, g, q));
       RC_TRY(pkernel(PC_GEMM_V, &g.ev_start, &g.ev_stop));
-      operands(hbf, h8, hmx, w.wqkv, w.wqkv8, w.sqkv, (size_t)2 * in, d);
+      operands(hbf, h8, hmx, w.wqkv, w.wqkv8, w.sqkv, w.wqkvq, (size_t)2 * in, d);
       g.bias = w.bqkv.as<float>() + 2 * in; g.N = in; g.n_valid = in; g.tile = tile_for(g.N);
       TL_SLOT(g);
       HIP_TRY(launch_gemm_bf16(EPI_V_T, g, q));
@@ -697,7 +726,7 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     TL_SLOT(at);
     HIP_TRY(launch_attention(at, q));
     RC_TRY(pkernel(PC_GEMM_OUT, &g.ev_start, &g.ev_stop));
-    operands(abf, a8, amx, w.wo, w.wo8, w.so, 0, in);
+    operands(abf, a8, amx, w.wo, w.wo8, w.so, w.woq, 0, in);
     g.bias = w.bo; g.N = d; g.K = in; g.n_valid = d;
     g.out_f32 = xres; g.ldc = d; g.gate_off = base + 2 * d; g.kv_len = has_len ? d_len.as<int>() : nullptr; g.tile = tile_for(g.N);
     if (fuse_ln) {   // ff_norm (modules.py:637) as the tail of the out-projection launch
@@ -713,13 +742,13 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
       RC_TRY(pend(q));
     }
     RC_TRY(pkernel(PC_GEMM_FF1, &g.ev_start, &g.ev_stop));
-    operands(hbf, h8, hmx, w.w1, w.w18, w.s1, 0, d);
+    operands(hbf, h8, hmx, w.w1, w.w18, w.s1, w.w1q, 0, d);
     g.bias = w.b1; g.N = ffd; g.K = d; g.n_valid = ffd;
     g.out_bf16 = ffb; g.out_f8 = ff8; g.out_mx = ffmx; g.ldc = ffd; g.kv_len = nullptr; g.tile = tile_for(g.N);
     TL_SLOT(g);
     HIP_TRY(launch_gemm_bf16(fp8 ? EPI_BIAS_GELU_F8 : EPI_BIAS_GELU_BF16, g, q));
     RC_TRY(pkernel(PC_GEMM_FF2, &g.ev_start, &g.ev_stop));
-    operands(ffb, ff8, ffmx, w.w2, w.w28, w.s2, 0, ffd);
+    operands(ffb, ff8, ffmx, w.w2, w.w28, w.s2, w.w2q, 0, ffd);
     g.bias = w.b2; g.N = d; g.K = ffd; g.n_valid = d;
     g.out_f32 = xres; g.ldc = d; g.gate_off = base + 5 * d; g.tile = tile_for(g.N);
     if (fuse_ln) {   // the next block's attn_norm (modules.py:314: shift, scale first), or the final norm (:335: scale, shift) after the last
@@ -795,7 +824,7 @@ int lemas_dit::solve(const lemas_sample_args* a, hipStream_t s) {
       graph_generation = moved;
     }
     char key[96];
-    snprintf(key, sizeof key, "B%d_N%d_cfg%d_len%d_dual%d_f8%d_ln%d", B, N, (int)use_cfg, (int)has_len, (int)dual, (int)fp8, (int)ln_fused);
+    snprintf(key, sizeof key, "B%d_N%d_cfg%d_len%d_dual%d_f8%d_ln%d", B, N, (int)use_cfg, (int)has_len, (int)dual, fp8 ? 1 : fp8_wonly ? 2 : 0, (int)ln_fused);
     auto it = graphs.find(key);
     if (it == graphs.end()) {
       if (graphs.size() >= 32) drop_graphs();   // a serving process sees a new length almost every utterance: bound the cache (a capture costs ~3 ms)
@@ -893,8 +922,10 @@ int lemas_dit_set_option(lemas_dit* m, const char* key, int64_t value) {
     return 0;
   }
   if (!strcmp(key, "fp8")) {      // block GEMMs on the MXFP8 path; takes effect at the next prepare()
-    if (m->fp8 != (value != 0)) m->prepared = false;
-    m->fp8 = value != 0;
+    if (value < 0 || value > 2) { set_error("lemas_dit_set_option: fp8 is 0 (bf16), 1 (MXFP8 GEMMs) or 2 (weights-only fp8 accuracy point)"); return LEMAS_E_ARG; }
+    if (m->fp8 != (value == 1) || m->fp8_wonly != (value == 2)) m->prepared = false;
+    m->fp8 = value == 1;
+    m->fp8_wonly = value == 2;
     return 0;
   }
   if (!strcmp(key, "profile")) {

@@ -133,6 +133,23 @@ __global__ __launch_bounds__(256) void w_quant_f8_kernel(const float* __restrict
   if (lane == 0) scale[row] = sc;
 }
 
+// e4m3 weights [N][K] with a per-row fp32 scale -> bf16 (the value the fp8 MFMA would see, in the bf16 kernels' operand format)
+__global__ __launch_bounds__(256) void f8_to_bf16_kernel(const uint8_t* __restrict__ w8, const float* __restrict__ scale, int N, int K,
+                                                         bf16_t* __restrict__ out) {
+  const size_t total = (size_t)N * (K / 4);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int row = (int)(i / (K / 4));
+    const int packed = reinterpret_cast<const int*>(w8)[i];
+    const float sc = scale[row];
+    bf16x4 o;
+    o[0] = (bf16_t)(__builtin_amdgcn_cvt_f32_fp8(packed, 0) * sc);
+    o[1] = (bf16_t)(__builtin_amdgcn_cvt_f32_fp8(packed, 1) * sc);
+    o[2] = (bf16_t)(__builtin_amdgcn_cvt_f32_fp8(packed, 2) * sc);
+    o[3] = (bf16_t)(__builtin_amdgcn_cvt_f32_fp8(packed, 3) * sc);
+    reinterpret_cast<bf16x4*>(out)[i] = o;
+  }
+}
+
 __global__ __launch_bounds__(256) void cfg_euler_kernel(float* __restrict__ y, const float* __restrict__ pred, int rows,
                                                         int cols, const float* __restrict__ dt_tab,
                                                         const float* __restrict__ cfg_tab, int* step_idx,
@@ -230,6 +247,12 @@ hipError_t launch_mx_quant_rows(const float* x, int M, int K, uint8_t* out8, uin
 hipError_t launch_w_quant_f8(const float* w, int N, int K, uint8_t* out8, float* scale, hipStream_t s) {
   if (K % 4 != 0 || N <= 0) return hipErrorInvalidValue;
   hipLaunchKernelGGL(w_quant_f8_kernel, dim3((N + 3) / 4), dim3(256), 0, s, w, N, K, out8, scale);
+  return hipGetLastError();
+}
+
+hipError_t launch_f8_to_bf16(const uint8_t* w8, const float* scale, int N, int K, bf16_t* out, hipStream_t s) {
+  if (K % 4 != 0 || N <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(f8_to_bf16_kernel, dim3(grid_for((size_t)N * (K / 4))), dim3(256), 0, s, w8, scale, N, K, out);
   return hipGetLastError();
 }
 

@@ -99,8 +99,8 @@ class CFM:
         self.prosody_encoder = prosody_encoder   # model.prosody_encoder.ProsodyEncoder (cfm.py:139-145), or None: embeds are inputs
         self.odeint_kwargs = odeint_kwargs
         self.engine = DiTEngine(arch, vocab_size, state_dict, device=device, prosody=use_prosody_encoder)
-        if fp8_weights:      # BASELINE config 5: block GEMMs on fp8-e4m3 MFMA (MXFP8 activations, per-channel weight scales)
-            self.engine.set_option("fp8", 1)
+        if fp8_weights:      # BASELINE config 5: block GEMMs on fp8-e4m3 MFMA (MXFP8 activations, per-channel weight scales); 2 = the
+            self.engine.set_option("fp8", 2 if fp8_weights == 2 else 1)     # weights-only accuracy point (bf16 activations)
 
     @property
     def device(self):

@@ -40,10 +40,11 @@ def _reference_y0(seed: int, durations) -> torch.Tensor:
 
 
 def run_case(name, arch, *, wseed, B, F, lens, Nt, duration, steps, cfg, coef, noise_seed,
-             edit_spans=None, prosody=False, use_acc_grl=False, no_ref_audio=False, ref_ratio=1, pyseed=None, store_traj=True):
+             edit_spans=None, prosody=False, use_acc_grl=False, no_ref_audio=False, ref_ratio=1, pyseed=None, store_traj=True,
+             outlier=None):
     if ONLY is not None and name not in ONLY:
         return
-    sd_np = synth.synth_cfm_state_dict(arch, VOCAB, wseed, prosody=prosody)
+    sd_np = synth.synth_cfm_state_dict(arch, VOCAB, wseed, prosody=prosody, outlier=outlier)
     sd = {k: torch.from_numpy(v) for k, v in sd_np.items()}
     cfm = ref_shims.build_reference_cfm(arch.reference_kwargs(), VOCAB, sd, use_prosody=prosody)
 
@@ -156,6 +157,8 @@ def run_case(name, arch, *, wseed, B, F, lens, Nt, duration, steps, cfg, coef, n
         fx["ref_ratio"] = np.float64(ref_ratio)
     if pyseed is not None:
         fx["pyseed"] = np.int64(pyseed)
+    if outlier is not None:
+        fx["outlier"] = np.asarray(outlier, dtype=np.float64)
     np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), **fx)
     print(f"{name}: N={N} steps={steps} ref {dt:.1f}s |out| mean {out.abs().mean():.4f} "
           f"traj[-1] std {traj[-1].std():.4f}")
@@ -242,6 +245,9 @@ def main():
         run_edit_mask_cases()
         run_prosody_case("prosody_enc_short", 17, 41)
         run_prosody_case("prosody_enc_10s", 18, 998)
+    # activation-outlier stress for the fp8 path (synth.synth_cfm_state_dict outlier=): 1 % of the residual channels x30, all 22 blocks
+    run_case("full_outlier", FULL, wseed=23, B=1, F=150, lens=None, Nt=[60], duration=400, steps=8,
+             cfg=2.0, coef=5, noise_seed=111, outlier=(0.01, 30.0), store_traj=False)
     run_case("full_plain", FULL, wseed=16, B=1, F=150, lens=None, Nt=[60], duration=400, steps=3,
              cfg=2.0, coef=5, noise_seed=106)
 

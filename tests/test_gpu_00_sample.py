@@ -21,7 +21,8 @@ GOLDEN_CASES = ["mini_plain", "mini_nocfg_nosway", "mini_batch", "mini_edit", "m
 def _load(golden_dir, name):
     fx = dict(np.load(os.path.join(golden_dir, name + ".npz")))
     arch = DiTArch(depth=int(fx["arch_depth"]))
-    sd = synth.synth_cfm_state_dict(arch, int(fx["vocab"]), int(fx["wseed"]), prosody=bool(fx["prosody"]))
+    sd = synth.synth_cfm_state_dict(arch, int(fx["vocab"]), int(fx["wseed"]), prosody=bool(fx["prosody"]),
+                                    outlier=tuple(fx["outlier"]) if "outlier" in fx else None)
     assert abs(synth.checksum(sd) - float(fx["wchecksum"])) < 1e-6 * abs(float(fx["wchecksum"])), "RNG drift"
     return fx, arch, sd
 
