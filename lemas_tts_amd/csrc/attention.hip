@@ -363,7 +363,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       if (lane == 0) flags[wq] = bad ? 1 : 0;
     }
     __syncthreads();                                   // xch consumed, flags visible
-    if (__builtin_expect((flags[0] | flags[1] | flags[2] | flags[3]) != 0, 0)) {
+    if (__builtin_expect((VAR < 32) && (flags[0] | flags[1] | flags[2] | flags[3]) != 0, 0)) {     // (ablation builds never redo)
       restart();
       key_loop(std::false_type{}, std::false_type{});
       merge();

@@ -166,6 +166,33 @@ def test_fp8_sampler_vs_emulation_and_reference_golden(golden_dir, name):
     assert mse_ref <= tol, mse_ref
 
 
+@pytest.mark.parametrize("name,bounds", [
+    # (bf16, MXFP8 weights + activations, fp8 weights only): stated bounds = ~2.5x the measured values in profiles/r03_fp8_points.txt
+    ("full_plain", (4e-5, 1e-3, 2.5e-4)),            # measured 1.3e-5 / 3.7e-4 / 8.4e-5 (3-step solve: see above)
+    ("full_outlier", (2e-5, 1.6e-3, 6e-4)),          # measured 6.3e-6 / 6.4e-4 / 2.4e-4
+])
+def test_fp8_cost_of_quantising_activations_and_outlier_stress(golden_dir, name, bounds):
+    """BASELINE configs[4] says "fp8 MFMA weights"; the fp8 path of this build also quantises the ACTIVATIONS (MXFP8) because that is
+    what the fp8 MFMA wants.  Both points against the REFERENCE's own output, on the plain synthetic weights and on activation-outlier
+    stress weights (1 % of the residual channels x30 in all 22 blocks, synth.synth_cfm_state_dict(outlier=...), fixture generated
+    through the reference with the same weights): option fp8 = 1 (weights + activations) and fp8 = 2 (weights only, bf16
+    activations; an accuracy point computed by the bf16 kernels on the dequantised weights).  With outlier channels NEITHER meets
+    the 1e-4 target of north_star -- stated in DESIGN.md section 2; the bf16 path is untouched by them."""
+    import test_gpu_00_sample as T
+    from lemas_tts_amd.model.cfm import CFM
+    fx, arch, sd = T._load(golden_dir, name)
+    m = CFM(arch, int(fx["vocab"]), sd, device=DEV)
+    args, kw = _golden_args(fx)
+    got = {}
+    for mode in (0, 1, 2):
+        m.engine.set_option("fp8", mode)
+        out, _ = m.sample(*args, use_acc_grl=False, **kw)
+        got[mode] = T._gen_mse(out.cpu().numpy(), fx["out"], fx)
+    print(f"\n[fp8 points {name}] mel-MSE vs reference: bf16 {got[0]:.3e}  MXFP8 weights+activations {got[1]:.3e}  fp8 weights only {got[2]:.3e}")
+    assert got[0] <= bounds[0] and got[1] <= bounds[1] and got[2] <= bounds[2], got
+    assert got[0] < got[2] < got[1], got          # each step of quantisation costs accuracy: bf16 < weights-only < weights + activations
+
+
 # The full-depth, NFE-32 tolerance of the fp8 path is checked at FULL SIZE against the reference's own output in
 # tests/test_gpu_06_configs.py::test_configs1_full_size_full_nfe_vs_the_reference (mel-MSE 4.2e-5 against the 1e-4 target); the
 # round-1 form of that check (N = 300 against a 2-minute oracle run on the GPU box's host cores) was dropped for it.

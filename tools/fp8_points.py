@@ -41,4 +41,4 @@ def main(names):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1:] or ["full_plain", "full_outlier", "configs1_nfe32", "configs4_edit_nfe48"])
+    main(sys.argv[1:] or ["full_plain", "full_outlier", "configs1_nfe32"])
