@@ -341,8 +341,9 @@ def main():
                                    + " / fp32 state, Vocos decode + D2H included",
                        "workload_key": a.workload,
                        "utterances_per_gpu_per_step": B, "audio_seconds_per_step": audio_per_step,
-                       "utterances_total": world * B * a.steps, "utterances_per_step_all_gpus": world * B,
+                       "utterances_total": world * B, "utterances_timed": world * B * a.steps,     # the job's utterances per step / in the timed region
                        "audio_seconds_per_rank": a.steps * audio_per_step,
+                       "per_rank_audio_seconds": [a.steps * audio_per_step] * world,                  # weak scaling: the same work on every rank
                        "pipelining": ("vocoder + D2H of utterance i on a side stream under the step loop of utterance i+1"
                                       if a.overlap else "none (strictly serial)"),
                        "parallelism": f"dp{world} ({world} process(es), one per GPU; utterance sharding, RCCL weight broadcast into "

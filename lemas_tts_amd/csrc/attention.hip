@@ -94,8 +94,15 @@ constexpr int STAGE2 = 4 * TILE;
 //      fp32 before the bf16 rounding, GemmParams::q_scale) and P = exp2(S) is taken as it comes out of the MFMA -- softmax is
 //      invariant to the per-query offset, so the offset only ever served the number range.  The range is checked once per workgroup
 //      on the merged rows: l and O finite and l >= 2^-90 (a row whose largest weight sits near the bottom of the fp32 range would
-//      lose its small weights to underflow); otherwise the workgroup runs the loop again classically.  |logit| < ~60 nats never
-//      trips it.  Per tile this leaves 32 v_exp + 16 v_cvt_pk + the row-sum adds: no multiply-add, no max tree, no exchange.
+//      lose its small weights to underflow); otherwise the workgroup goes round again as a TWO-PASS softmax: a max-only sweep over
+//      the keys (QK MFMAs + max tree, nothing else) fixes every row's true maximum, then the same fast loop with P = exp2(S - max).
+//      |logit| < ~60 nats never trips it.  Per tile the fast loop has 32 v_exp + 16 v_cvt_pk + the row-sum adds: no multiply-add, no
+//      max tree, no exchange.  (The fallback used to be the classical online-softmax loop: correct, but its live ranges sat on the
+//      fast loop's register allocation -- with the hand-scheduled P.V of bit 1024 that cost 3 us per launch; the two sweeps of the
+//      fallback have the fast loop's own register shape.)
+// 1024 (with 16) P.V hand-scheduled like the K side: V^T fragments are asm reads into a double buffer (the K fragments' dead registers),
+//      requested two 16-key steps ahead, each step = wait for ITS two fragments (exact lgkmcnt) -> 2 MFMAs -> request step e+2 ->
+//      exponentials / bf16 packing of step e+1: the VALU work of the next step issues while the matrix pipe runs this one.
 //  32 / 64 / 128 / 256 / 512  ABLATIONS for measurement only (wrong results): no v_exp (one FMA instead) / no P.V MFMAs / no K,V DMA after
 //      the first pair / no s_barrier in the pair hand-off / no vmcnt wait either.  What each removes is that resource's share of the loop.
 //   2  static priority for the younger half of the workgroup (waves 4-7), no per-cluster flips
@@ -146,9 +153,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int krow = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
   const int ksw = (krow >> 1) & 7, vsw = (l31 >> 1) & 7;
   const unsigned kx0 = krow * 128 + ((hi ^ ksw) << 4);   // k-step kk: kx0 ^ (kk << 5)
-  int vx[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) vx[e] = l31 * 128 + (((2 * e + hi) ^ vsw) << 4);
+  // V^T fragment of 16-key step e: row l31, 16-B chunk (2 e + hi) ^ vsw.  2 e and hi occupy disjoint bits, so the chunk is
+  // (hi ^ vsw) ^ 2 e and the byte offset vx0 ^ (e << 5): ONE register serves the four steps (the K side's trick)
+  const int vx0 = l31 * 128 + ((hi ^ vsw) << 4);
+  auto vx = [&](int e) __attribute__((always_inline)) { return vx0 ^ (e << 5); };
 
   bf16x8 qf[4];
   {
@@ -178,10 +186,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     if (i + 1 < nsup) issue(sg ^ 1, i + 1);
   };
   // sg_c: ring stage, an integral_constant inside the unrolled loops (every LDS address is then base register + immediate) or a
-  // plain int.  fast_c: true = max-free softmax against the running max the wave's first tile fixed (see VAR & 1).
-  auto compute = [&](int i, auto sg_c, auto fast_c) __attribute__((always_inline)) -> bool {
+  // plain int.  mode_c: 0 classical online softmax | 1 fast: P = exp2(S c - m_run) with m_run fixed (see VAR & 1 / 16) | 2 max-only
+  // sweep (m_run = running row maximum, nothing accumulated) | 3 = 1 for VAR & 16 but subtracting m_run (second sweep of the fallback)
+  auto compute = [&](int i, auto sg_c, auto mode_c) __attribute__((always_inline)) -> bool {
     const int SG = sg_c;
-    constexpr bool FAST = decltype(fast_c)::value;
+    constexpr int MODE = decltype(mode_c)::value;
+    constexpr bool FAST = MODE == 1 || MODE == 3;
+    constexpr bool SUB = MODE == 3;
     const int j = 2 * i + grp;
     if (j >= ntiles) return true;
     const unsigned ka = lds_base + SG * STAGE2 + grp * 2 * TILE + kx0;
@@ -220,6 +231,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
           }
       }
     }
+    if constexpr (MODE == 2) {            // max-only sweep: the row maximum over this wave's tiles, in the units of S c
+      float mx = s[0][0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      m_run = fmaxf(m_run, mx * c);
+      return true;
+    }
     const f32x2 c2 = {c, c};
     bf16x8 pb[2][2];
     // P = exp2(s c - m) as bf16 B-operand fragments; returns this lane's partial row sum (the other 32 keys sit in lane ^ 32)
@@ -242,15 +263,56 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     if constexpr ((VAR & 8) != 0) {         // ABLATION ONLY (wrong on large scores): no running max at all
       l_run += exps(0.f);
       m_run = 0.f;
+    } else if constexpr (FAST && (VAR & 16) != 0 && (VAR & 1024) != 0) {
+      const unsigned va = lds_base + SG * STAGE2 + grp * 2 * TILE + TILE;
+      u32x4 fv[2][2];
+      auto vread = [&](int e, u32x4 (&f)[2]) __attribute__((always_inline)) {
+        const unsigned ad = (va + (unsigned)vx0) ^ (unsigned)(e << 5);   // va is a multiple of 8 KiB
+        lds_read_b128<0>(f[0], ad);
+        lds_read_b128<4096>(f[1], ad);
+      };
+      vread(0, fv[0]);
+      vread(1, fv[1]);
+      f32x2 ps = {0.f, 0.f};
+      const f32x2 m2 = {m_run, m_run};
+      bf16x8 pe[2];
+      auto pchunk = [&](int e, bf16x8& dst) __attribute__((always_inline)) {   // keys 16 e .. 16 e + 15: registers 8 (e & 1) .. + 7 of s[e >> 1]
+#pragma unroll
+        for (int r = 0; r < 8; r += 2) {
+          const int q = 8 * (e & 1) + r;
+          f32x2 a = {s[e >> 1][q], s[e >> 1][q + 1]};
+          if constexpr (SUB) a = a - m2;
+          f32x2 pv = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+          ps += pv;
+          dst[r] = (bf16_t)pv[0];
+          dst[r + 1] = (bf16_t)pv[1];
+        }
+      };
+      pchunk(0, pe[0]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        u32x4 (&f)[2] = fv[e & 1];
+        if (e < 3) wait_lgkm_frags<2>(f[0], f[1]);     // the two youngest outstanding reads belong to the next step
+        else wait_lgkm_frags<0>(f[0], f[1]);
+        o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f[0]), pe[e & 1], o[0], 0, 0, 0);
+        o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f[1]), pe[e & 1], o[1], 0, 0, 0);
+        if (e + 2 < 4) vread(e + 2, f);
+        if (e + 1 < 4) pchunk(e + 1, pe[(e + 1) & 1]);
+      }
+      l_run += ps[0] + ps[1];
+      return true;
     } else if constexpr (FAST && (VAR & 16) != 0) {
-      f32x2 ps = {0.f, 0.f};                // P = exp2(S): see VAR & 16
+      f32x2 ps = {0.f, 0.f};                // P = exp2(S) (second sweep of the fallback: exp2(S - m_run)): see VAR & 16
+      const f32x2 m2 = {m_run, m_run};
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
           f32x2 pv;
-          if constexpr ((VAR & 32) != 0) pv = f32x2{s[t][r] * 1.0e-3f + 1.0f, s[t][r + 1] * 1.0e-3f + 1.0f};
-          else pv = f32x2{__builtin_amdgcn_exp2f(s[t][r]), __builtin_amdgcn_exp2f(s[t][r + 1])};
+          f32x2 a = {s[t][r], s[t][r + 1]};
+          if constexpr (SUB) a = a - m2;
+          if constexpr ((VAR & 32) != 0) pv = f32x2{a[0] * 1.0e-3f + 1.0f, a[1] * 1.0e-3f + 1.0f};
+          else pv = f32x2{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
           ps += pv;
           pb[t][r >> 3][r & 7] = (bf16_t)pv[0];
           pb[t][r >> 3][(r & 7) + 1] = (bf16_t)pv[1];
@@ -295,7 +357,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     for (int e = 0; e < 4; ++e) {
       bf16x8 a[2];
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt) a[dt] = *reinterpret_cast<const bf16x8*>(sV + dt * 4096 + vx[e]);
+      for (int dt = 0; dt < 2; ++dt) a[dt] = *reinterpret_cast<const bf16x8*>(sV + dt * 4096 + vx(e));
       if constexpr ((VAR & 4) != 0) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[dt], pb[e >> 1][e & 1], o[dt], 0, 0, 0);
@@ -306,18 +368,33 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   using c0_t = std::integral_constant<int, 0>;
   using c1_t = std::integral_constant<int, 1>;
   ATTN_STAMP(1);
-  // the key loop: pairs of tiles through the 2-stage ring, unrolled by the ring depth.  first_fast_c / later_fast_c: the wave's first
-  // tile / every later one on the max-free path
-  auto key_loop = [&](auto first_fast_c, auto later_fast_c) __attribute__((always_inline)) {
+  // the key loop: pairs of tiles through the 2-stage ring, unrolled by the ring depth.  first_c / later_c: the mode (see compute) of
+  // the wave's first tile / of every later one
+  using classic_t = std::integral_constant<int, 0>;
+  using fast_t = std::integral_constant<int, 1>;
+  using maxonly_t = std::integral_constant<int, 2>;
+  using fastsub_t = std::integral_constant<int, 3>;
+  auto key_loop = [&](auto first_c, auto later_c) __attribute__((always_inline)) {
     issue(0, 0);
     sync(0, 0);
-    compute(0, c0_t{}, first_fast_c);
+    compute(0, c0_t{}, first_c);
     for (int i = 1; i < nsup; i += 2) {
       sync(i, 1);
-      compute(i, c1_t{}, later_fast_c);
-      if (i + 1 < nsup) { sync(i + 1, 0); compute(i + 1, c0_t{}, later_fast_c); }
+      compute(i, c1_t{}, later_c);
+      if (i + 1 < nsup) { sync(i + 1, 0); compute(i + 1, c0_t{}, later_c); }
     }
     __syncthreads();                                   // every wave is done with the ring
+  };
+  // the same loop for the (rare) fallback sweeps: ONE instance of the tile body with the ring stage as a run-time value -- small code
+  // that shares nothing with the unrolled loop above
+  auto key_loop_cold = [&](auto mode_c) __attribute__((always_inline)) {
+    issue(0, 0);
+#pragma clang loop unroll(disable)
+    for (int i = 0; i < nsup; ++i) {
+      sync(i, i & 1);
+      compute(i, i & 1, mode_c);
+    }
+    __syncthreads();
   };
   // merge the two key-parity partials: group 1 parks (m, l, O^T) in LDS, group 0 folds it in
   float* xch = reinterpret_cast<float*>(smem) + (size_t)wq * 64 * 36 + lane * 36;   // 34 floats used per lane, 36 pitch
@@ -351,7 +428,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   int* flags = reinterpret_cast<int*>(smem + 2 * STAGE2);      // behind the ring: no wave's tile reads reach here
   if constexpr ((VAR & 17) == 17) {
     m_run = 0.f;                                       // P = exp2(S) for every tile, the first included (see VAR & 16)
-    key_loop(std::true_type{}, std::true_type{});
+    key_loop(fast_t{}, fast_t{});
     ATTN_STAMP(2);
     merge();
     if (grp == 0) {                                    // range check on the merged rows
@@ -363,14 +440,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       if (lane == 0) flags[wq] = bad ? 1 : 0;
     }
     __syncthreads();                                   // xch consumed, flags visible
-    if (__builtin_expect((VAR < 32) && (flags[0] | flags[1] | flags[2] | flags[3]) != 0, 0)) {     // (ablation builds never redo)
-      restart();
-      key_loop(std::false_type{}, std::false_type{});
+    if (__builtin_expect((VAR & (32 | 64 | 128 | 256 | 512 | 2048)) == 0 && (flags[0] | flags[1] | flags[2] | flags[3]) != 0, 0)) {     // (ablation builds never redo)
+      restart();                                       // two-pass softmax: every row's maximum over this wave's tiles ...
+      key_loop_cold(maxonly_t{});
+      key_loop_cold(fastsub_t{});                      // ... then P = exp2(S - max); the merge below reconciles the two key groups' maxima
       merge();
       __syncthreads();
     }
   } else if constexpr ((VAR & 1) != 0) {
-    key_loop(std::false_type{}, std::true_type{});
+    key_loop(classic_t{}, fast_t{});
     ATTN_STAMP(2);
     // overflow check of the max-free pass (see VAR & 1): anything non-finite in l or O of any wave sends the WORKGROUP round again
     float t = l_run;
@@ -384,12 +462,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     for (int w = 0; w < 8; ++w) redo |= flags[w];
     if (__builtin_expect(redo != 0, 0)) {
       restart();
-      key_loop(std::false_type{}, std::false_type{});
+      key_loop(classic_t{}, classic_t{});
     }
     merge();
     __syncthreads();   // xch fully consumed before the slabs below reuse the LDS
   } else {
-    key_loop(std::false_type{}, std::false_type{});
+    key_loop(classic_t{}, classic_t{});
     ATTN_STAMP(2);
     merge();
     __syncthreads();   // xch fully consumed before the slabs below reuse the LDS
@@ -463,7 +541,8 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
     LEMAS_ATTN_LAUNCH(0) LEMAS_ATTN_LAUNCH(1) LEMAS_ATTN_LAUNCH(2) LEMAS_ATTN_LAUNCH(3) LEMAS_ATTN_LAUNCH(4) LEMAS_ATTN_LAUNCH(5)
     LEMAS_ATTN_LAUNCH(7) LEMAS_ATTN_LAUNCH(8) LEMAS_ATTN_LAUNCH(10) LEMAS_ATTN_LAUNCH(17) LEMAS_ATTN_LAUNCH(19)
     LEMAS_ATTN_LAUNCH(17 + 32) LEMAS_ATTN_LAUNCH(17 + 64) LEMAS_ATTN_LAUNCH(17 + 128) LEMAS_ATTN_LAUNCH(17 + 256) LEMAS_ATTN_LAUNCH(17 + 256 + 512)
-    LEMAS_ATTN_LAUNCH(17 + 128 + 256 + 512)
+    LEMAS_ATTN_LAUNCH(17 + 128 + 256 + 512) LEMAS_ATTN_LAUNCH(17 + 1024) LEMAS_ATTN_LAUNCH(19 + 1024)
+    LEMAS_ATTN_LAUNCH(19 + 2048) LEMAS_ATTN_LAUNCH(19 + 1024 + 2048)      // 2048: MEASUREMENT ONLY, no fallback pass compiled in
     default: return hipErrorInvalidValue;
   }
 #undef LEMAS_ATTN_LAUNCH

@@ -388,7 +388,7 @@ def _attn_ref(q, k, v, lens, prescaled=False):
     return out
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 7, 17, 19])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 7, 17, 19, 17 + 1024, 19 + 1024])
 @pytest.mark.parametrize("case", ["plain", "late_spike", "overflow", "early_peak", "ragged", "deep_negative"])
 def test_attention_variants(variant, case):
     L, lib = _lib()

@@ -43,14 +43,16 @@ def test_bench_runs_every_rccl_call_of_the_multi_gpu_path_in_a_world_of_one():
     assert wb["backend"] == "nccl" and wb["on_device"] is True and wb["world"] == 1 and wb["bytes"] > 1.3e9
     assert line["n_gpus"] == 1 and line["mel_mse_vs_reference"] is not None and line["mel_mse_vs_reference"] <= 1e-4
     assert line["per_rank_ms"]["min"] > 0 and len(line["per_rank_ms"]["all"]) == 1
-    assert line["config"]["utterances_total"] == 1 and line["config"]["parity_fixture"] == "configs1_nfe32.npz"
+    assert line["config"]["utterances_total"] == 1 and line["config"]["utterances_timed"] == 1
+    assert line["config"]["parity_fixture"] == "configs1_nfe32.npz"
 
 
 @pytest.mark.timeout(900)
 def test_bench_configs3_reports_the_utterance_count_of_the_whole_job():
     two = _bench(["--gpus", "2", "--steps", "1", "--warmup", "1", "--depth", "2", "--no-cpu-baseline", "--workload", "configs3"],
                  env={"LEMAS_SHARE_GPU": "1", "LEMAS_DIST_BACKEND": "gloo"})
-    assert two["config"]["utterances_per_step_all_gpus"] == 16 and two["config"]["utterances_total"] == 16
+    assert two["config"]["utterances_total"] == 16 and two["config"]["utterances_timed"] == 16          # 8 per GPU: 64 on 8 GPUs
+    assert two["config"]["per_rank_audio_seconds"] == [pytest.approx(8 * 8.0, rel=1e-6)] * 2
     assert len(two["per_rank_ms"]["all"]) == 2 and two["per_rank_ms"]["max"] >= two["per_rank_ms"]["min"] > 0
     assert two["config"]["audio_seconds_per_rank"] == pytest.approx(8 * 8.0, rel=1e-6)
 
