@@ -188,6 +188,7 @@ def main():
     ap.add_argument("--overlap", type=int, default=1, help="1 = Vocos decode + D2H of utterance i on a side stream under the step loop of "
                     "utterance i+1 (default), 0 = strictly serial")
     ap.add_argument("--ln-fused", type=int, default=-1, help="engine option ln_fused (-1 = engine default)")
+    ap.add_argument("--ln-fold", type=int, default=-1, help="engine option ln_fold (-1 = engine default)")
     a = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -259,6 +260,8 @@ def main():
     model.engine.set_option("fp8", a.fp8)
     if a.ln_fused >= 0:
         model.engine.set_option("ln_fused", a.ln_fused)
+    if a.ln_fold >= 0:
+        model.engine.set_option("ln_fold", a.ln_fold)
     model.engine.set_option("table_cache", 0)      # hoists are redone for every utterance: nothing cached across steps
     vocoder = VocosEngine(vsd, device=device)
     del sd, vsd                                     # the engines own their copies; the broadcast buffer can go

@@ -65,6 +65,17 @@ int lemas_k_gemm_gate_ln(int32_t tile, const float* A, const float* W, const flo
                          const float* shift, const int32_t* seq_len, float* x, float* h, int32_t batch, int32_t pitch, int32_t frames,
                          int32_t K, int32_t concurrent, void* stream);
 
+/* "ln fold": the AdaLN-modulated LayerNorm between a gated residual update and the GEMM behind it, folded across the two GEMMs as the
+ * sampler runs it (csrc/common.h GemmParams).  producer = the gate + residual GEMM (A [M,Kp], Wp [1024,Kp], bias_p, gate; tile prod_tile:
+ * 16 / 17 / 18 / 19 / 22 / 26, 0 = production choice) updating x [M,1024] in place -- or, with use_prep != 0, the chain-entry kernel on x
+ * as given; then the c1 / c2 rows through the production table builders; then the consumer GEMM on Wc [Nc,1024], bias_c with epilogue
+ * cons_epi (1: y [M,Nc] = gelu_tanh(.); 4: y = q then k [batch][H][pitch][64] with rope = [cos | sin]; 5: y = v^T [batch][H][64][pitch])
+ * on tile cons_tile.  Mathematically y = epi(LN(x_new; eps 1e-6) * (1 + scale) + shift) . Wc^T + bias_c).  (modules.py:627-641) */
+int lemas_k_ln_fold_pair(int32_t prod_tile, int32_t cons_epi, int32_t cons_tile, const float* A, const float* Wp, const float* bias_p,
+                         const float* gate, const float* scale, const float* shift, const float* Wc, const float* bias_c, const float* rope,
+                         const int32_t* seq_len, float* x, float* y, int32_t batch, int32_t pitch, int32_t frames, int32_t Kp, int32_t Nc,
+                         int32_t use_prep, void* stream);
+
 /* Measurement builds only (-DLEMAS_PHASE_TIMESTAMPS, tools/timeline_step.py): every block GEMM and attention launch the engines enqueue from now
  * on stamps its workgroups' start / end (100 MHz wall clock) into slot k of `buf` (u64 [slots][4096]: [workgroup][4]), k counting the
  * launches of one forward pass in enqueue order; buf = NULL switches it off.  In a product build this returns LEMAS_E_STATE. */

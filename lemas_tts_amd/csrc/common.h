@@ -23,6 +23,10 @@ __device__ __forceinline__ void store_wt_b128(void* p, unsigned int __attribute_
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 
+__device__ __forceinline__ void store_wt_b64(void* p, unsigned int __attribute__((ext_vector_type(2))) v) {
+  asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -139,6 +143,22 @@ struct GemmParams {
   int ln_scale_off, ln_shift_off;   // offsets of the scale / shift vectors inside the AdaLN table row of the current step
   unsigned int* ln_cnt;             // [ceil(M / BM)] arrival counters
   unsigned int* ln_err;             // sticky error word (host-visible): set when a wait gives up instead of hanging
+  // ---- LayerNorm folded ACROSS the GEMMs ("ln fold"; bf16 path, row width D = 32 * ln_np) -------------------------------------------
+  // The AdaLN-modulated LayerNorm between a gated residual update and the GEMM that consumes it is linear in everything but the two
+  // row statistics:   ((x - mu) r (1 + s) + b) . W^T + bias  =  r (x (1 + s)) . W^T  -  r mu c1  +  c2,
+  //   c1[n] = sum_k (1 + s_k) W[n][k],   c2[n] = sum_k b_k W[n][k] + bias[n]      (per ODE step and site: hoisted into the AdaLN table)
+  // so the producer writes the SCALED bf16 image of its new rows plus per-row partial sums, the consumer applies r / mu in its
+  // epilogue, and the separate LayerNorm launch (with its two dependent-launch boundaries) disappears from the lane's chain.
+  // producer (EPI_GATE_RES, xs_out != nullptr): xs_out[m][n] = bf16(x_new[m][n] * (1 + tab[step][xs_scale_off + n])) and
+  //   ln_part_out[m][slot][2] = (sum x_new, sum x_new^2) over the 32 columns of slot n / 32 (every row m < M, updated or not)
+  bf16_t* xs_out;
+  int xs_scale_off;
+  float* ln_part_out;
+  // consumer (any row epilogue and EPI_V_T; A = that xs image): ln_part != nullptr -> acc + bias becomes
+  //   r_m acc - r_m mu_m c1[n] + c2[n],  c1 = tab[step][lnc1_off + n], c2 = tab[step][lnc2_off + n]  (p.bias is not read)
+  const float* ln_part;
+  int ln_np;                        // 32-column slots per row (D / 32) of ln_part / ln_part_out
+  int lnc1_off, lnc2_off;
 #ifdef LEMAS_PHASE_TIMESTAMPS
   unsigned long long* dbg;   // measurement builds: per-workgroup phase timestamps [grid][4] (gemm_bf16.hip PHASE_STAMP)
 #endif
@@ -151,6 +171,8 @@ hipError_t launch_gemm_bf16(int epi, const GemmParams& p, hipStream_t s);
 hipError_t launch_gemm_bf16_tile(int epi, const GemmParams& p, int tile, hipStream_t s);
 // one-time > 64 KB dynamic-LDS opt-in of every GEMM instantiation (called from lemas_kernels_init, never on a launch path)
 hipError_t gemm_bf16_init();
+// `groups` independent EPI_BIAS_F32 GEMMs (parameter blocks in DEVICE memory, 128 x 128 tiles, at most max_tiles tiles each) as one launch
+hipError_t launch_gemm_bf16_group(const GemmParams* dev_params, int groups, int max_tiles, hipStream_t s);
 // one launch for a lane's QK (+RoPE) and V^T projections (same A, different W / bias / epilogue)
 hipError_t launch_gemm_qkv_fused(const GemmParams& pq, const GemmParams& pv, hipStream_t s);
 // EPI_GATE_RES with the LayerNorm-modulate tail (GemmParams::ln_out): number of workgroups the launch would have if the production
@@ -181,6 +203,20 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t s);
 // out_bf16[m][c] = LN(x[m][:])[c] * (1 + scale[c]) + shift[c]; scale/shift read from the AdaLN table row of the current step
 hipError_t launch_ln_mod(const float* x, bf16_t* out, int M, int D, const float* tab, int tab_stride,
                          int scale_off, int shift_off, const int* step_idx, hipStream_t s);
+
+// ---- ln fold (see GemmParams): chain entry, and the c1 / c2 table rows of a t-grid ------------------------------------------------
+// xs[m][c] = bf16(x[m][c] (1 + scale[c])), part[m][D / 32][2] = (sum, sum of squares) of x over each 32-column slot
+hipError_t launch_ln_prep(const float* x, bf16_t* xs, float* part, int M, int D, const float* tab, int tab_stride, int scale_off,
+                          const int* step_idx, hipStream_t s);
+struct LnFoldSite {          // one LayerNorm + the GEMM behind it; offsets are positions inside an AdaLN table row
+  const float* bias;         // [N] bias of that GEMM
+  const float* tmp;          // [4 S][N] fp32: the split-term GEMM's output for this site
+  int N, scale_off, shift_off, c1_off, c2_off;
+};
+// A[site][4 S][d] bf16 = hi / lo terms of (1 + scale) and of shift, per step (the A operands of the sites' table GEMMs)
+hipError_t launch_ln_fold_split(const float* tab, int tab_stride, int S, int d, const LnFoldSite* sites, int nsites, bf16_t* A, hipStream_t s);
+// tab[step][c1_off + n] = tmp rows 0+1, tab[step][c2_off + n] = tmp rows 2+3 + bias
+hipError_t launch_ln_fold_combine(const LnFoldSite* sites, int nsites, int max_n, int S, float* tab, int tab_stride, hipStream_t s);
 
 // same LayerNorm-modulate, written as MXFP8 (out8 [M][D] e4m3 + mx [M][D/32] E8M0) for the fp8 GEMMs
 hipError_t launch_ln_mod_f8(const float* x, uint8_t* out8, uint8_t* mx, int M, int D, const float* tab, int tab_stride,

@@ -59,10 +59,24 @@ struct lemas_dit {
   // per workgroup with a classical second pass if it trips) + static priority for the younger half-workgroup: 25.9 -> 22.5 us per lane
   // launch at configs[1], +4.6 % end to end (profiles/r03_attention_variants.txt); 0 = the classical online softmax
   int attn_variant = 19;
+  // measurement option: lane 1 launches stage k of a block only after lane 0's stage k has completed (the lanes run one stage apart
+  // instead of in lock-step, so unlike kernels share the chip)
+  int lane_skew = 0;
+  hipEvent_t ev_skew[8] = {};
   // the AdaLN LayerNorms behind the gated residual updates as the tail of those GEMM launches (gemm_bf16.hip ln_tail).  OFF: measured on
   // configs[1] it is 1.5x SLOWER end to end (88.9 -> 59.8 audio-s/s, profiles/r03_ln_tail_experiment.txt): with two lanes sharing the chip a
   // panel's column tiles do not run at the same time, so finished workgroups sit on their CUs waiting for panel-mates that have not started
   bool ln_fused = false;
+  // "ln fold" (common.h GemmParams): the AdaLN LayerNorms of the block chain folded across the GEMMs on either side -- the gate +
+  // residual epilogues write the scaled bf16 rows and per-row partial sums, the QKV / FF1 epilogues apply the row statistics, and c1 / c2
+  // rows per ODE step live in the AdaLN table.  Two of the seven launches per block and lane disappear.  bf16 activations only (the
+  // MXFP8 path keeps its quantising LayerNorm launch).  OFF: end to end it is a wash at configs[1] (95.9 = 95.9 audio-s/s) and 2-2.5 %
+  // slower at the batched and the short workload (profiles/r03_ln_fold_experiment.txt).  What the two removed launches cost a lane's
+  // chain the other lane was already hiding; what counts with two lanes on the chip is workgroup-time, and there the fold adds (1-2 us per
+  // producer launch for the bf16 image and the statistics, 1-2.5 us per consumer launch for re-reading 256 B of statistics per row by
+  // every column tile) about what the two small LayerNorm launches took.
+  bool ln_fold = false;
+  bool fold_on() const { return ln_fold && !fp8; }
   unsigned int* ln_err_host = nullptr;   // pinned, device-visible: set by a device-side wait that gave up (checked at every entry point)
   unsigned int* ln_err_dev = nullptr;
   hipStream_t s2 = nullptr;
@@ -88,6 +102,10 @@ struct lemas_dit {
   DevBuf d_pconst, d_y, d_xres, d_hbf, d_q, d_k, d_vt, d_abf, d_ff, d_cmid, d_pred;
   DevBuf d_h8, d_hmx, d_a8, d_amx, d_ff8, d_ffmx;         // MXFP8 activations of the fp8 path (bytes + E8M0 scales)
   DevBuf d_lncnt;                                         // arrival counters of the fused LayerNorm tails: [block][site][lane][panel]
+  DevBuf d_lnpart;                                        // ln fold: [rows][32][2] (sum, sum of squares) per 32-column slot
+  DevBuf d_foldA, d_foldtmp, d_foldsites, d_foldparams, d_zero;   // ln-fold table build: split A operands, GEMM outputs, site / launch descriptors
+  std::vector<LnFoldSite> h_foldsites;
+  std::vector<GemmParams> h_foldparams;
   int tab_stride = 0;
   int n_cus = 0;
 
@@ -102,7 +120,8 @@ struct lemas_dit {
     return {&wproj_out, &bproj_out, &d_tabW, &d_tabB, &wconv[0], &wconv[1], &d_step, &d_dt, &d_cfg, &d_t, &d_tab, &d_rope_cos,
             &d_rope_sin, &d_len, &d_sin, &d_h1, &d_temb, &d_st, &d_cond_eff, &d_step_cond, &d_pm, &d_pt, &d_te,
             &d_rowmask, &d_t1, &d_t2, &d_t3, &d_gx, &d_ct, &d_pconst, &d_y, &d_xres, &d_hbf, &d_q, &d_k, &d_vt,
-            &d_abf, &d_ff, &d_cmid, &d_pred, &d_h8, &d_hmx, &d_a8, &d_amx, &d_ff8, &d_ffmx, &d_lncnt};
+            &d_abf, &d_ff, &d_cmid, &d_pred, &d_h8, &d_hmx, &d_a8, &d_amx, &d_ff8, &d_ffmx, &d_lncnt, &d_lnpart,
+            &d_foldA, &d_foldtmp, &d_foldsites, &d_foldparams, &d_zero};
   }
   static std::vector<DevBuf*> block_bufs(BlockW& b) {
     return {&b.wqkv, &b.wo, &b.w1, &b.w2, &b.bqkv, &b.wqkv8, &b.wo8, &b.w18, &b.w28, &b.sqkv, &b.so, &b.s1, &b.s2, &b.wqkvq, &b.woq, &b.w1q, &b.w2q};
@@ -122,6 +141,7 @@ struct lemas_dit {
     if (s2) (void)hipStreamDestroy(s2);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
+    for (auto& e : ev_skew) if (e) (void)hipEventDestroy(e);
     for (auto& r : prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (DevBuf* b : own_bufs()) b->release();
     for (auto& b : blocks)
@@ -151,6 +171,9 @@ struct lemas_dit {
   int enqueue_forward(hipStream_t s);
   int enqueue_update(float* traj, hipStream_t s);
   int build_tables(const lemas_sample_args* a, hipStream_t s);
+  int build_fold_tables(int Snew, hipStream_t s);
+  // AdaLN table row: [depth x 6 d modulation | 2 d final norm | depth x (c1_qkv, c2_qkv [3 inner each], c1_ff1, c2_ff1 [ff each])]
+  int fold_off(int l) const { return cfg.depth * 6 * cfg.dim + 2 * cfg.dim + l * (6 * inner() + 2 * cfg.ff_mult * cfg.dim); }
   int text_embed(const lemas_sample_args* a, hipStream_t s);
 
   // profiling helpers
@@ -370,7 +393,7 @@ int lemas_dit::finalize() {
     HIP_TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
   }
   HIP_TRY(hipStreamSynchronize(s));
-  tab_stride = cfg.depth * 6 * d + 2 * d;
+  tab_stride = fold_off(cfg.depth);
   finalized = true;
   return 0;
 }
@@ -421,6 +444,7 @@ int lemas_dit::build_tables(const lemas_sample_args* a, hipStream_t s) {
     g.W = ws.ptr(T("norm_out.linear.weight")); g.bias = ws.ptr(T("norm_out.linear.bias")); g.N = 2 * d;
     g.out = d_tab.as<float>() + (size_t)cfg.depth * 6 * d;
     HIP_TRY(launch_gemm_f32(F32_BIAS, g, s));
+    if (fold_on()) RC_TRY(build_fold_tables(Snew, s));
     tgrid_cached = tg;
   }
   if (rope_n != a->frames) {
@@ -430,6 +454,50 @@ int lemas_dit::build_tables(const lemas_sample_args* a, hipStream_t s) {
     HIP_TRY(launch_rope_table(d_rope_cos.as<float>(), d_rope_sin.as<float>(), a->frames, half, ws.ptr(T("rotary_embed.inv_freq")), s));
     rope_n = a->frames;
   }
+  return 0;
+}
+
+// ln fold: c1 / c2 rows of every (block, LayerNorm site, ODE step) -- see ln_fold_split_kernel (norm_elementwise.hip).  One split
+// launch, one grouped GEMM launch over the 2 x depth sites against the bf16 weights the step loop uses, one combine launch.
+int lemas_dit::build_fold_tables(int Snew, hipStream_t s) {
+  const int d = cfg.dim, in = inner(), ffd = cfg.ff_mult * d, depth = cfg.depth;
+  const int nsites = 2 * depth, ra = 4 * Snew;
+  RC_TRY(d_foldA.ensure((size_t)nsites * ra * d * 2));
+  RC_TRY(d_foldtmp.ensure((size_t)depth * ra * (3 * in + ffd) * 4));
+  RC_TRY(d_foldsites.ensure((size_t)nsites * sizeof(LnFoldSite)));
+  RC_TRY(d_foldparams.ensure((size_t)nsites * sizeof(GemmParams)));
+  RC_TRY(d_zero.ensure((size_t)(3 * in > ffd ? 3 * in : ffd) * 4));     // zero-filled at allocation, never written
+  h_foldsites.assign(nsites, LnFoldSite{});
+  h_foldparams.assign(nsites, GemmParams{});
+  size_t off = 0;
+  int max_n = 0;
+  for (int l = 0; l < depth; ++l)
+    for (int site = 0; site < 2; ++site) {
+      const BlockW& w = blocks[l];
+      const int base = l * 6 * d, n = site == 0 ? 3 * in : ffd, idx = 2 * l + site;
+      LnFoldSite& st = h_foldsites[idx];
+      st.bias = site == 0 ? w.bqkv.as<float>() : w.b1;
+      st.tmp = d_foldtmp.as<float>() + off;
+      st.N = n;
+      st.scale_off = base + (site == 0 ? d : 4 * d);        // [shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp]
+      st.shift_off = base + (site == 0 ? 0 : 3 * d);
+      st.c1_off = fold_off(l) + (site == 0 ? 0 : 6 * in);
+      st.c2_off = st.c1_off + n;
+      GemmParams& g = h_foldparams[idx];
+      g.A = d_foldA.as<bf16_t>() + (size_t)idx * ra * d;
+      const DevBuf& wb = site == 0 ? (fp8_wonly ? w.wqkvq : w.wqkv) : (fp8_wonly ? w.w1q : w.w1);
+      g.W = wb.as<bf16_t>();
+      g.bias = d_zero.as<float>();
+      g.M = ra; g.N = n; g.K = d; g.n_valid = n; g.out_f32 = d_foldtmp.as<float>() + off; g.ldc = n;
+      g.seq_pitch = (ra + 127) & ~127; g.seq_valid = ra; g.batch = 1; g.xcd_gx = 8;
+      off += (size_t)ra * n;
+      max_n = n > max_n ? n : max_n;
+    }
+  HIP_TRY(hipMemcpyAsync(d_foldsites.p, h_foldsites.data(), (size_t)nsites * sizeof(LnFoldSite), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(d_foldparams.p, h_foldparams.data(), (size_t)nsites * sizeof(GemmParams), hipMemcpyHostToDevice, s));
+  HIP_TRY(launch_ln_fold_split(d_tab.as<float>(), tab_stride, Snew, d, d_foldsites.as<LnFoldSite>(), nsites, d_foldA.as<bf16_t>(), s));
+  HIP_TRY(launch_gemm_bf16_group(d_foldparams.as<GemmParams>(), nsites, ((ra + 127) / 128) * (max_n / 128), s));
+  HIP_TRY(launch_ln_fold_combine(d_foldsites.as<LnFoldSite>(), nsites, max_n, Snew, d_tab.as<float>(), tab_stride, s));
   return 0;
 }
 
@@ -499,6 +567,7 @@ int lemas_dit::prepare(const lemas_sample_args* a, hipStream_t s) {
   npad = pitch;
   const int d = cfg.dim, md = cfg.mel_dim, td = cfg.text_dim, rows = BB * pitch, in = inner();
 
+  if (fp8_wonly) RC_TRY(dequantize_fp8());      // before the tables: the ln-fold rows are sums over the weights the step loop multiplies with
   RC_TRY(build_tables(a, s));
   if (has_len) {
     RC_TRY(d_len.ensure((size_t)B * 4));
@@ -545,7 +614,7 @@ int lemas_dit::prepare(const lemas_sample_args* a, hipStream_t s) {
   RC_TRY(d_cmid.ensure((size_t)rows * d * 2));
   RC_TRY(d_pred.ensure((size_t)rows * md * 4));
   RC_TRY(d_lncnt.ensure((size_t)cfg.depth * 2 * 2 * (rows / 64 + 1) * sizeof(unsigned int)));   // >= [block][site][lane][panel of >= 64 rows]
-  if (fp8_wonly) RC_TRY(dequantize_fp8());
+  RC_TRY(d_lnpart.ensure((size_t)rows * (d / 32) * 2 * 4));
   if (fp8) {
     RC_TRY(quantize_fp8());
     RC_TRY(d_h8.ensure((size_t)rows * d));
@@ -606,7 +675,8 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
   // row panel).  configs[1]: 2 x 120 workgroups of 96 KB LDS on 256 CUs.  Batched shapes keep the separate ln_mod launches.
   int ln_panels = 0;
   bool fuse_ln = false;
-  if (ln_fused && !fp8) {
+  const bool fold = fold_on();
+  if (ln_fused && !fp8 && !fold) {
     GemmParams t{};
     t.M = rows; t.N = d; t.K = in; t.n_valid = d; t.ldc = d; t.concurrency = lanes; t.tile = d == 1024 ? opt_tile_n1024 : 0;
     int per_cu = 1;
@@ -643,8 +713,17 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     return 0;
   };
 
+  const bool skew = fork && lane_skew != 0;
+  if (skew)
+    for (auto& e : ev_skew)
+      if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  int skew_k = 0;
+  // around every launch of a block: lane 0 records "stage k done", lane 1 waits for it before its own stage k
+  auto skew_pre = [&](int ln, hipStream_t q) -> int { if (skew && ln == 1) HIP_TRY(hipStreamWaitEvent(q, ev_skew[skew_k & 7], 0)); return 0; };
+  auto skew_post = [&](int ln, hipStream_t q) -> int { if (skew && ln == 0) HIP_TRY(hipEventRecord(ev_skew[skew_k & 7], q)); ++skew_k; return 0; };
   auto block = [&](int l, int ln) -> int {   // one DiTBlock (modules.py:627-641) on one lane's rows
     hipStream_t q = st[ln];
+    skew_k = 0;
     const size_t r0 = (size_t)ln * rows;
     float* xres = d_xres.as<float>() + r0 * d;
     bf16_t* hbf = d_hbf.as<bf16_t>() + r0 * d;
@@ -682,7 +761,16 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
         g.A = abf16; g.W = (fp8_wonly ? wq.as<bf16_t>() : wb.as<bf16_t>()) + row_off * K;
       }
     };
-    if (!(fuse_ln && l > 0)) {      // fused: block l's attn_norm rows were written by block l-1's FF2 launch
+    float* lnpart = d_lnpart.as<float>() + r0 * (d / 32) * 2;
+    const int fo = fold_off(l);
+    if (fold) {                     // ln fold: only the chain's entry needs a launch; later blocks get xs + partial sums from FF2
+      if (l == 0) {
+        RC_TRY(pbegin(PC_LN, q));
+        HIP_TRY(launch_ln_prep(xres, hbf, lnpart, rows, d, tab, tab_stride, base + d, step, q));
+        RC_TRY(pend(q));
+      }
+      g.ln_part = lnpart; g.ln_np = d / 32;
+    } else if (!(fuse_ln && l > 0)) {      // fused: block l's attn_norm rows were written by block l-1's FF2 launch
       RC_TRY(pbegin(PC_LN, q));
       if (fp8) HIP_TRY(launch_ln_mod_f8(xres, h8, hmx, rows, d, tab, tab_stride, base + d, base, step, q));
       else HIP_TRY(launch_ln_mod(xres, hbf, rows, d, tab, tab_stride, base + d, base, step, q));
@@ -698,6 +786,7 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
       operands(hbf, h8, hmx, w.wqkv, w.wqkv8, w.sqkv, w.wqkvq, 0, d);
       gq.A = g.A; gq.a_mx = g.a_mx; gq.W = g.W; gq.w_scale = g.w_scale;
       gq.bias = w.bqkv.as<float>(); gq.N = 2 * in; gq.K = d; gq.n_valid = 2 * in; gq.kv_len = nullptr;
+      gq.lnc1_off = fo; gq.lnc2_off = fo + 3 * in; gv.lnc1_off = fo + 2 * in; gv.lnc2_off = fo + 5 * in;
       operands(hbf, h8, hmx, w.wqkv, w.wqkv8, w.sqkv, w.wqkvq, (size_t)2 * in, d);
       gv.A = g.A; gv.a_mx = g.a_mx; gv.W = g.W; gv.w_scale = g.w_scale;
       gv.bias = w.bqkv.as<float>() + 2 * in; gv.N = in; gv.K = d; gv.n_valid = in; gv.kv_len = nullptr;
@@ -706,25 +795,30 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
 #ifdef LEMAS_PHASE_TIMESTAMPS
       gv.dbg = gq.dbg;
 #endif
+      RC_TRY(skew_pre(ln, q));
       HIP_TRY(launch_gemm_qkv_fused(gq, gv, q));
+      RC_TRY(skew_post(ln, q));
       g.K = d;
     } else {
       RC_TRY(pkernel(PC_GEMM_QK, &g.ev_start, &g.ev_stop));
       operands(hbf, h8, hmx, w.wqkv, w.wqkv8, w.sqkv, w.wqkvq, 0, d);
       g.bias = w.bqkv.as<float>(); g.N = 2 * in; g.K = d; g.n_valid = 2 * in;
-      g.kv_len = nullptr; g.tile = tile_for(g.N);
+      g.kv_len = nullptr; g.tile = tile_for(g.N); g.lnc1_off = fo; g.lnc2_off = fo + 3 * in;
       TL_SLOT(g);
       HIP_TRY(launch_gemm_bf16(EPI_QK_ROPE, g, q));
       RC_TRY(pkernel(PC_GEMM_V, &g.ev_start, &g.ev_stop));
       operands(hbf, h8, hmx, w.wqkv, w.wqkv8, w.sqkv, w.wqkvq, (size_t)2 * in, d);
-      g.bias = w.bqkv.as<float>() + 2 * in; g.N = in; g.n_valid = in; g.tile = tile_for(g.N);
+      g.bias = w.bqkv.as<float>() + 2 * in; g.N = in; g.n_valid = in; g.tile = tile_for(g.N); g.lnc1_off = fo + 2 * in; g.lnc2_off = fo + 5 * in;
       TL_SLOT(g);
       HIP_TRY(launch_gemm_bf16(EPI_V_T, g, q));
     }
+    g.ln_part = nullptr;
     RC_TRY(pkernel(PC_ATTN, &at.ev_start, &at.ev_stop));
     at.out8 = a8; at.out_mx = amx;
     TL_SLOT(at);
+    RC_TRY(skew_pre(ln, q));
     HIP_TRY(launch_attention(at, q));
+    RC_TRY(skew_post(ln, q));
     RC_TRY(pkernel(PC_GEMM_OUT, &g.ev_start, &g.ev_stop));
     operands(abf, a8, amx, w.wo, w.wo8, w.so, w.woq, 0, in);
     g.bias = w.bo; g.N = d; g.K = in; g.n_valid = d;
@@ -732,10 +826,13 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     if (fuse_ln) {   // ff_norm (modules.py:637) as the tail of the out-projection launch
       g.ln_out = hbf; g.ln_scale_off = base + 4 * d; g.ln_shift_off = base + 3 * d; g.ln_cnt = ln_site(l, 0, ln); g.ln_err = ln_err_dev;
     }
+    if (fold) { g.xs_out = hbf; g.xs_scale_off = base + 4 * d; g.ln_part_out = lnpart; g.ln_np = d / 32; }     // ff_norm's scale (modules.py:637)
     TL_SLOT(g);
+    RC_TRY(skew_pre(ln, q));
     HIP_TRY(launch_gemm_bf16(EPI_GATE_RES, g, q));
-    g.ln_out = nullptr;
-    if (!fuse_ln) {
+    RC_TRY(skew_post(ln, q));
+    g.ln_out = nullptr; g.xs_out = nullptr;
+    if (!fuse_ln && !fold) {
       RC_TRY(pbegin(PC_LN, q));
       if (fp8) HIP_TRY(launch_ln_mod_f8(xres, h8, hmx, rows, d, tab, tab_stride, base + 4 * d, base + 3 * d, step, q));
       else HIP_TRY(launch_ln_mod(xres, hbf, rows, d, tab, tab_stride, base + 4 * d, base + 3 * d, step, q));
@@ -745,8 +842,12 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     operands(hbf, h8, hmx, w.w1, w.w18, w.s1, w.w1q, 0, d);
     g.bias = w.b1; g.N = ffd; g.K = d; g.n_valid = ffd;
     g.out_bf16 = ffb; g.out_f8 = ff8; g.out_mx = ffmx; g.ldc = ffd; g.kv_len = nullptr; g.tile = tile_for(g.N);
+    if (fold) { g.ln_part = lnpart; g.lnc1_off = fo + 6 * in; g.lnc2_off = fo + 6 * in + ffd; }
     TL_SLOT(g);
+    RC_TRY(skew_pre(ln, q));
     HIP_TRY(launch_gemm_bf16(fp8 ? EPI_BIAS_GELU_F8 : EPI_BIAS_GELU_BF16, g, q));
+    RC_TRY(skew_post(ln, q));
+    g.ln_part = nullptr;
     RC_TRY(pkernel(PC_GEMM_FF2, &g.ev_start, &g.ev_stop));
     operands(ffb, ff8, ffmx, w.w2, w.w28, w.s2, w.w2q, 0, ffd);
     g.bias = w.b2; g.N = d; g.K = ffd; g.n_valid = d;
@@ -757,9 +858,13 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
       if (l + 1 < cfg.depth) { g.ln_scale_off = nb + d; g.ln_shift_off = nb; }
       else { g.ln_scale_off = fb; g.ln_shift_off = fb + d; }
     }
+    // ln fold: the next block's attn_norm scale (modules.py:314); the final norm after the last block stays a launch of its own
+    if (fold && l + 1 < cfg.depth) { g.xs_out = hbf; g.xs_scale_off = (l + 1) * 6 * d + d; g.ln_part_out = lnpart; g.ln_np = d / 32; }
     TL_SLOT(g);
+    RC_TRY(skew_pre(ln, q));
     HIP_TRY(launch_gemm_bf16(EPI_GATE_RES, g, q));
-    g.ln_out = nullptr;
+    RC_TRY(skew_post(ln, q));
+    g.ln_out = nullptr; g.xs_out = nullptr;
     return 0;
   };
 
@@ -824,7 +929,7 @@ int lemas_dit::solve(const lemas_sample_args* a, hipStream_t s) {
       graph_generation = moved;
     }
     char key[96];
-    snprintf(key, sizeof key, "B%d_N%d_cfg%d_len%d_dual%d_f8%d_ln%d", B, N, (int)use_cfg, (int)has_len, (int)dual, fp8 ? 1 : fp8_wonly ? 2 : 0, (int)ln_fused);
+    snprintf(key, sizeof key, "B%d_N%d_cfg%d_len%d_dual%d_f8%d_ln%d", B, N, (int)use_cfg, (int)has_len, (int)dual, fp8 ? 1 : fp8_wonly ? 2 : 0, (int)ln_fused + 2 * (int)fold_on());
     auto it = graphs.find(key);
     if (it == graphs.end()) {
       if (graphs.size() >= 32) drop_graphs();   // a serving process sees a new length almost every utterance: bound the cache (a capture costs ~3 ms)
@@ -909,7 +1014,7 @@ int lemas_dit_set_option(lemas_dit* m, const char* key, int64_t value) {
   {
     int* slot = !strcmp(key, "tile_n1024") ? &m->opt_tile_n1024 : !strcmp(key, "tile_n2048") ? &m->opt_tile_n2048
               : !strcmp(key, "tile_qkv") ? &m->opt_tile_qkv : !strcmp(key, "xcd_gx") ? &m->opt_xcd_gx
-              : !strcmp(key, "attn_variant") ? &m->attn_variant : nullptr;
+              : !strcmp(key, "attn_variant") ? &m->attn_variant : !strcmp(key, "lane_skew") ? &m->lane_skew : nullptr;
     if (slot) {
       *slot = (int)value;
       m->drop_graphs();     // a captured graph baked the kernels of the old choice
@@ -921,9 +1026,16 @@ int lemas_dit_set_option(lemas_dit* m, const char* key, int64_t value) {
     m->drop_graphs();
     return 0;
   }
+  if (!strcmp(key, "ln_fold")) {
+    m->ln_fold = value != 0;
+    m->tgrid_cached.clear();      // the c1 / c2 rows of the table exist only while the fold is on
+    m->prepared = false;
+    m->drop_graphs();
+    return 0;
+  }
   if (!strcmp(key, "fp8")) {      // block GEMMs on the MXFP8 path; takes effect at the next prepare()
     if (value < 0 || value > 2) { set_error("lemas_dit_set_option: fp8 is 0 (bf16), 1 (MXFP8 GEMMs) or 2 (weights-only fp8 accuracy point)"); return LEMAS_E_ARG; }
-    if (m->fp8 != (value == 1) || m->fp8_wonly != (value == 2)) m->prepared = false;
+    if (m->fp8 != (value == 1) || m->fp8_wonly != (value == 2)) { m->prepared = false; m->tgrid_cached.clear(); }   // (ln-fold rows follow the weight image)
     m->fp8 = value == 1;
     m->fp8_wonly = value == 2;
     return 0;

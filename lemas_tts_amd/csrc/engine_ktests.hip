@@ -245,6 +245,85 @@ int lemas_k_gemm_gate_ln(int32_t tile, const float* A, const float* W, const flo
   return 0;
 }
 
+// ln fold at kernel level (common.h GemmParams): producer (the gate + residual GEMM on tile prod_tile, or with use_prep the chain-entry
+// kernel on x as given) -> the c1 / c2 rows through the production table builders (one site, one step) -> consumer GEMM with epilogue
+// cons_epi (1 GELU -> y [M][Nc]; 4 QK+RoPE -> y = q then k [batch][H][pitch][64]; 5 -> y = v^T [batch][H][64][pitch]) on tile cons_tile.
+int lemas_k_ln_fold_pair(int32_t prod_tile, int32_t cons_epi, int32_t cons_tile, const float* A, const float* Wp, const float* bias_p,
+                         const float* gate, const float* scale, const float* shift, const float* Wc, const float* bias_c, const float* rope,
+                         const int32_t* seq_len, float* x, float* y, int32_t batch, int32_t pitch, int32_t frames, int32_t Kp, int32_t Nc,
+                         int32_t use_prep, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  RC_TRY(kernels_init());
+  const int D = 1024;
+  if (batch <= 0 || pitch % 128 != 0 || frames <= 0 || frames > pitch || Kp % 64 != 0 || Nc % 128 != 0 ||
+      !(cons_epi == EPI_BIAS_GELU_BF16 || cons_epi == EPI_QK_ROPE || cons_epi == EPI_V_T) || (cons_epi == EPI_QK_ROPE && !rope)) {
+    set_error("lemas_k_ln_fold_pair: bad arguments");
+    return LEMAS_E_ARG;
+  }
+  const int M = batch * pitch, stride = 3 * D + 2 * Nc;
+  Scratch sc;
+  bf16_t* a = sc.get<bf16_t>((size_t)M * Kp);
+  bf16_t* wp = sc.get<bf16_t>((size_t)D * Kp);
+  bf16_t* wc = sc.get<bf16_t>((size_t)Nc * D);
+  bf16_t* xs = sc.get<bf16_t>((size_t)M * D);
+  float* part = sc.get<float>((size_t)M * 64);
+  float* tab = sc.get<float>((size_t)stride);
+  float* zero = sc.get<float>((size_t)Nc);
+  float* tmp = sc.get<float>((size_t)4 * Nc);
+  bf16_t* fa = sc.get<bf16_t>((size_t)4 * D);
+  LnFoldSite* site_d = sc.get<LnFoldSite>(1);
+  GemmParams* gp_d = sc.get<GemmParams>(1);
+  int* step = sc.get<int>(16);
+  bf16_t* ob = sc.get<bf16_t>((size_t)M * Nc);
+  if (!a || !wp || !wc || !xs || !part || !tab || !zero || !tmp || !fa || !site_d || !gp_d || !step || !ob) {
+    set_error("lemas_k_ln_fold_pair: out of memory");
+    return LEMAS_E_STATE;
+  }
+  HIP_TRY(launch_f32_to_bf16(A, a, (size_t)M * Kp, s));
+  HIP_TRY(launch_f32_to_bf16(Wp, wp, (size_t)D * Kp, s));
+  HIP_TRY(launch_f32_to_bf16(Wc, wc, (size_t)Nc * D, s));
+  HIP_TRY(hipMemcpyAsync(tab, gate, (size_t)D * 4, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipMemcpyAsync(tab + D, scale, (size_t)D * 4, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipMemcpyAsync(tab + 2 * D, shift, (size_t)D * 4, hipMemcpyDeviceToDevice, s));
+  // the table rows, exactly as lemas_dit::build_fold_tables does it
+  LnFoldSite site{};
+  site.bias = bias_c; site.tmp = tmp; site.N = Nc; site.scale_off = D; site.shift_off = 2 * D; site.c1_off = 3 * D; site.c2_off = 3 * D + Nc;
+  GemmParams gf{};
+  gf.A = fa; gf.W = wc; gf.bias = zero; gf.M = 4; gf.N = Nc; gf.K = D; gf.n_valid = Nc; gf.out_f32 = tmp; gf.ldc = Nc;
+  gf.seq_pitch = 128; gf.seq_valid = 4; gf.batch = 1; gf.xcd_gx = 8;
+  HIP_TRY(hipMemcpyAsync(site_d, &site, sizeof site, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(gp_d, &gf, sizeof gf, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  HIP_TRY(launch_ln_fold_split(tab, stride, 1, D, site_d, 1, fa, s));
+  HIP_TRY(launch_gemm_bf16_group(gp_d, 1, Nc / 128, s));
+  HIP_TRY(launch_ln_fold_combine(site_d, 1, Nc, 1, tab, stride, s));
+  GemmParams p{};
+  p.M = M; p.seq_pitch = pitch; p.seq_valid = frames; p.batch = batch; p.step_idx = step; p.tab = tab; p.tab_stride = stride;
+  if (use_prep) {
+    HIP_TRY(launch_ln_prep(x, xs, part, M, D, tab, stride, D, step, s));
+  } else {
+    p.A = a; p.W = wp; p.bias = bias_p; p.N = D; p.K = Kp; p.n_valid = D; p.ldc = D; p.out_f32 = x; p.gate_off = 0; p.kv_len = seq_len;
+    p.xs_out = xs; p.xs_scale_off = D; p.ln_part_out = part; p.ln_np = D / 32;
+    HIP_TRY(launch_gemm_bf16_tile(EPI_GATE_RES, p, prod_tile, s));
+    p.xs_out = nullptr; p.ln_part_out = nullptr; p.kv_len = nullptr;
+  }
+  p.A = xs; p.W = wc; p.bias = bias_c; p.N = Nc; p.K = D; p.n_valid = Nc; p.ldc = Nc;
+  p.ln_part = part; p.ln_np = D / 32; p.lnc1_off = 3 * D; p.lnc2_off = 3 * D + Nc;
+  size_t nout = (size_t)M * Nc;
+  if (cons_epi == EPI_BIAS_GELU_BF16) {
+    p.out_bf16 = ob;
+  } else if (cons_epi == EPI_QK_ROPE) {
+    p.heads = Nc / 128; p.q = ob; p.k = ob + (size_t)M * p.heads * 64; p.npad = pitch; p.rope_cos = rope; p.rope_sin = rope + (size_t)frames * 32;
+  } else {
+    p.heads = Nc / 64; p.vt = ob; p.npad = pitch;
+  }
+  HIP_TRY(launch_gemm_bf16_tile(cons_epi, p, cons_tile, s));
+  hipLaunchKernelGGL(widen_kernel, dim3(2048), dim3(256), 0, s, ob, y, nout);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(s));
+  return 0;
+}
+
 int lemas_k_linear_f32(const float* A, const float* W, const float* bias, float* out, int32_t M, int32_t N, int32_t K,
                        int32_t act, void* stream) {
   hipStream_t s = (hipStream_t)stream;
@@ -412,6 +491,9 @@ extern "C" int lemas_k_bench(const char* what, int32_t M, int32_t N, int32_t K, 
   };
   const bool with_ln = w == "gemm_gate_ln";    // the gate + residual GEMM with its LayerNorm tail (N = 1024)
   if (with_ln) w = "gemm_gate";
+  // "<name>_fold": the same launch as a ln-fold producer (gemm_gate) / consumer (gemm_gelu, gemm_qk, gemm_v); K or N = 1024 as the fold needs
+  const bool fold = w.size() > 5 && w.compare(w.size() - 5, 5, "_fold") == 0;
+  if (fold) w = w.substr(0, w.size() - 5);
   if (w == "gemm_gelu" || w == "gemm_gelu8" || w == "gemm_gate" || w == "gemm_qk" || w == "gemm_v" || w == "gemm_f32out") {
     const int Np = (N + 127) & ~127;
     bf16_t* a = sc.get<bf16_t>((size_t)M * K);
@@ -446,6 +528,15 @@ extern "C" int lemas_k_bench(const char* what, int32_t M, int32_t N, int32_t K, 
     }
     const int epi = w == "gemm_gelu8" ? EPI_BIAS_GELU_F8 : w == "gemm_gelu" ? EPI_BIAS_GELU_BF16 : w == "gemm_gate" ? EPI_GATE_RES : w == "gemm_qk" ? EPI_QK_ROPE : w == "gemm_v" ? EPI_V_T : EPI_BIAS_F32;
     if ((epi == EPI_QK_ROPE && N != 2048) || (epi == EPI_V_T && N != 1024)) { set_error("bench: gemm_qk needs N = 2048, gemm_v N = 1024"); return LEMAS_E_ARG; }
+    if (fold) {
+      float* tabf = sc.get<float>((size_t)4096 + 2 * Np);
+      float* part = sc.get<float>((size_t)M * 64);
+      bf16_t* xs = sc.get<bf16_t>((size_t)M * 1024);
+      if (!tabf || !part || !xs) { set_error("bench: out of memory"); return LEMAS_E_STATE; }
+      p.tab = tabf; p.ln_np = 32;
+      if (epi == EPI_GATE_RES) { p.xs_out = xs; p.xs_scale_off = 1024; p.ln_part_out = part; }
+      else { p.ln_part = part; p.lnc1_off = 4096; p.lnc2_off = 4096 + Np; }
+    }
     unsigned int* err_host = nullptr;
     if (with_ln) {
       if (f8 || N != 1024) { set_error("bench: gemm_gate_ln is the bf16 N = 1024 launch"); return LEMAS_E_ARG; }

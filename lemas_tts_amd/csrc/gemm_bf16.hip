@@ -33,6 +33,7 @@
 namespace {
 
 constexpr int BK = 64;
+constexpr int LN_NP = LN_D / 32;      // ln fold: 32-column statistics slots per row (GemmParams::ln_np)
 
 // Measurement builds only (-DLEMAS_PHASE_TIMESTAMPS, see profiles/r02_kbench_phases.txt): thread 0 of every workgroup stamps the 100 MHz
 // wall clock at entry, after the prologue, after the K loop and after its last store has drained.  Compiled out of the product.
@@ -109,6 +110,13 @@ struct ReadScales {
     }
   }
 };
+
+// the value of lane perm(l) inside each row of 16 lanes (DPP control CTRL: 0xB1 = quad_perm [1,0,3,2], 0x4E = [2,3,0,1], 0x141 = row_half_mirror,
+// 0x140 = row_mirror)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
 
 __device__ __forceinline__ bf16x4 pack4(float a, float b, float c, float d) {
   bf16x4 o;
@@ -319,12 +327,21 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x16 (&acc)
 // row-dependent operands of its FIRST 32-row block (fp32 residual rows / RoPE table rows).  load() is called one K-tile before the
 // end of the main loop (the operands are in registers when the loop ends); every load is unconditional with a clamped address,
 // so the number of vector-memory operations in flight does not depend on the data (the loops count them with vmcnt).
-template <int EPI, int TJ, bool COLS_ONCE>
+// epilogues that can consume the LayerNorm-folded operand (GemmParams::ln_part): acc + bias -> r_m acc - r_m mu_m c1[n] + c2[n]
+template <int EPI>
+constexpr bool epi_lna() { return EPI == EPI_QK_ROPE || EPI == EPI_BIAS_GELU_BF16 || EPI == EPI_V_T; }
+
+// LNA: 0 = the instantiation never consumes a folded LayerNorm (fp8 bodies, gate/residual, fp32 outputs); 1 = it may, c1 columns held
+// in registers beside the bias; 2 = it may, c1 columns re-read per 32-row block (the 256 x 256 tile has no registers to spare)
+template <int EPI, int TJ, bool COLS_ONCE, int LNA = (epi_lna<EPI>() ? 1 : 0)>
 struct EpiPre {
   static constexpr int WTN = 32 * TJ;
   static constexpr int NC = COLS_ONCE ? TJ * 4 : 1;
   static constexpr int NR = EPI == EPI_GATE_RES ? SlabF32<32, WTN>::ITERS : EPI == EPI_QK_ROPE ? 32 / (64 / (WTN / 8)) : 1;
+  static_assert(LNA == 0 || (epi_lna<EPI>() && COLS_ONCE), "ln-fold consumers keep their column vectors in registers");
   float4 bias_c[NC], gate_c[EPI == EPI_GATE_RES ? NC : 1];
+  float4 c1_c[LNA == 1 ? NC : 1];               // ln fold: c1 columns (zero when the launch is not a ln-fold consumer)
+  const float* c1src;                           // LNA == 2: where to re-read them (nullptr: not a consumer)
   float4 r0[NR], r1[EPI == EPI_QK_ROPE ? NR : 1];     // block 0: residual rows | cos rows, sin rows
   const float* gate;
 
@@ -359,14 +376,25 @@ struct EpiPre {
     const int hi = lane >> 5;
     gate = nullptr;
     if (EPI == EPI_GATE_RES) gate = p.tab + (size_t)p.step_idx[0] * p.tab_stride + p.gate_off;
+    const float* bsrc = p.bias;
+    c1src = nullptr;
+    if constexpr (LNA != 0) {
+      if (p.ln_part) {       // ln fold: c2 (which holds the bias) in place of the bias vector, c1 beside it
+        const float* row = p.tab + (size_t)p.step_idx[0] * p.tab_stride;
+        bsrc = row + p.lnc2_off;
+        c1src = row + p.lnc1_off;
+      }
+    }
     if (COLS_ONCE) {
 #pragma unroll
       for (int j = 0; j < TJ; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int nl = j * 32 + 8 * g + 4 * hi;
-          bias_c[j * 4 + g] = *reinterpret_cast<const float4*>(p.bias + nw + nl);
+          bias_c[j * 4 + g] = *reinterpret_cast<const float4*>(bsrc + nw + nl);
           if (EPI == EPI_GATE_RES) gate_c[j * 4 + g] = *reinterpret_cast<const float4*>(gate + nw + nl);
+          if constexpr (LNA == 1)
+            c1_c[j * 4 + g] = c1src ? *reinterpret_cast<const float4*>(c1src + nw + nl) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
     load_rows(p, mw, nw, lane, 0, r0, r1);
@@ -379,14 +407,28 @@ struct EpiPre {
 // 11-17 us per 256 x 256 tile at full chip.  Here the column vectors are loaded once per wave tile (COLS_ONCE; off where the
 // registers do not allow it), block 0's row operands arrive with `pre`, and those of block i+1 are in flight while block i goes
 // through the slab.
-template <int EPI, int TI, int TJ, bool COLS_ONCE, bool AHEAD = true>
+// `lnx`: ln fold (GemmParams), consumer epilogues: the (r, -r mu) pairs of this wave tile's rows in LDS ([row][2], written by
+// ln_rowstat_store at the top of the kernel).  The producer side (EPI_GATE_RES with xs_out) needs nothing from the caller.
+template <int EPI, int TI, int TJ, bool COLS_ONCE, bool AHEAD = true, int LNA = (epi_lna<EPI>() ? 1 : 0)>
 __device__ __forceinline__ void epilogue_row_blocks(const GemmParams& p, f32x16 (&acc)[TI][TJ], char* slab, int mw, int nw, int lane,
-                                                    EpiPre<EPI, TJ, COLS_ONCE>& pre) {
+                                                    EpiPre<EPI, TJ, COLS_ONCE, LNA>& pre, const float* lnx = nullptr) {
   static_assert(EPI != EPI_BIAS_GELU_F8 && EPI != EPI_V_T, "bf16-path row epilogues only");
   constexpr int WTN = 32 * TJ;
-  using Pre = EpiPre<EPI, TJ, COLS_ONCE>;
+  using Pre = EpiPre<EPI, TJ, COLS_ONCE, LNA>;
   const int l31 = lane & 31, hi = lane >> 5;
   const float* gate = pre.gate;
+  // ln-fold consumer: v = r acc + (nrm c1 + c2); without it r = 1, nrm = 0, c1 = 0 and the same expression is acc + bias exactly
+  bool lna = false;
+  if constexpr (LNA != 0) lna = p.ln_part != nullptr;
+  auto c1_of = [&](int j, int g) -> float4 {
+    if constexpr (LNA == 2) return pre.c1src ? *reinterpret_cast<const float4*>(pre.c1src + nw + j * 32 + 8 * g + 4 * hi) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (LNA == 1) return pre.c1_c[j * 4 + g];
+    return make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  auto row_rn = [&](int i, float& r, float& nrm) {
+    r = 1.0f; nrm = 0.f;
+    if (lna) { const float2 t = *reinterpret_cast<const float2*>(lnx + 2 * (32 * i + l31)); r = t.x; nrm = t.y; }
+  };
   auto bias_of = [&](int j, int g) -> float4 {
     if (COLS_ONCE) return pre.bias_c[j * 4 + g];
     return *reinterpret_cast<const float4*>(p.bias + nw + j * 32 + 8 * g + 4 * hi);
@@ -400,6 +442,12 @@ __device__ __forceinline__ void epilogue_row_blocks(const GemmParams& p, f32x16 
     using S = SlabF32<32, WTN>;
     const int rr = lane / S::CPR, ch = lane % S::CPR;
     float4 xnext[Pre::NR], unused[1];
+    const bool prod = p.xs_out != nullptr;      // ln-fold producer: scaled bf16 image + row partial sums of the new rows
+    float4 sc1p = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (prod) {
+      const float4 t = *reinterpret_cast<const float4*>(gate - p.gate_off + p.xs_scale_off + nw + ch * 4);
+      sc1p = make_float4(1.0f + t.x, 1.0f + t.y, 1.0f + t.z, 1.0f + t.w);
+    }
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
       float4 xin[Pre::NR];
@@ -420,18 +468,47 @@ __device__ __forceinline__ void epilogue_row_blocks(const GemmParams& p, f32x16 
               make_float4(gt.x * (acc[i][j][4 * g + 0] + bias.x), gt.y * (acc[i][j][4 * g + 1] + bias.y),
                           gt.z * (acc[i][j][4 * g + 2] + bias.z), gt.w * (acc[i][j][4 * g + 3] + bias.w));
         }
+      // all slab rows of the block first: the stores below are asm with a memory clobber, which would otherwise put every LDS read
+      // behind the previous iteration's stores
+      float4 dv[S::ITERS];
+#pragma unroll
+      for (int it = 0; it < S::ITERS; ++it) dv[it] = *reinterpret_cast<const float4*>(slab + (it * S::RPI + rr) * S::PITCH + ch * 16);
+      float k1 = 0.f, k2 = 0.f;      // ln fold: the (sum, sum of squares) pair this lane will publish for the block
 #pragma unroll
       for (int it = 0; it < S::ITERS; ++it) {
-        const float4 d = *reinterpret_cast<const float4*>(slab + (it * S::RPI + rr) * S::PITCH + ch * 16);
+        const float4 d = dv[it];
         const int m = mw + 32 * i + it * S::RPI + rr;
         const int b2 = m / p.seq_pitch, pos = m - b2 * p.seq_pitch;
         bool live = m < p.M && pos < p.seq_valid && (nw + ch * 4) < p.n_valid;
         if (p.kv_len) live = live && pos < p.kv_len[b2 % p.batch];
+        float4 x = xin[it];
         if (live) {
-          float4 x = xin[it];
           x.x += d.x; x.y += d.y; x.z += d.z; x.w += d.w;
           store_wt_b128(p.out_f32 + (size_t)m * p.ldc + nw + ch * 4, __builtin_bit_cast(u32x4, x));
         }
+        if (prod) {     // every row of the activation space (updated or not): the consumer GEMM reads all of them
+          if (m < p.M) {
+            const bf16x4 o = pack4(x.x * sc1p.x, x.y * sc1p.y, x.z * sc1p.z, x.w * sc1p.w);
+            store_wt_b64(p.xs_out + (size_t)m * p.ldc + nw + ch * 4, __builtin_bit_cast(unsigned int __attribute__((ext_vector_type(2))), o));
+          }
+          float s1 = (x.x + x.y) + (x.z + x.w);
+          float s2 = __builtin_fmaf(x.x, x.x, __builtin_fmaf(x.y, x.y, __builtin_fmaf(x.z, x.z, x.w * x.w)));
+          // butterfly over the 8 lanes (32 columns = one statistics slot) of the row on DPP: v_add_f32 with a lane-permuting source
+          // modifier (the __shfl_xor form is a ds_bpermute round trip per step: 2 us of a 16 us launch).  xor 1, xor 2 (quad
+          // permutes), then the other quad of the 8 (row_half_mirror), whose lanes all hold their quad's sum by then
+          s1 += dpp_f<0xB1>(s1); s2 += dpp_f<0xB1>(s2);
+          s1 += dpp_f<0x4E>(s1); s2 += dpp_f<0x4E>(s2);
+          s1 += dpp_f<0x141>(s1); s2 += dpp_f<0x141>(s2);
+          // lane (rr, ch) keeps the pair of iteration it = ch % 8: after the loop ITERS * RPI * (CPR / 8) = 32 * WTN / 32 lanes hold one
+          // (row, slot) pair each and ONE store instruction publishes the block's statistics
+          if ((ch & 7) == it) { k1 = s1; k2 = s2; }
+        }
+      }
+      if (prod) {
+        static_assert(S::ITERS <= 8 && (S::CPR == 8 || S::CPR == 16), "one kept pair per lane");
+        const int m = mw + 32 * i + (ch & 7) * S::RPI + rr;
+        if ((ch & 7) < S::ITERS && m < p.M)
+          *reinterpret_cast<float2*>(p.ln_part_out + ((size_t)m * LN_NP + ((nw + ch * 4) >> 5)) * 2) = make_float2(k1, k2);
       }
     }
   } else if constexpr (EPI == EPI_QK_ROPE) {
@@ -450,15 +527,26 @@ __device__ __forceinline__ void epilogue_row_blocks(const GemmParams& p, f32x16 
 #pragma unroll
       for (int it = 0; it < ITERS; ++it) { cs[it] = i == 0 ? pre.r0[it] : cnext[it]; sn[it] = i == 0 ? pre.r1[it] : snext[it]; }
       if (i + 1 < TI) pre.load_rows(p, mw, nw, lane, i + 1, cnext, snext);
+      float r, nrm;
+      row_rn(i, r, nrm);
 #pragma unroll
       for (int j = 0; j < TJ; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int nl = j * 32 + 8 * g + 4 * hi;
           const float4 bias = bias_of(j, g);
-          *reinterpret_cast<float4*>(slab + l31 * S::PITCH + nl * 4) =
-              make_float4(acc[i][j][4 * g + 0] + bias.x, acc[i][j][4 * g + 1] + bias.y, acc[i][j][4 * g + 2] + bias.z,
-                          acc[i][j][4 * g + 3] + bias.w);
+          float4 v;
+          if constexpr (LNA != 0) {
+            const float4 c1 = c1_of(j, g);
+            v = make_float4(__builtin_fmaf(r, acc[i][j][4 * g + 0], __builtin_fmaf(nrm, c1.x, bias.x)),
+                            __builtin_fmaf(r, acc[i][j][4 * g + 1], __builtin_fmaf(nrm, c1.y, bias.y)),
+                            __builtin_fmaf(r, acc[i][j][4 * g + 2], __builtin_fmaf(nrm, c1.z, bias.z)),
+                            __builtin_fmaf(r, acc[i][j][4 * g + 3], __builtin_fmaf(nrm, c1.w, bias.w)));
+          } else {
+            v = make_float4(acc[i][j][4 * g + 0] + bias.x, acc[i][j][4 * g + 1] + bias.y, acc[i][j][4 * g + 2] + bias.z,
+                            acc[i][j][4 * g + 3] + bias.w);
+          }
+          *reinterpret_cast<float4*>(slab + l31 * S::PITCH + nl * 4) = v;
         }
 #pragma unroll
       for (int it = 0; it < ITERS; ++it) {
@@ -504,14 +592,25 @@ __device__ __forceinline__ void epilogue_row_blocks(const GemmParams& p, f32x16 
     const int rr = lane / S::CPR, ch = lane % S::CPR;
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
+      float r, nrm;
+      row_rn(i, r, nrm);
 #pragma unroll
       for (int j = 0; j < TJ; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int nl = j * 32 + 8 * g + 4 * hi;
           const float4 bias = bias_of(j, g);
-          float v0 = acc[i][j][4 * g + 0] + bias.x, v1 = acc[i][j][4 * g + 1] + bias.y;
-          float v2 = acc[i][j][4 * g + 2] + bias.z, v3 = acc[i][j][4 * g + 3] + bias.w;
+          float v0, v1, v2, v3;
+          if constexpr (LNA != 0) {
+            const float4 c1 = c1_of(j, g);
+            v0 = __builtin_fmaf(r, acc[i][j][4 * g + 0], __builtin_fmaf(nrm, c1.x, bias.x));
+            v1 = __builtin_fmaf(r, acc[i][j][4 * g + 1], __builtin_fmaf(nrm, c1.y, bias.y));
+            v2 = __builtin_fmaf(r, acc[i][j][4 * g + 2], __builtin_fmaf(nrm, c1.z, bias.z));
+            v3 = __builtin_fmaf(r, acc[i][j][4 * g + 3], __builtin_fmaf(nrm, c1.w, bias.w));
+          } else {
+            v0 = acc[i][j][4 * g + 0] + bias.x; v1 = acc[i][j][4 * g + 1] + bias.y;
+            v2 = acc[i][j][4 * g + 2] + bias.z; v3 = acc[i][j][4 * g + 3] + bias.w;
+          }
           bf16x4 o;
           if (EPI == EPI_BIAS_GELU_BF16) o = pack4(gelu_tanh_f(v0), gelu_tanh_f(v1), gelu_tanh_f(v2), gelu_tanh_f(v3));
           else o = pack4(v0, v1, v2, v3);
@@ -531,20 +630,40 @@ __device__ __forceinline__ void epilogue_row_blocks(const GemmParams& p, f32x16 
 // ---- plain orientation, used only for the V projection (EPI_V_T): lane -> column n (= head dim d),
 //      register r -> row m = mw + 32 i + (r&3) + 8 (r>>2) + 4 (lane>>5).  The slab is [d][pos] so that v^T rows
 //      (contiguous positions) leave as whole 64/128-B segments.
+// ln fold (p.ln_part): `rs` = the (r, -r mu) pairs of the rows mw .. mw + 32 TI - 1 in LDS; four consecutive rows per register group.
 template <int TI, int TJ>
-__device__ __forceinline__ void epilogue_vt(const GemmParams& p, f32x16 (&acc)[TI][TJ], char* slab, int mw, int nw, int lane) {
+__device__ __forceinline__ void epilogue_vt(const GemmParams& p, f32x16 (&acc)[TI][TJ], char* slab, int mw, int nw, int lane,
+                                            const float* rs = nullptr) {
   constexpr int WTM = 32 * TI, WTN = 32 * TJ;
   using S = SlabBf16<WTN, WTM>;   // rows = d (WTN of them), columns = positions (WTM)
   const int l31 = lane & 31, hi = lane >> 5;
+  const bool lna = p.ln_part != nullptr;
+  const float* bsrc = p.bias;
+  const float* c1src = nullptr;
+  if (lna) {
+    const float* row = p.tab + (size_t)p.step_idx[0] * p.tab_stride;
+    bsrc = row + p.lnc2_off;
+    c1src = row + p.lnc1_off;
+  }
 #pragma unroll
   for (int j = 0; j < TJ; ++j) {
-    const float bias = p.bias[nw + j * 32 + l31];
+    const float bias = bsrc[nw + j * 32 + l31];
+    const float c1 = lna ? c1src[nw + j * 32 + l31] : 0.f;
 #pragma unroll
     for (int i = 0; i < TI; ++i)
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
+      for (int g = 0; g < 4; ++g) {
+        float4 ra = make_float4(1.f, 0.f, 1.f, 0.f), rb = ra;      // (r, -r mu) of rows +0, +1 | +2, +3
+        if (lna) {
+          ra = *reinterpret_cast<const float4*>(rs + 2 * (i * 32 + 8 * g + 4 * hi));
+          rb = *reinterpret_cast<const float4*>(rs + 2 * (i * 32 + 8 * g + 4 * hi) + 4);
+        }
         *reinterpret_cast<bf16x4*>(slab + (j * 32 + l31) * S::PITCH + (i * 32 + 8 * g + 4 * hi) * 2) =
-            pack4(acc[i][j][4 * g + 0] + bias, acc[i][j][4 * g + 1] + bias, acc[i][j][4 * g + 2] + bias, acc[i][j][4 * g + 3] + bias);
+            pack4(__builtin_fmaf(ra.x, acc[i][j][4 * g + 0], __builtin_fmaf(ra.y, c1, bias)),
+                  __builtin_fmaf(ra.z, acc[i][j][4 * g + 1], __builtin_fmaf(ra.w, c1, bias)),
+                  __builtin_fmaf(rb.x, acc[i][j][4 * g + 2], __builtin_fmaf(rb.y, c1, bias)),
+                  __builtin_fmaf(rb.z, acc[i][j][4 * g + 3], __builtin_fmaf(rb.w, c1, bias)));
+      }
   }
   const int rr = lane / S::CPR, ch = lane % S::CPR;
   const int b2 = mw / p.seq_pitch, pos0 = mw - b2 * p.seq_pitch;   // a wave tile never straddles samples (pitch % 128 == 0)
@@ -654,6 +773,49 @@ __device__ __forceinline__ void ln_tail(const GemmParams& p, int m0, int n0) {
   }
 }
 
+// ---------------------------------------------------------------- ln fold: row statistics on both sides of a GEMM (GemmParams)
+// consumer: thread t < TBM turns the LN_NP partial (sum, sum of squares) pairs of row m0 + t into (r, -r mu) in LDS.  The loads
+// are issued BEFORE the K loop's first LDS-DMA (so the counted vmcnt waits of the loops only ever see them as older operations)
+// and consumed after the prologue has been issued; the table lives behind the ring / slab area and is read by the epilogues.
+// TPR adjacent threads share a row (each takes LN_NP / TPR slots): thread t of the first TBM * TPR threads of the workgroup.
+template <int TPR> struct RowStatLoad { f32x4 v[LN_NP / 2 / TPR]; };
+template <int TPR>
+__device__ __forceinline__ void ln_rowstat_load(const GemmParams& p, int m0, int t, RowStatLoad<TPR>& L) {
+  int m = m0 + t / TPR;
+  m = m < p.M ? m : p.M - 1;
+  const float4* q = reinterpret_cast<const float4*>(p.ln_part + (size_t)m * (LN_NP * 2)) + (t % TPR) * (LN_NP / 2 / TPR);
+  // asm loads (invisible to the compiler's vmcnt bookkeeping, like the loops' fragment reads): the caller waits with an exact count
+  // -- the number of LDS-DMA instructions it issued after this -- instead of the vmcnt(0) the compiler would put in front of the first
+  // use, which also drains every prologue DMA
+#pragma unroll
+  for (int j = 0; j < LN_NP / 2 / TPR; ++j) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(L.v[j]) : "v"(q + j) : "memory");
+}
+template <int TPR>
+__device__ __forceinline__ void ln_rowstat_store(RowStatLoad<TPR>& L, float* rs, int t) {
+#pragma clang fp contract(off)
+  // the caller's s_waitcnt is a volatile asm just before this; these empty volatile asms stay behind it and make every use of the
+  // loaded registers depend on them (nothing that reads L.v can be scheduled above the wait)
+#pragma unroll
+  for (int j = 0; j < LN_NP / 2 / TPR; ++j) asm volatile("" : "+v"(L.v[j]));
+  // one balanced binary tree over the 16 slots whatever TPR is (pairs inside a float4, then inside the thread, then across the TPR
+  // threads): the statistics of a row do not depend on the tile that consumes it (single-lane and two-lane runs stay bit-identical)
+  constexpr int NV = LN_NP / 2 / TPR;
+  float a[NV], b[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) { a[j] = L.v[j][0] + L.v[j][2]; b[j] = L.v[j][1] + L.v[j][3]; }
+#pragma unroll
+  for (int w = 1; w < NV; w <<= 1)
+#pragma unroll
+    for (int j = 0; j + w < NV; j += 2 * w) { a[j] += a[j + w]; b[j] += b[j + w]; }
+  float s = a[0], ss = b[0];
+#pragma unroll
+  for (int o = 1; o < TPR; o <<= 1) { s += __shfl_xor(s, o, 64); ss += __shfl_xor(ss, o, 64); }
+  const float mean = s * (1.0f / LN_D);
+  float var = ss * (1.0f / LN_D) - mean * mean;
+  var = var > 0.f ? var : 0.f;
+  const float r = rsqrtf(var + 1e-6f);
+  if (t % TPR == 0) *reinterpret_cast<float2*>(rs + 2 * (t / TPR)) = make_float2(r, -r * mean);
+}
 template <bool F8> struct FragT { using type = bf16x8; };
 template <> struct FragT<true> { using type = i32x8; };
 
@@ -663,7 +825,7 @@ template <> struct FragT<true> { using type = i32x8; };
 // (probed on the hardware, tools/exp/mx_probe.hip): lane (i = l&31, h = l>>5) holds row i; registers 0-3 are K
 // 16h..16h+15 and registers 4-7 are K 32+16h..; the scale of K-block beta (32 K) comes from lane i + 32 beta.
 template <int EPI, int TBM, int TBN, int NSTAGE, int NWM, int NWN, bool SWAP, bool F8>
-__device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, int m0, int n0) {
+__device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, int m0, int n0, float* rs_lds) {
   using frag_t = typename FragT<F8>::type;
   constexpr int NW = NWM * NWN;                       // waves per workgroup
   constexpr int WTM = TBM / NWM, WTN = TBN / NWN;     // wave tile
@@ -730,13 +892,23 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, int m
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   constexpr bool PREFETCH_EPI = SWAP && EPI != EPI_BIAS_GELU_F8;
-  EpiPre<EPI, TJ, true> pre;
+  constexpr int LNA = (epi_lna<EPI>() && !F8) ? 1 : 0;      // the fp8 path keeps its MXFP8 LayerNorm launch
+  EpiPre<EPI, TJ, true, LNA> pre;
 
   const int nk = (int)(rowb >> 7);
   PHASE_STAMP(0); PHASE_STAMP(1);
+  constexpr int TPR = (64 * NW / TBM) >= 4 ? 4 : (64 * NW / TBM) >= 2 ? 2 : 1;
+  RowStatLoad<TPR> rsl;
+  bool rs_mine = false;
+  if constexpr (LNA != 0) {
+    rs_mine = p.ln_part != nullptr && tid < TBM * TPR;
+    if (rs_mine) ln_rowstat_load<TPR>(p, m0, tid, rsl);
+  }
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s)
     if (s < nk) issue(s, s);
+  // (the loaded statistics stay in registers through the K loop -- they are older than every LDS-DMA, so the loop's counted waits cover
+  // them -- and become the (r, -r mu) table just before the epilogue: waiting for them here costs ~1-2 us of every launch)
 
   // one MFMA of k-step kk; asc = this lane's scale dword for the A row-fragment, already shifted by 8 hi
   auto mfma1 = [&](const frag_t& fa, const frag_t& fb, f32x16& c, int kk, int asc) {
@@ -846,19 +1018,20 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, int m
       }
     }
   }
+  if constexpr (LNA != 0) { if (rs_mine) ln_rowstat_store<TPR>(rsl, rs_lds, tid); }
   __syncthreads();   // every wave is done with the ring: its LDS becomes the epilogue slabs
   PHASE_STAMP(2);
   // one 32-row block of the wave tile at a time through a small wave-private slab (LDS ops of a wave execute in order, so
   // the slab can be rewritten right after it was read): keeps the kernel's LDS footprint = the ring, not ring + big slabs
   char* slab = smem + wave * slab_bytes<EPI, 32, WTN>();
   if constexpr (SWAP && EPI != EPI_BIAS_GELU_F8) {
-    epilogue_row_blocks<EPI, TI, TJ, true>(p, acc, slab, m0 + wm * WTM, n0 + wn * WTN, lane, pre);
+    epilogue_row_blocks<EPI, TI, TJ, true, true, LNA>(p, acc, slab, m0 + wm * WTM, n0 + wn * WTN, lane, pre, rs_lds + 2 * (wm * WTM));
   } else {
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
       f32x16 (&blk)[1][TJ] = *reinterpret_cast<f32x16 (*)[1][TJ]>(&acc[i]);
       if (SWAP) epilogue_rows<EPI, 1, TJ>(p, blk, slab, m0 + wm * WTM + 32 * i, n0 + wn * WTN, lane);
-      else epilogue_vt<1, TJ>(p, blk, slab, m0 + wm * WTM + 32 * i, n0 + wn * WTN, lane);
+      else epilogue_vt<1, TJ>(p, blk, slab, m0 + wm * WTM + 32 * i, n0 + wn * WTN, lane, rs_lds + 2 * (wm * WTM + 32 * i));
     }
   }
   if constexpr (EPI == EPI_GATE_RES && SWAP && !F8) {
@@ -889,7 +1062,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, int m
 //   WAR  the DMA that overwrites buffer [parity][op][half] is issued a full K-tile (>= 2 phases, 4 barriers) after the last
 //        read of its previous content, and those reads were retired by an lgkmcnt(0) before their own MFMA segment.
 template <int EPI, bool SWAP>
-__device__ __forceinline__ void gemm_body_pp(const GemmParams& p, char* smem, int m0, int n0) {
+__device__ __forceinline__ void gemm_body_pp(const GemmParams& p, char* smem, int m0, int n0, float* rs_lds) {
   constexpr int HT = 16384;                 // bytes per half-tile buffer: 128 rows x 128 B
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -980,7 +1153,14 @@ __device__ __forceinline__ void gemm_body_pp(const GemmParams& p, char* smem, in
 
   // ---- prologue: the four half-tiles of K-tile 0 in consumption order (W0, A0, W1, A1); W0 and A0 must have landed
   PHASE_STAMP(0);
+  RowStatLoad<2> rsl;      // 512 threads, 256 rows
+  bool rs_mine = false;
+  if constexpr (epi_lna<EPI>()) {
+    rs_mine = p.ln_part != nullptr;
+    if (rs_mine) ln_rowstat_load<2>(p, m0, tid, rsl);
+  }
   issue_half(1, 0, 0); issue_half(0, 0, 0); issue_half(1, 1, 0); issue_half(0, 1, 0);
+  if constexpr (epi_lna<EPI>()) { if (rs_mine) { wait_vmcnt<8>(); ln_rowstat_store<2>(rsl, rs_lds, tid); } }
   wait_vmcnt<4>();
   __builtin_amdgcn_s_barrier();
   PHASE_STAMP(1);
@@ -1021,14 +1201,19 @@ __device__ __forceinline__ void gemm_body_pp(const GemmParams& p, char* smem, in
     // 128 accumulator registers are still live here: the gate + residual epilogue has no room for its column vectors or a second
     // set of residual rows (and gained nothing from them: at full chip it is bound by the fp32 read-modify-write traffic), and
     // the loop (224-256 VGPRs) none for an early request
-    EpiPre<EPI, 2, EPI != EPI_GATE_RES> pre;
+    constexpr int LNA = epi_lna<EPI>() ? 2 : 0;
+    EpiPre<EPI, 2, EPI != EPI_GATE_RES, LNA> pre;
     pre.load(p, m0 + wm * 128, n0 + wn * 64, lane);
-    epilogue_row_blocks<EPI, 4, 2, EPI != EPI_GATE_RES, EPI != EPI_GATE_RES>(p, acc, slab, m0 + wm * 128, n0 + wn * 64, lane, pre);
+    if constexpr (EPI == EPI_GATE_RES) {
+      epilogue_row_blocks<EPI, 4, 2, false, false, LNA>(p, acc, slab, m0 + wm * 128, n0 + wn * 64, lane, pre);
+    } else {
+      epilogue_row_blocks<EPI, 4, 2, true, true, LNA>(p, acc, slab, m0 + wm * 128, n0 + wn * 64, lane, pre, rs_lds + 2 * (wm * 128));
+    }
   } else {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       f32x16 (&blk)[1][2] = *reinterpret_cast<f32x16 (*)[1][2]>(&acc[i]);
-      epilogue_vt<1, 2>(p, blk, slab, m0 + wm * 128 + 32 * i, n0 + wn * 64, lane);
+      epilogue_vt<1, 2>(p, blk, slab, m0 + wm * 128 + 32 * i, n0 + wn * 64, lane, rs_lds + 2 * (wm * 128 + 32 * i));
     }
   }
   PHASE_STAMP_END();
@@ -1044,7 +1229,7 @@ __device__ __forceinline__ void gemm_body_pp(const GemmParams& p, char* smem, in
 // segment of the second phase of its predecessor and read one phase later; every wave retires its fragment reads (lgkmcnt 0)
 // BEFORE the barrier that ends its L segment, so the stage of K-tile t-1 may be restaged by either group right after that barrier.
 template <int EPI, bool SWAP>
-__device__ __forceinline__ void gemm_body_pp2(const GemmParams& p, char* smem, int m0, int n0) {
+__device__ __forceinline__ void gemm_body_pp2(const GemmParams& p, char* smem, int m0, int n0, float* rs_lds) {
   constexpr int A_BYTES = 256 * 128, STAGE = (256 + 128) * 128;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1128,6 +1313,12 @@ __device__ __forceinline__ void gemm_body_pp2(const GemmParams& p, char* smem, i
 
   // prologue: K-tiles 0 and 1 requested, K-tile 0 landed
   PHASE_STAMP(0);
+  RowStatLoad<2> rsl;      // 512 threads, 256 rows
+  bool rs_mine = false;
+  if constexpr (epi_lna<EPI>()) {
+    rs_mine = p.ln_part != nullptr;
+    if (rs_mine) ln_rowstat_load<2>(p, m0, tid, rsl);
+  }
 #pragma unroll
   for (int x = 0; x < 6; ++x) issue_piece(0, 0, x);
   if (nk > 1) {
@@ -1173,16 +1364,18 @@ __device__ __forceinline__ void gemm_body_pp2(const GemmParams& p, char* smem, i
     stage = stage == 2 ? 0 : stage + 1;
   }
   if (wm < 2) __builtin_amdgcn_s_barrier();      // rows 0-1 catch up: equal barrier counts
+  // ln fold: the statistics loaded at the top (older than every LDS-DMA: long since landed) become the (r, -r mu) table now
+  if constexpr (epi_lna<EPI>()) { if (rs_mine) ln_rowstat_store<2>(rsl, rs_lds, tid); }
   __syncthreads();
   PHASE_STAMP(2);
   char* slab = smem + wave * slab_bytes<EPI, 32, 64>();
   if constexpr (SWAP) {
-    epilogue_row_blocks<EPI, 2, 2, true>(p, acc, slab, m0 + wm * 64, n0 + wn * 64, lane, pre);
+    epilogue_row_blocks<EPI, 2, 2, true>(p, acc, slab, m0 + wm * 64, n0 + wn * 64, lane, pre, rs_lds + 2 * (wm * 64));
   } else {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       f32x16 (&blk)[1][2] = *reinterpret_cast<f32x16 (*)[1][2]>(&acc[i]);
-      epilogue_vt<1, 2>(p, blk, slab, m0 + wm * 64 + 32 * i, n0 + wn * 64, lane);
+      epilogue_vt<1, 2>(p, blk, slab, m0 + wm * 64 + 32 * i, n0 + wn * 64, lane, rs_lds + 2 * (wm * 64 + 32 * i));
     }
   }
   PHASE_STAMP_END();
@@ -1193,12 +1386,12 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int tm, tn;
   tile_coords(xcd_remap(blockIdx.x, gridDim.x), (p.M + 255) / 256, p.N / 128, p.xcd_gx, tm, tn);
-  gemm_body_pp2<EPI, EPI != EPI_V_T>(p, smem, tm * 256, tn * 128);
+  gemm_body_pp2<EPI, EPI != EPI_V_T>(p, smem, tm * 256, tn * 128, reinterpret_cast<float*>(smem + 3 * (256 + 128) * 128));
 }
 
 template <int EPI>
 struct LaunchPP2 {
-  static constexpr int lds = 3 * (256 + 128) * 128;
+  static constexpr int lds = 3 * (256 + 128) * 128 + 256 * 8;     // ring + the ln-fold (r, -r mu) table of the tile's rows
   static hipError_t init() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp2_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   }
@@ -1216,13 +1409,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int tm, tn;
   tile_coords(xcd_remap(blockIdx.x, gridDim.x), (p.M + 255) / 256, p.N / 256, p.xcd_gx, tm, tn);
-  gemm_body_pp<EPI, EPI != EPI_V_T>(p, smem, tm * 256, tn * 256);
+  gemm_body_pp<EPI, EPI != EPI_V_T>(p, smem, tm * 256, tn * 256, reinterpret_cast<float*>(smem + 8 * 16384));
 }
 
 template <int EPI>
 struct LaunchPP {
-  static constexpr int lds = 8 * 16384;
-  static_assert(8 * slab_bytes<EPI, 32, 64>() <= lds, "epilogue slabs must fit the half-tile buffers");
+  static constexpr int lds = 8 * 16384 + 256 * 8;                 // half-tile buffers + the ln-fold (r, -r mu) table
+  static_assert(8 * slab_bytes<EPI, 32, 64>() <= 8 * 16384, "epilogue slabs must fit the half-tile buffers");
   static hipError_t init() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   }
@@ -1235,12 +1428,21 @@ struct LaunchPP {
   }
 };
 
+// LDS of the lock-step body: the ring (reused by the epilogue slabs), then the ln-fold (r, -r mu) table of the tile's rows
+template <int EPI, int TBM, int TBN, int NSTAGE, int NWM, int NWN, bool F8>
+constexpr int body_lds_base() {
+  constexpr int ring = NSTAGE * ((TBM + TBN) * 128 + (F8 ? TBM * 4 : 0));
+  constexpr int slabs = NWM * NWN * slab_bytes<EPI, 32, TBN / NWN>();
+  return ring > slabs ? ring : slabs;
+}
+
 template <int EPI, int TBM, int TBN, int NSTAGE, int NWM, int NWN, bool F8>
 __global__ __launch_bounds__(64 * NWM * NWN) void gemm_bf16_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int tm, tn;
   tile_coords(xcd_remap(blockIdx.x, gridDim.x), (p.M + TBM - 1) / TBM, p.N / TBN, p.xcd_gx, tm, tn);
-  gemm_body<EPI, TBM, TBN, NSTAGE, NWM, NWN, EPI != EPI_V_T, F8>(p, smem, tm * TBM, tn * TBN);
+  gemm_body<EPI, TBM, TBN, NSTAGE, NWM, NWN, EPI != EPI_V_T, F8>(p, smem, tm * TBM, tn * TBN,
+      reinterpret_cast<float*>(smem + body_lds_base<EPI, TBM, TBN, NSTAGE, NWM, NWN, F8>()));
 }
 
 // The tile shapes in use.
@@ -1265,13 +1467,13 @@ template <> struct TileCfg<T128x128> { static constexpr int BM = 128, BN = 128, 
 template <> struct TileCfg<T128x64>  { static constexpr int BM = 128, BN = 64,  ST = 3, WM = 2, WN = 2; };
 template <> struct TileCfg<T64x64>   { static constexpr int BM = 64,  BN = 64,  ST = 3, WM = 2, WN = 2; };
 template <> struct TileCfg<T128x128W4> { static constexpr int BM = 128, BN = 128, ST = 3, WM = 2, WN = 2; };
+// Tried and dropped in round 3 (profiles/r03_structural_attempts.txt): the 8 waves as 4 x 2 (whole 128-B lines for the ln-fold image:
+// +0.7 us plain, -0.7 us as fold producer) and a TWO-stage ring (64 KB: two workgroups per CU; -2 ... -8 % end to end).
 
 template <int EPI, int TILE, bool F8>
 struct Launch {
   using C = TileCfg<TILE>;
-  static constexpr int ring = C::ST * ((C::BM + C::BN) * 128 + (F8 ? C::BM * 4 : 0));
-  static constexpr int slabs = C::WM * C::WN * slab_bytes<EPI, 32, C::BN / C::WN>();
-  static constexpr int lds = ring > slabs ? ring : slabs;
+  static constexpr int lds = body_lds_base<EPI, C::BM, C::BN, C::ST, C::WM, C::WN, F8>() + C::BM * 8;
   static_assert(lds <= 160 * 1024, "LDS budget");
   static const void* fn() { return reinterpret_cast<const void*>(gemm_bf16_kernel<EPI, C::BM, C::BN, C::ST, C::WM, C::WN, F8>); }
   // the > 64 KB dynamic-LDS opt-in; done once from lemas_kernels_init(), never on a launch path (a launch may sit inside a
@@ -1354,31 +1556,40 @@ hipError_t init_epi() {
 // 256x128 at configs[1] (128 + 64 workgroups; measured 0.6 % faster end to end than 128x128 V tiles), 128x128 / 128x64 for short
 // utterances, where 256-row tiles leave most of the chip idle (N = 750: 72 workgroups, 19.6 us -- as long as at N = 1875).
 template <bool F8, int TILE>
+struct QkvLds {
+  using C = TileCfg<TILE>;
+  static constexpr int NW = C::WM * C::WN;
+  static constexpr int ring = C::ST * ((C::BM + C::BN) * 128 + (F8 ? C::BM * 4 : 0));
+  static constexpr int slab_q = NW * slab_bytes<EPI_QK_ROPE, 32, C::BN / C::WN>(), slab_v = NW * slab_bytes<EPI_V_T, 32, C::BN / C::WN>();
+  static constexpr int slab = slab_q > slab_v ? slab_q : slab_v;
+  static constexpr int base = ring > slab ? ring : slab;      // then the ln-fold (r, -r mu) table of the tile's rows
+  static constexpr int lds = base + C::BM * 8;
+};
+
+template <bool F8, int TILE>
 __global__ __launch_bounds__(64 * TileCfg<TILE>::WM * TileCfg<TILE>::WN) void gemm_qkv_fused_kernel(const GemmParams pq, const GemmParams pv,
                                                                                                       int tiles_q, int tiles_v) {
   using C = TileCfg<TILE>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int bid = blockIdx.x;
+  float* rs = reinterpret_cast<float*>(smem + QkvLds<F8, TILE>::base);
   int tm, tn;
   if (bid < tiles_q) {
     tile_coords(xcd_remap(bid, tiles_q), (pq.M + C::BM - 1) / C::BM, pq.N / C::BN, pq.xcd_gx, tm, tn);
-    if constexpr (!F8 && TILE == T256x128) gemm_body_pp2<EPI_QK_ROPE, true>(pq, smem, tm * 256, tn * 128);
-    else gemm_body<EPI_QK_ROPE, C::BM, C::BN, C::ST, C::WM, C::WN, true, F8>(pq, smem, tm * C::BM, tn * C::BN);
+    if constexpr (!F8 && TILE == T256x128) gemm_body_pp2<EPI_QK_ROPE, true>(pq, smem, tm * 256, tn * 128, rs);
+    else gemm_body<EPI_QK_ROPE, C::BM, C::BN, C::ST, C::WM, C::WN, true, F8>(pq, smem, tm * C::BM, tn * C::BN, rs);
   } else {
     tile_coords(xcd_remap(bid - tiles_q, tiles_v), (pv.M + C::BM - 1) / C::BM, pv.N / C::BN, pv.xcd_gx, tm, tn);
-    if constexpr (!F8 && TILE == T256x128) gemm_body_pp2<EPI_V_T, false>(pv, smem, tm * 256, tn * 128);
-    else gemm_body<EPI_V_T, C::BM, C::BN, C::ST, C::WM, C::WN, false, F8>(pv, smem, tm * C::BM, tn * C::BN);
+    if constexpr (!F8 && TILE == T256x128) gemm_body_pp2<EPI_V_T, false>(pv, smem, tm * 256, tn * 128, rs);
+    else gemm_body<EPI_V_T, C::BM, C::BN, C::ST, C::WM, C::WN, false, F8>(pv, smem, tm * C::BM, tn * C::BN, rs);
   }
 }
 
 template <bool F8, int TILE>
 struct LaunchQkv {
   using C = TileCfg<TILE>;
-  static constexpr int ring = C::ST * ((C::BM + C::BN) * 128 + (F8 ? C::BM * 4 : 0));
   static constexpr int NW = C::WM * C::WN;
-  static constexpr int slab_q = NW * slab_bytes<EPI_QK_ROPE, 32, C::BN / C::WN>(), slab_v = NW * slab_bytes<EPI_V_T, 32, C::BN / C::WN>();
-  static constexpr int slab = slab_q > slab_v ? slab_q : slab_v;
-  static constexpr int lds = ring > slab ? ring : slab;
+  static constexpr int lds = QkvLds<F8, TILE>::lds;
   static_assert(lds <= 160 * 1024, "LDS budget");
   static hipError_t init() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_qkv_fused_kernel<F8, TILE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -1393,6 +1604,21 @@ struct LaunchQkv {
     return hipGetLastError();
   }
 };
+
+// Several independent GEMMs of the same epilogue in ONE launch (blockIdx.y picks a parameter block from device memory, 128 x 128
+// lock-step tiles): the 2 x depth small ln-fold table GEMMs of a prepare() ([4 S rows] x [3 inner | ff] x dim each) would otherwise be
+// 44 launches of ~20 workgroups.
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_group_kernel(const GemmParams* __restrict__ ps) {
+  using C = TileCfg<T128x128>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const GemmParams& p = ps[blockIdx.y];
+  const int tiles_n = p.N / C::BN, tiles = ((p.M + C::BM - 1) / C::BM) * tiles_n;
+  const int bid = blockIdx.x;
+  if (bid >= tiles) return;
+  gemm_body<EPI, C::BM, C::BN, C::ST, C::WM, C::WN, true, false>(p, smem, (bid / tiles_n) * C::BM, (bid % tiles_n) * C::BN,
+      reinterpret_cast<float*>(smem + body_lds_base<EPI, C::BM, C::BN, C::ST, C::WM, C::WN, false>()));
+}
 
 // tile of the fused QK+V launch: the largest whose QK part alone still gives ~100 workgroups per lane (two lanes share the chip)
 int pick_qkv_tile(const GemmParams& pq) {
@@ -1412,6 +1638,8 @@ hipError_t gemm_bf16_init() {
   LEMAS_INIT(EPI_V_T)
 #undef LEMAS_INIT
   if ((e = init_epi<EPI_BIAS_GELU_F8, true>()) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_group_kernel<EPI_BIAS_F32>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               Launch<EPI_BIAS_F32, T128x128, false>::lds)) != hipSuccess) return e;
   if ((e = LaunchQkv<false, T256x128>::init()) != hipSuccess) return e;
   if ((e = LaunchQkv<false, T128x128>::init()) != hipSuccess) return e;
   if ((e = LaunchQkv<false, T128x64>::init()) != hipSuccess) return e;
@@ -1433,8 +1661,30 @@ static int pick_xcd_gx(int M, int N) {
   return best;
 }
 
+// ln fold: what a launch that consumes (ln_part) or produces (xs_out) the folded LayerNorm must look like
+static bool ln_fold_ok(int epi, const GemmParams& p) {
+  if (p.ln_part) {
+    if (!(epi == EPI_QK_ROPE || epi == EPI_V_T || epi == EPI_BIAS_GELU_BF16)) return false;
+    if (p.f8 || p.K != LN_D || p.ln_np != LN_NP || !p.tab || !p.step_idx) return false;
+  }
+  if (p.xs_out) {
+    if (epi != EPI_GATE_RES || p.f8 || p.N != LN_D || p.ldc != LN_D || p.n_valid != LN_D || p.ln_np != LN_NP || !p.ln_part_out || !p.tab ||
+        !p.step_idx)
+      return false;
+  }
+  return true;
+}
+
+hipError_t launch_gemm_bf16_group(const GemmParams* dev_params, int groups, int max_tiles, hipStream_t s) {
+  if (groups <= 0 || max_tiles <= 0) return hipErrorInvalidValue;
+  constexpr int lds = Launch<EPI_BIAS_F32, T128x128, false>::lds;
+  hipLaunchKernelGGL((gemm_group_kernel<EPI_BIAS_F32>), dim3(max_tiles, groups), dim3(512), lds, s, dev_params);
+  return hipGetLastError();
+}
+
 hipError_t launch_gemm_qkv_fused(const GemmParams& pq_in, const GemmParams& pv_in, hipStream_t s) {
   GemmParams pq = pq_in, pv = pv_in;
+  if (!ln_fold_ok(EPI_QK_ROPE, pq) || !ln_fold_ok(EPI_V_T, pv) || pq.xs_out || pv.xs_out) return hipErrorInvalidValue;
   // only {8, 4, 2, 1} cut the tile grid into 8 XCD blocks (anything else would make tile_coords divide by zero or skip tiles)
   if (pq.xcd_gx != 8 && pq.xcd_gx != 4 && pq.xcd_gx != 2 && pq.xcd_gx != 1) pq.xcd_gx = pick_xcd_gx(pq.M, pq.N);
   if (pv.xcd_gx != 8 && pv.xcd_gx != 4 && pv.xcd_gx != 2 && pv.xcd_gx != 1) pv.xcd_gx = pick_xcd_gx(pv.M, pv.N);
@@ -1471,6 +1721,7 @@ hipError_t launch_gemm_bf16_tile(int epi, const GemmParams& p_in, int tile, hipS
   GemmParams p = p_in;
   if (p.xcd_gx != 8 && p.xcd_gx != 4 && p.xcd_gx != 2 && p.xcd_gx != 1) p.xcd_gx = pick_xcd_gx(p.M, p.N);
   if (p.K % BK != 0 || p.N % 128 != 0 || p.M <= 0 || p.seq_pitch <= 0) return hipErrorInvalidValue;
+  if (!ln_fold_ok(epi, p)) return hipErrorInvalidValue;
   if (p.ln_out) {   // LayerNorm tail: only on the tiles that carry it, with complete row panels and the counters in place
     int bm, bn, per_cu;
     if (epi != EPI_GATE_RES || p.f8 || p.N != LN_D || p.ldc != LN_D || p.n_valid != LN_D || !p.ln_cnt || !p.ln_err || !p.tab || !p.step_idx)

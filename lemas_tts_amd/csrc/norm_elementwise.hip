@@ -41,6 +41,88 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const float* __restrict__ x
   for (int r = 0; r < ROWS; ++r) ln_row_store(v[r], a, b, out + (size_t)(row0 + r) * D, lane, row0 + r < M);
 }
 
+// ln fold (GemmParams): the entry of a lane's block chain, where no gate + residual GEMM precedes the first LayerNorm.  Writes what
+// such a GEMM's epilogue would: xs = bf16(x (1 + scale)) and the (sum, sum of squares) pair of each 32-column slot of each row, added
+// up in the same order (4-column groups, then a binary tree over the slot's 8 groups).
+// Row image as in ln_core.h: v[i][h] = row[8 (lane + 64 i) + 4 h ..], so slot (lane >> 2) + 16 i is shared by 4 consecutive lanes.
+template <int ROWS>
+__global__ __launch_bounds__(256) void ln_prep_kernel(const float* __restrict__ x, bf16_t* __restrict__ xs, float* __restrict__ part, int M,
+                                                      const float* __restrict__ tab, int tab_stride, int scale_off,
+                                                      const int* __restrict__ step_idx) {
+  constexpr int PER = LN_PER, D = LN_D;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS;
+  if (row0 >= M) return;
+  const int lane = threadIdx.x & 63;
+  const float* base = tab + (step_idx ? (size_t)step_idx[0] * tab_stride : 0);
+  float4 v[ROWS][PER][2];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    const int row = row0 + r < M ? row0 + r : M - 1;
+    const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * D);
+#pragma unroll
+    for (int i = 0; i < PER; ++i)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) v[r][i][h] = xr[(lane + 64 * i) * 2 + h];
+  }
+  float4 a[PER][2];
+  ln_load_vec(base + scale_off, lane, a);
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    const int row = row0 + r;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      float g1[2], g2[2];
+      bf16x8 o;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float4 t = v[r][i][h];
+        g1[h] = (t.x + t.y) + (t.z + t.w);
+        g2[h] = __builtin_fmaf(t.x, t.x, __builtin_fmaf(t.y, t.y, __builtin_fmaf(t.z, t.z, t.w * t.w)));
+        o[4 * h + 0] = (bf16_t)(t.x * (1.0f + a[i][h].x)); o[4 * h + 1] = (bf16_t)(t.y * (1.0f + a[i][h].y));
+        o[4 * h + 2] = (bf16_t)(t.z * (1.0f + a[i][h].z)); o[4 * h + 3] = (bf16_t)(t.w * (1.0f + a[i][h].w));
+      }
+      float s1 = g1[0] + g1[1], s2 = g2[0] + g2[1];
+#pragma unroll
+      for (int m = 1; m < 4; m <<= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }
+      if (row < M) {
+        store_wt_b128(xs + (size_t)row * D + (lane + 64 * i) * 8, __builtin_bit_cast(u32x4, o));
+        if ((lane & 3) == 0) *reinterpret_cast<float2*>(part + ((size_t)row * (D / 32) + (lane >> 2) + 16 * i) * 2) = make_float2(s1, s2);
+      }
+    }
+  }
+}
+
+// ln-fold tables, once per t-grid (prepare()): for every site (a LayerNorm + the GEMM behind it) and ODE step
+//   c1[n] = sum_k (1 + scale_k) W[n][k],   c2[n] = sum_k shift_k W[n][k] + bias[n].
+// The sums run on the bf16 MFMA GEMM against the SAME bf16 weights the step loop multiplies with: (1 + scale) and shift are cut into two
+// bf16 terms each (hi = bf16(v), lo = bf16(v - hi): 16 mantissa bits, products exact in the fp32 accumulator), stacked as the rows
+// [hi(1+scale) | lo | hi(shift) | lo] x S of one small A matrix per site, and the four partial rows are added up afterwards.
+__global__ __launch_bounds__(256) void ln_fold_split_kernel(const float* __restrict__ tab, int tab_stride, int S, int d,
+                                                            const LnFoldSite* __restrict__ sites, bf16_t* __restrict__ A) {
+  const int step = blockIdx.x, site = blockIdx.y;
+  const LnFoldSite st = sites[site];
+  const float* row = tab + (size_t)step * tab_stride;
+  bf16_t* a = A + (size_t)site * 4 * S * d;
+  for (int k = threadIdx.x; k < d; k += 256) {
+    const float sc = 1.0f + row[st.scale_off + k], sh = row[st.shift_off + k];
+    const bf16_t sch = (bf16_t)sc, shh = (bf16_t)sh;
+    a[(size_t)(0 * S + step) * d + k] = sch;
+    a[(size_t)(1 * S + step) * d + k] = (bf16_t)(sc - (float)sch);
+    a[(size_t)(2 * S + step) * d + k] = shh;
+    a[(size_t)(3 * S + step) * d + k] = (bf16_t)(sh - (float)shh);
+  }
+}
+__global__ __launch_bounds__(256) void ln_fold_combine_kernel(const LnFoldSite* __restrict__ sites, int S, float* __restrict__ tab, int tab_stride) {
+  const LnFoldSite st = sites[blockIdx.z];
+  const int step = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= st.N) return;
+  const float* t = st.tmp;
+  const size_t N = (size_t)st.N;
+  float* row = tab + (size_t)step * tab_stride;
+  row[st.c1_off + n] = t[(size_t)(0 * S + step) * N + n] + t[(size_t)(1 * S + step) * N + n];
+  row[st.c2_off + n] = (t[(size_t)(2 * S + step) * N + n] + t[(size_t)(3 * S + step) * N + n]) + st.bias[n];
+}
+
 // Same row pass, written as MXFP8 for the fp8 GEMMs: e4m3 bytes + one E8M0 scale per 32 columns.  A 32-column block is
 // the float4s of 8 consecutive lanes (for each of the PER strides), so the block max is three xor-shuffles.
 template <int D>
@@ -226,6 +308,21 @@ hipError_t launch_ln_mod(const float* x, bf16_t* out, int M, int D, const float*
   if (D != 1024) return hipErrorInvalidValue;
   // two rows per wave: +0.4 ... 1.3 % end to end over one (tools/e2e_ab.py, all three workloads)
   hipLaunchKernelGGL((ln_mod_kernel<1024, 2>), dim3((M + 7) / 8), dim3(256), 0, s, x, out, M, tab, tab_stride, scale_off, shift_off, step_idx);
+  return hipGetLastError();
+}
+
+hipError_t launch_ln_prep(const float* x, bf16_t* xs, float* part, int M, int D, const float* tab, int tab_stride, int scale_off,
+                          const int* step_idx, hipStream_t s) {
+  if (D != LN_D) return hipErrorInvalidValue;
+  hipLaunchKernelGGL((ln_prep_kernel<2>), dim3((M + 7) / 8), dim3(256), 0, s, x, xs, part, M, tab, tab_stride, scale_off, step_idx);
+  return hipGetLastError();
+}
+hipError_t launch_ln_fold_split(const float* tab, int tab_stride, int S, int d, const LnFoldSite* sites, int nsites, bf16_t* A, hipStream_t s) {
+  hipLaunchKernelGGL(ln_fold_split_kernel, dim3(S, nsites), dim3(256), 0, s, tab, tab_stride, S, d, sites, A);
+  return hipGetLastError();
+}
+hipError_t launch_ln_fold_combine(const LnFoldSite* sites, int nsites, int max_n, int S, float* tab, int tab_stride, hipStream_t s) {
+  hipLaunchKernelGGL(ln_fold_combine_kernel, dim3((max_n + 255) / 256, S, nsites), dim3(256), 0, s, sites, S, tab, tab_stride);
   return hipGetLastError();
 }
 

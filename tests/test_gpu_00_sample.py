@@ -205,3 +205,32 @@ def test_seed_draws_the_reference_cpu_noise(golden_dir):
                            sway_sampling_coef=float(fx["coef"]), seed=seed, use_acc_grl=False, return_trajectory=True)
         np.testing.assert_array_equal(tr[0].cpu().numpy(), fx["y0"])
         assert _gen_mse(out.cpu().numpy(), fx["out"], fx) <= MSE_TOL
+
+
+@pytest.mark.parametrize("name", ["mini_plain", "mini_batch", "mini_prosody", "full_plain", "full_outlier"])
+def test_ln_fold_option_meets_the_reference_goldens(golden_dir, name):
+    """Option "ln_fold" (off by default, csrc/common.h GemmParams): the block chain's LayerNorms folded across the GEMMs on either side --
+    no LayerNorm launches after a step's first, per-step c1 / c2 rows in the AdaLN table.  It is a different rounding of the same
+    arithmetic (bf16 of x (1 + s) instead of LN(x) (1 + s) + b), so the bar is the reference's golden at the sampler's tolerance; the
+    single-lane, two-lane, eager and replayed runs of the fold stay bit-identical among themselves (the row statistics are added up in
+    one fixed tree whatever tile produces or consumes them)."""
+    fx, arch, sd = _load(golden_dir, name)
+    m = _model(arch, int(fx["vocab"]), int(fx["wseed"]), bool(fx["prosody"]), sd)
+    base, _ = _run_case(fx, arch, sd, graph=True, traj=False)
+    outs = {}
+    try:
+        m.engine.set_option("ln_fold", 1)
+        for dual in (1, 0):
+            m.engine.set_option("dual", dual)
+            for graph in (False, True):
+                outs[(dual, graph)] = _run_case(fx, arch, sd, graph=graph, traj=False)[0]
+    finally:
+        m.engine.set_option("dual", 1)
+        m.engine.set_option("ln_fold", 0)
+    m.engine.check_health()
+    out = outs[(1, True)]
+    mse, dm = _gen_mse(out, fx["out"], fx), _gen_mse(out, base, fx)
+    print(f"\n[{name}] ln_fold: mel-MSE vs reference {mse:.3e} (default path {_gen_mse(base, fx['out'], fx):.3e}), vs default path {dm:.3e}")
+    assert mse <= MSE_TOL, mse
+    for k, v in outs.items():
+        np.testing.assert_array_equal(v, out, err_msg=str(k))

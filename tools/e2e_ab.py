@@ -5,7 +5,7 @@
     python tools/e2e_ab.py --workload configs1 --arms default n1024=18 n1024=18,qkv_fused=0 [--rounds 3] [--steps 6]
 
 Arm syntax: comma-separated key=value with keys n1024 / n2048 / qkv / gx (GEMM tile ids and XCD block grid: the engine's per-engine
-measurement options tile_n1024 / tile_n2048 / tile_qkv / xcd_gx), qkv_fused, dual, fp8, ln_fused, overlap (vocoder on a side stream)."""
+measurement options tile_n1024 / tile_n2048 / tile_qkv / xcd_gx), qkv_fused, dual, fp8, ln_fused, ln_fold, overlap (vocoder on a side stream)."""
 import argparse
 import os
 import sys
@@ -55,6 +55,8 @@ def main():
         m.engine.set_option("tile_qkv", int(opts.get("qkv", 0)))
         m.engine.set_option("xcd_gx", int(opts.get("gx", 0)))
         m.engine.set_option("ln_fused", int(opts.get("ln_fused", 0)))
+        m.engine.set_option("ln_fold", int(opts.get("ln_fold", 0)))
+        m.engine.set_option("lane_skew", int(opts.get("skew", 0)))
         m.engine.set_option("attn_variant", int(opts.get("attn", DEFAULT_ATTN)))
         m.engine.set_option("fp8", int(opts.get("fp8", 0)))
         m.engine.set_option("qkv_fused", int(opts.get("qkv_fused", 1)))
