@@ -1468,7 +1468,10 @@ template <> struct TileCfg<T128x64>  { static constexpr int BM = 128, BN = 64,  
 template <> struct TileCfg<T64x64>   { static constexpr int BM = 64,  BN = 64,  ST = 3, WM = 2, WN = 2; };
 template <> struct TileCfg<T128x128W4> { static constexpr int BM = 128, BN = 128, ST = 3, WM = 2, WN = 2; };
 // Tried and dropped in round 3 (profiles/r03_structural_attempts.txt): the 8 waves as 4 x 2 (whole 128-B lines for the ln-fold image:
-// +0.7 us plain, -0.7 us as fold producer) and a TWO-stage ring (64 KB: two workgroups per CU; -2 ... -8 % end to end).
+// +0.7 us plain, -0.7 us as fold producer), a TWO-stage ring (64 KB: two workgroups per CU; -2 ... -8 % end to end), and the K-tile
+// split over two groups of 2 x 2 waves with 64 x 64 outputs that swap halves through LDS before the epilogue (a third less LDS read
+// traffic, parity-green: the K loop is no faster -- 0.43 vs 0.44 us per K-tile, it is the lock-step structure, not LDS bandwidth --
+// and the swap costs 1.5 us: 15.05 vs 13.43 us for the out-projection).
 
 template <int EPI, int TILE, bool F8>
 struct Launch {
