@@ -108,6 +108,11 @@ int lemas_dit_finalize(lemas_dit* m);
  * "ln_fused" (1 = the AdaLN LayerNorms that follow the gated residual updates (modules.py:637, the next block's :314, the final
  *        :335) run as the tail of the out-projection / FF2 launches whenever all workgroups of those launches fit the chip at
  *        once; default 0 = separate ln_mod launches: the fused form measured slower),
+ * "ln_fold" (1 = those LayerNorms folded ACROSS the GEMMs on either side -- the gate + residual epilogues write the scaled bf16 rows and
+ *        per-row partial sums, the QKV / FF1 epilogues apply the row statistics, c1 / c2 rows per ODE step in the AdaLN table: no
+ *        LayerNorm launch after a step's first; bf16 activations only; a different rounding of the same arithmetic, inside the
+ *        sampler's tolerance; default 0: measured neutral to 2 % slower), "lane_skew" (1 = lane 1 runs one
+ *        stage behind lane 0 through event edges; measurement only, 1.7x slower),
  * measurement options (0 = the production choice; each drops the cached graphs): "tile_n1024", "tile_n2048", "tile_qkv" = explicit
  *        GEMM tile ids (include/lemas_hip_test.h) for the block GEMMs of that width / the fused QK+V launch, "xcd_gx" = XCD block
  *        grid of the tile order (8, 4, 2, 1), "attn_variant" = schedule variant of the attention kernel (csrc/attention.hip; default
