@@ -17,6 +17,8 @@
  *   lemas_resample_create/forward           <- torchaudio Resample call, lemas_tts/infer/utils_infer.py:494-496
  *   lemas_prosody_*                         <- lemas_tts/model/backbones/prosody_encoder.py ProsodyEncoder / extract_fbank_16k,
  *                                              called per sample at lemas_tts/model/cfm.py:248-262
+ *   lemas_stft_create/forward/inverse       <- uvr5/multiprocess_cuda_infer.py:206-223 Inference.stft / .istft (the torch.stft /
+ *                                              torch.istft pair around the MDX-Net prompt denoiser; tts_multilingual.py:38-86)
  * Single-kernel entry points for the parity tests and micro-benchmarks (lemas_k_*) are declared in lemas_hip_test.h; they
  * live in a separate library, liblemas_hip_test.so, and are not part of the drop-in surface.
  *
@@ -158,6 +160,19 @@ int lemas_resample_create(int32_t orig_freq, int32_t new_freq, lemas_resample** 
 void lemas_resample_destroy(lemas_resample* r);
 int64_t lemas_resample_out_len(const lemas_resample* r, int64_t samples);   /* ceil(new * samples / orig) */
 int lemas_resample_forward(lemas_resample* r, const float* wav, int32_t batch, int32_t samples, float* out, void* stream);
+
+/* ---- STFT / inverse STFT around the UVR5 MDX-Net prompt denoiser (uvr5/multiprocess_cuda_infer.py:206-223): torch.stft(n_fft, hop,
+ * window, center=True, onesided) and torch.istft(..., center=True) as fp32 GEMMs.  `window` host [n_fft] (the reference passes
+ * hann_window(n_fft, periodic=False)).  Spectrogram frames are [re(0..n_fft/2) | im(0..n_fft/2) | padding], ld = lemas_stft_ld().
+ *   forward: wav device [B, samples] -> spec device [B, samples / hop + 1, ld]
+ *   inverse: spec device [B, frames, ld] -> wav device [B, hop * (frames - 1)]  (imaginary parts of bins 0 and n_fft/2 are ignored) ---- */
+typedef struct lemas_stft lemas_stft;
+int lemas_stft_create(int32_t n_fft, int32_t hop_length, const float* window, lemas_stft** out);
+void lemas_stft_destroy(lemas_stft* m);
+int32_t lemas_stft_ld(const lemas_stft* m);
+int64_t lemas_stft_frames(const lemas_stft* m, int64_t samples);
+int lemas_stft_forward(lemas_stft* m, const float* wav, int32_t batch, int32_t samples, float* spec, void* stream);
+int lemas_stft_inverse(lemas_stft* m, const float* spec, int32_t batch, int32_t frames, float* wav, void* stream);
 
 /* ---- prosody encoder (ECAPA-TDNN), the prompt's global prosody embedding ----
  * Architecture numbers = the reference's pretssel_cfg.json "model.prosody_*" keys (prosody_encoder.py:390-403). */

@@ -97,6 +97,12 @@ def lib():
         "lemas_resample_destroy": (None, [vp]),
         "lemas_resample_out_len": (C.c_int64, [vp, C.c_int64]),
         "lemas_resample_forward": (C.c_int, [vp, vp, i32, i32, vp, vp]),
+        "lemas_stft_create": (C.c_int, [i32, i32, vp, C.POINTER(vp)]),
+        "lemas_stft_destroy": (None, [vp]),
+        "lemas_stft_ld": (C.c_int32, [vp]),
+        "lemas_stft_frames": (C.c_int64, [vp, C.c_int64]),
+        "lemas_stft_forward": (C.c_int, [vp, vp, i32, i32, vp, vp]),
+        "lemas_stft_inverse": (C.c_int, [vp, vp, i32, i32, vp, vp]),
     }
     _bind(L, sig)
     _lib = L
@@ -155,6 +161,7 @@ EXPORTED = [      # include/lemas_hip.h: the product library
     "lemas_mel_forward", "lemas_resample_create", "lemas_resample_destroy", "lemas_resample_out_len", "lemas_resample_forward",
     "lemas_prosody_create", "lemas_prosody_destroy", "lemas_prosody_load_weight", "lemas_prosody_finalize", "lemas_prosody_fbank_frames",
     "lemas_prosody_fbank", "lemas_prosody_encode",
+    "lemas_stft_create", "lemas_stft_destroy", "lemas_stft_ld", "lemas_stft_frames", "lemas_stft_forward", "lemas_stft_inverse",
 ]
 EXPORTED_TEST = [  # include/lemas_hip_test.h: the test library
     "lemas_k_linear_bf16", "lemas_k_linear_f32", "lemas_k_attention", "lemas_k_attention_variant", "lemas_k_ln_mod", "lemas_k_convpos", "lemas_k_bench", "lemas_k_gemm_epi",

@@ -68,19 +68,26 @@ def set_frontend_factory(factory) -> None:
     FRONTEND_FACTORY = factory
 
 
-def resolve_frontend_factory(spec: str):
-    """``"package.module:callable"`` -> the callable (e.g. ``lemas_tts.infer.frontend:TextNorm`` called as ``TextNorm(dtype=...)``).
-    This is how the command-line entry points and the ``LEMAS_FRONTEND_FACTORY`` environment variable name a frontend without this
-    package importing one."""
+def resolve_callable(spec: str, what: str = "factory"):
+    """``"package.module:callable"`` -> the callable object it names (how the command-line entry points take host-side plug-ins -- the
+    text frontend, the prompt denoiser's network -- without this package importing them)."""
     import importlib
     mod, sep, attr = spec.partition(":")
     if not sep or not mod or not attr:
-        raise ValueError(f"frontend factory {spec!r}: expected 'package.module:callable'")
+        raise ValueError(f"{what} {spec!r}: expected 'package.module:callable'")
     obj = importlib.import_module(mod)
     for part in attr.split("."):
         obj = getattr(obj, part)
     if not callable(obj):
-        raise TypeError(f"frontend factory {spec!r} is not callable")
+        raise TypeError(f"{what} {spec!r} is not callable")
+    return obj
+
+
+def resolve_frontend_factory(spec: str):
+    """``"package.module:callable"`` -> the frontend factory (e.g. ``lemas_tts.infer.frontend:TextNorm`` called as ``TextNorm(dtype=...)``).
+    This is how the command-line entry points and the ``LEMAS_FRONTEND_FACTORY`` environment variable name a frontend without this
+    package importing one."""
+    obj = resolve_callable(spec, "frontend factory")
     return lambda dtype, _f=obj: _f(dtype=dtype)
 
 

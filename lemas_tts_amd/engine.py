@@ -316,6 +316,59 @@ class ResampleEngine(_Streamed):
         return out
 
 
+class StftEngine(_Streamed):
+    """``torch.stft`` / ``torch.istft`` (center=True, onesided) as the UVR5 denoiser uses them (uvr5/multiprocess_cuda_infer.py:206-223).
+    ``forward``: wav [B, nw] -> complex spectrogram [B, n_fft // 2 + 1, nw // hop + 1] (torch.stft's layout);
+    ``inverse``: that layout -> wav [B, hop * (frames - 1)]."""
+
+    def __init__(self, n_fft: int, hop_length: int, window: torch.Tensor, device="cuda:0"):
+        super().__init__(device)
+        self.n_fft, self.hop_length = int(n_fft), int(hop_length)
+        w = window.detach().to("cpu", torch.float32).contiguous()
+        assert w.numel() == self.n_fft
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().lemas_stft_create(self.n_fft, self.hop_length, w.data_ptr(), C.byref(self._h)), "lemas_stft_create")
+        self.ld = int(_lib.lib().lemas_stft_ld(self._h))
+        self.n_bins = self.n_fft // 2 + 1
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().lemas_stft_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def forward(self, wav: torch.Tensor) -> torch.Tensor:
+        with torch.cuda.device(self.device):
+            wav = wav.to(self.device, torch.float32).contiguous()
+            B, nw = wav.shape
+            F = nw // self.hop_length + 1
+            spec = torch.empty((B, F, self.ld), device=self.device, dtype=torch.float32)
+            s = self._enter(wav, spec)
+            _lib.check(_lib.lib().lemas_stft_forward(self._h, wav.data_ptr(), B, nw, spec.data_ptr(), s), "lemas_stft_forward")
+            self._exit()
+        nb = self.n_bins
+        return torch.complex(spec[:, :, :nb], spec[:, :, nb:2 * nb]).permute(0, 2, 1)      # [B, n_bins, frames]
+
+    def inverse(self, spec: torch.Tensor) -> torch.Tensor:
+        with torch.cuda.device(self.device):
+            B, nb, F = spec.shape
+            assert nb == self.n_bins
+            buf = torch.zeros((B, F, self.ld), device=self.device, dtype=torch.float32)
+            buf[:, :, :nb] = spec.real.permute(0, 2, 1)
+            buf[:, :, nb:2 * nb] = spec.imag.permute(0, 2, 1)
+            wav = torch.empty((B, self.hop_length * (F - 1)), device=self.device, dtype=torch.float32)
+            s = self._enter(buf, wav)
+            _lib.check(_lib.lib().lemas_stft_inverse(self._h, buf.data_ptr(), B, F, wav.data_ptr(), s), "lemas_stft_inverse")
+            self._exit()
+        return wav
+
+
 _RESAMPLERS: dict = {}
 
 

@@ -6,9 +6,11 @@ with the sampler and vocoder behind it running on the MI355X engines.
 
 What differs from the reference script, and why:
 
-* ``--denoise`` (UVR5 MDX-Net through onnxruntime, ``tts_multilingual.py:38-86``) is refused: that network lives in an ONNX
-  file that is not part of the tree and there is no ONNX runtime for this device.  Denoise the prompt
-  beforehand and pass the result as ``--ref_audio``.
+* ``--denoise`` (UVR5 MDX-Net through onnxruntime, ``tts_multilingual.py:38-86``): the shell around the network -- resample to
+  44.1 kHz, stereo chunking, STFT, inverse STFT, 24-bit temporary wav -- is built (``lemas_tts_amd/uvr5``); the network
+  is an ONNX file that is not part of the tree and there is no ONNX runtime for this device, so it has to be supplied:
+  ``--denoise_model_factory package.module:callable`` names a function that returns ``model_run(spek) -> spec_pred`` (and
+  ``--denoise_config`` the reference's json files).  Without it ``--denoise`` is refused.
 * there is no CPU retry (``:332-336``): this build has no CPU path, a missing GPU is an error;
 * checkpoints resolve locally only (``:89-119`` falls back to a Hugging Face download; no network here);
 * the text frontend comes from the factory registered with ``lemas_tts_amd.api.set_frontend_factory``; ``--ref_phones`` / ``--phones``
@@ -98,6 +100,10 @@ def build_parser() -> argparse.ArgumentParser:
                    help="'package.module:callable' building the text frontend for --frontend phone|char, called as callable(dtype=...): "
                         "e.g. lemas_tts.infer.frontend:TextNorm.  Default: the LEMAS_FRONTEND_FACTORY environment variable.  The text "
                         "frontend (espeak / jieba / langid) is host Python outside this package")
+    p.add_argument("--denoise_model_factory", type=str, default=None,
+                   help="'package.module:callable' returning the MDX-Net as model_run(spek[b, 4, dim_f, dim_t]) -> spec_pred for --denoise")
+    p.add_argument("--denoise_config", type=str, nargs="*", default=None,
+                   help="the reference's MDX-Net json files (model_data entry, MDX-Net-Kim-Vocal1.json); default: published Kim_Vocal_1 values")
     return p
 
 
@@ -107,9 +113,10 @@ def _phone_lines(s: str) -> List[List[str]]:
 
 def main(argv=None) -> int:
     args = build_parser().parse_args(argv)
-    if args.denoise:
+    if args.denoise and not args.denoise_model_factory:
         raise NotImplementedError("--denoise: the UVR5 MDX-Net is an ONNX model outside this tree and there is no ONNX runtime for "
-                                  "MI355X here; denoise the prompt beforehand (SURVEY.md 8f-4)")
+                                  "MI355X here; supply it with --denoise_model_factory package.module:callable, or denoise the prompt "
+                                  "beforehand (SURVEY.md 8f-4)")
     phones_given = args.ref_phones is not None or args.phones is not None
     if phones_given and (args.ref_phones is None or args.phones is None):
         raise SystemExit("--ref_phones and --phones go together")
@@ -124,6 +131,14 @@ def main(argv=None) -> int:
     if args.frontend_factory:
         from ..api import resolve_frontend_factory, set_frontend_factory
         set_frontend_factory(resolve_frontend_factory(args.frontend_factory))
+    ref_audio, tmp_denoised = args.ref_audio, None
+    if args.denoise:             # :303-314: the prompt goes through UVR5 first, the temporary file is removed at the end
+        from ..api import resolve_callable
+        from ..uvr5 import MDXConfig, UVR5
+        cfg = MDXConfig.from_json(*args.denoise_config) if args.denoise_config else MDXConfig()
+        network = resolve_callable(args.denoise_model_factory, "denoise model factory")()
+        tmp_denoised = UVR5(network, cfg, device=args.device or "cuda:0").denoise_file(ref_audio)
+        ref_audio = tmp_denoised
     tts = build_tts(args.model, ckpt_file, vocab_file, args.device, args.use_ema, None if phones_given else args.frontend,
                     args.enable_prosody_encoder, args.prosody_cfg_path, args.prosody_ckpt_path, args.vocoder_local_path)
     if phones_given:
@@ -131,11 +146,15 @@ def main(argv=None) -> int:
     else:
         ref_text, gen_text = args.ref_text.strip(), args.text.strip()
     seed = None if args.seed == -1 else args.seed
-    tts.infer(ref_file=args.ref_audio, ref_text=ref_text, gen_text=gen_text, nfe_step=int(args.nfe_step),
-              cfg_strength=float(args.cfg_strength), sway_sampling_coef=float(args.sway_sampling_coef),
-              use_acc_grl=bool(args.use_acc_grl), ref_ratio=float(args.ref_ratio), no_ref_audio=bool(args.no_ref_audio),
-              separate_langs=bool(args.separate_langs), speed=float(args.speed),
-              use_prosody_encoder=args.enable_prosody_encoder, file_wave=args.output_wave, seed=seed)
+    try:
+        tts.infer(ref_file=ref_audio, ref_text=ref_text, gen_text=gen_text, nfe_step=int(args.nfe_step),
+                  cfg_strength=float(args.cfg_strength), sway_sampling_coef=float(args.sway_sampling_coef),
+                  use_acc_grl=bool(args.use_acc_grl), ref_ratio=float(args.ref_ratio), no_ref_audio=bool(args.no_ref_audio),
+                  separate_langs=bool(args.separate_langs), speed=float(args.speed),
+                  use_prosody_encoder=args.enable_prosody_encoder, file_wave=args.output_wave, seed=seed)
+    finally:
+        if tmp_denoised is not None and os.path.isfile(tmp_denoised):
+            os.remove(tmp_denoised)
     print(f"Saved synthesized audio to: {args.output_wave}")
     return 0
 

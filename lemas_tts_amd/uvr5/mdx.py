@@ -1,0 +1,187 @@
+"""MI355X mirror of the reference's UVR5 MDX-Net denoising shell (``uvr5/multiprocess_cuda_infer.py:181-301`` ``Inference``; wrapper
+``lemas_tts/scripts/tts_multilingual.py:38-86`` ``UVR5``): everything AROUND the separation network -- stereo chunking with trimmed
+overlaps, STFT to the network's [batch, 4, dim_f, dim_t] layout, the +-input averaging ("denoise") trick, inverse STFT, margin
+handling -- with the same method names and argument meaning.
+
+The network itself is an ONNX file (``Kim_Vocal_1.onnx``) that is neither in the reference tree nor runnable here (no onnxruntime for
+MI355X), so it is a CALLABLE handed to ``load_model``: ``model_run(spek) -> spec_pred`` on ``[b, 4, dim_f, dim_t]`` float32, device
+tensor in, tensor or numpy array out.  The two transforms run in ``liblemas_hip.so`` (``lemas_stft_*``: fp32 MFMA GEMMs against
+precomputed bases); slicing, padding and concatenation are tensor plumbing.  Resampling to 44.1 kHz uses ``lemas_resample_*``.
+"""
+from __future__ import annotations
+
+import os
+import tempfile
+from dataclasses import dataclass
+from typing import Callable, Dict, Optional
+
+import numpy as np
+import torch
+
+from ..engine import StftEngine, resampler
+
+MODEL_RATE = 44100
+
+
+@dataclass
+class MDXConfig:
+    """The fields of the reference's ``ModelData`` that ``Inference`` reads (multiprocess_cuda_infer.py:183-204).  The reference fills
+    them from ``MDX-Net-Kim-Vocal1.json`` / ``model_data.json`` in its pretrained directory; neither file is in the tree, so the defaults
+    here are the values UVR publishes for Kim_Vocal_1 -- an assumption, override from the real json (``from_json``)."""
+    mdx_n_fft_scale_set: int = 7680
+    mdx_dim_f_set: int = 3072
+    mdx_dim_t_set: int = 8            # dim_t = 2 ** this
+    compensate: float = 1.043
+    is_normalization: bool = False
+    is_denoise: bool = False
+    mdx_batch_size: int = 1
+    chunks: int = 0
+    margin: int = 44100
+    save_background: bool = False
+
+    @classmethod
+    def from_json(cls, *paths) -> "MDXConfig":
+        """Merge the reference's json files (later wins), keeping the keys this class knows."""
+        import json
+        cfg = cls()
+        for p in paths:
+            with open(p, "r", encoding="utf-8") as f:
+                for k, v in json.load(f).items():
+                    if hasattr(cfg, k):
+                        setattr(cfg, k, type(getattr(cfg, k))(v))
+        return cfg
+
+
+class Inference:
+    def __init__(self, model_data: MDXConfig, device="cuda:0"):
+        self.device = torch.device(device)
+        self.n_fft = int(model_data.mdx_n_fft_scale_set)
+        self.is_normalization = model_data.is_normalization
+        self.compensate = model_data.compensate
+        self.dim_f, self.dim_t = int(model_data.mdx_dim_f_set), 2 ** int(model_data.mdx_dim_t_set)
+        self.mdx_batch_size = int(model_data.mdx_batch_size)
+        self.is_denoise = bool(model_data.is_denoise)
+        self.hop = 1024
+        self.dim_c = 4
+        self.chunks = model_data.chunks
+        self.margin = int(model_data.margin)
+        self.adjust = 1
+        self.n_bins = self.n_fft // 2 + 1
+        self.trim = self.n_fft // 2
+        self.chunk_size = self.hop * (self.dim_t - 1)
+        self.gen_size = self.chunk_size - 2 * self.trim
+        if self.gen_size <= 0:
+            raise ValueError("chunk (hop * (dim_t - 1)) must be longer than n_fft")
+        self.window = torch.hann_window(self.n_fft, periodic=False)
+        self.save_background = model_data.save_background
+        self._stft = StftEngine(self.n_fft, self.hop, self.window, device=self.device)
+        self.model_run: Optional[Callable] = None
+
+    # ---- transforms (multiprocess_cuda_infer.py:206-223) ---------------------------------------------------------
+    def stft(self, x: torch.Tensor) -> torch.Tensor:
+        """[b, 2, chunk] -> [b, 4, dim_f, dim_t]; channel order (left re, left im, right re, right im)."""
+        x = x.reshape(-1, self.chunk_size)
+        spec = self._stft.forward(x)                                         # [b*2, n_bins, dim_t] complex
+        planes = torch.stack((spec.real, spec.imag), dim=1)                  # [b*2, 2, n_bins, dim_t]
+        return planes.reshape(-1, self.dim_c, self.n_bins, self.dim_t)[:, :, :self.dim_f]
+
+    def istft(self, x: torch.Tensor, freq_pad: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """[b, 4, dim_f, dim_t] -> [b, 2, chunk]; bins above dim_f are zero (or ``freq_pad``)."""
+        b = x.shape[0]
+        if freq_pad is None:
+            freq_pad = torch.zeros((b, self.dim_c, self.n_bins - self.dim_f, self.dim_t), device=x.device, dtype=x.dtype)
+        full = torch.cat((x, freq_pad), dim=-2).reshape(b * 2, 2, self.n_bins, self.dim_t)
+        wav = self._stft.inverse(torch.complex(full[:, 0].contiguous(), full[:, 1].contiguous()))
+        return wav.reshape(b, 2, self.chunk_size)
+
+    # ---- the network ---------------------------------------------------------------------------------------------
+    def load_model(self, model_run, threads: int = 1, device=None):
+        """The reference builds an onnxruntime session from a path here (:226-240); this mirror takes the network as a callable."""
+        if isinstance(model_run, (str, os.PathLike)):
+            raise NotImplementedError(f"{model_run}: the MDX-Net is an ONNX file and there is no ONNX runtime for MI355X in this tree; "
+                                      "pass a callable model_run(spek[b, 4, dim_f, dim_t]) -> spec_pred")
+        if not callable(model_run):
+            raise TypeError("model_run must be callable")
+
+        def run(spek: torch.Tensor) -> torch.Tensor:
+            out = model_run(spek)
+            if isinstance(out, np.ndarray):
+                out = torch.from_numpy(out)
+            return out.to(self.device, torch.float32)
+        self.model_run = run
+
+    # ---- chunking (multiprocess_cuda_infer.py:243-258) -------------------------------------------------------------
+    def initialize_mix(self, mix: torch.Tensor):
+        """[2, n] -> ([chunks, 2, chunk_size], pad): windows of chunk_size every gen_size samples over the mix framed by `trim` zeros
+        and padded to a whole number of gen_size pieces (a FULL extra piece when n is already a multiple, as the reference)."""
+        n = mix.shape[1]
+        pad = self.gen_size - n % self.gen_size
+        framed = torch.nn.functional.pad(mix, (self.trim, pad + self.trim))
+        starts = range(0, n + pad, self.gen_size)
+        waves = torch.stack([framed[:, i:i + self.chunk_size] for i in starts], dim=0)
+        return waves.to(self.device), pad
+
+    def run_model(self, mix: torch.Tensor, is_match_mix: bool = False) -> torch.Tensor:
+        """[b, 2, chunk] -> [2, b * gen_size]: the network's output (or, is_match_mix, the band-limited input itself) back in time."""
+        spek = self.stft(mix.to(self.device)) * self.adjust
+        spek[:, :, :3, :] = 0                                   # the three lowest bins are always dropped (:264)
+        if is_match_mix:
+            pred = spek
+        else:
+            if self.model_run is None:
+                raise RuntimeError("load_model() has not been given a network")
+            pred = (self.model_run(spek) - self.model_run(-spek)) * 0.5 if self.is_denoise else self.model_run(spek)
+        wav = self.istft(pred)[:, :, self.trim:-self.trim]
+        return wav.transpose(0, 1).reshape(2, -1)
+
+    def demix_base(self, mix: Dict[int, torch.Tensor], is_match_mix: bool = False, device=None) -> torch.Tensor:
+        """{slice id: [2, n]} -> [2, n'].  Margins: every slice but the first drops `margin` samples at its start, every slice but the
+        last at its end.  As in the reference (:278-301) the returned tensor is that of the LAST slice of the dict -- the callers on
+        the path pass a single slice {0: mix}."""
+        keys = list(mix.keys())
+        result = None
+        for key in keys:
+            waves, pad = self.initialize_mix(mix[key].to(self.device))
+            with torch.no_grad():
+                parts = [self.run_model(w, is_match_mix=is_match_mix) for w in waves.split(self.mdx_batch_size)]
+            tar = torch.cat(parts, dim=-1)[:, :-pad]
+            start = 0 if key == 0 else self.margin
+            end = None if key == keys[-1] or self.margin == 0 else -self.margin
+            result = tar[:, start:end] * (1 / self.adjust)
+        return result
+
+
+def normalize_two_stem(wave: torch.Tensor, mix: torch.Tensor, is_normalize: bool = False):
+    """multiprocess_cuda_infer.py:337-350: scale both stems by the primary stem's peak when it clips and normalisation is on."""
+    peak = wave.abs().max()
+    if peak > 1.0 and is_normalize:
+        wave, mix = wave / peak, mix / peak
+    return wave, mix
+
+
+class UVR5:
+    """``tts_multilingual.py:38-86``: denoise a prompt file.  ``model_run`` is the separation network (see ``Inference.load_model``)."""
+
+    def __init__(self, model_run: Callable, config: Optional[MDXConfig] = None, device: str = "cuda:0") -> None:
+        self.device = device
+        self.model = Inference(config or MDXConfig(), device)
+        self.model.load_model(model_run, 1)
+
+    def denoise(self, wav: torch.Tensor, sr: int) -> torch.Tensor:
+        """wav [channels, n] at `sr` -> vocal stem [2, n'] at 44.1 kHz."""
+        wav = wav.to(self.device, torch.float32)
+        if wav.shape[0] == 1:
+            wav = torch.cat((wav, wav), dim=0)          # mono -> stereo
+        if sr != MODEL_RATE:
+            wav = resampler(sr, MODEL_RATE, device=self.device)(wav)
+        return self.model.demix_base({0: wav}, is_match_mix=False, device=self.device)
+
+    def denoise_file(self, wav_path: str) -> str:
+        """Denoise a wav file and return the path of a temporary 24-bit wav holding the vocal stem."""
+        from ..infer import audio_io
+        wav, sr = audio_io.load_wav(wav_path)
+        out = self.denoise(wav, sr).to("cpu").numpy().T            # [T, 2]
+        with tempfile.NamedTemporaryFile(delete=False, suffix=".wav") as f:
+            name = f.name
+        audio_io.save_wav(name, out, MODEL_RATE, subtype="PCM_24")
+        return name

@@ -1,5 +1,6 @@
 """The north-star entry point end to end (scripts/tts_multilingual.py): files on disk in, a wav file out,
 through the mirrored command line -> TTS -> infer_process -> CFM.sample -> Vocos on the MI355X engines."""
+import os
 import wave
 
 import numpy as np
@@ -150,3 +151,40 @@ def test_cli_default_usage_reaches_the_string_frontend_through_a_named_factory(t
     assert rc == 0
     a, b, c = (load_wav(tmp_path / n)[0].numpy() for n in ("a.wav", "b.wav", "c.wav"))
     assert a.shape[1] > 2400 and np.array_equal(a, b) and np.array_equal(a, c)
+
+
+def test_cli_denoise_runs_the_uvr5_shell_with_a_named_network(tmp_path, monkeypatch):
+    """--denoise (tts_multilingual.py:303-314): the prompt goes through the UVR5 shell (lemas_tts_amd/uvr5) before TTS.infer; the network
+    is named with --denoise_model_factory.  With an identity network the shell only band-limits and resamples the prompt, so the output
+    exists and differs from the undenoised run only through that; the temporary file is removed."""
+    import glob
+    import tempfile
+    import lemas_tts_amd.api as A
+    import lemas_tts_amd.scripts.tts_multilingual as M
+    from lemas_tts_amd.infer.audio_io import load_wav, save_wav
+    depth = 1
+    root = _assets(tmp_path, depth)
+    monkeypatch.setattr(M, "PRETRAINED_ROOT", root)
+    monkeypatch.setattr(M, "CKPTS_ROOT", root / "ckpts")
+    real_cfg = A.load_arch_config
+    monkeypatch.setattr(A, "load_arch_config", lambda m: {**real_cfg(m), "arch": {**real_cfg(m)["arch"], "depth": depth}})
+    (tmp_path / "fake_mdx.py").write_text("def build():\n    return lambda spek: spek\n")
+    (tmp_path / "mdx.json").write_text('{"mdx_n_fft_scale_set": 2048, "mdx_dim_f_set": 768, "mdx_dim_t_set": 5, "compensate": 1.0}')
+    monkeypatch.syspath_prepend(str(tmp_path))
+    t = np.arange(int(1.2 * 22050)) / 22050.0
+    save_wav(tmp_path / "ref.wav", 0.05 * np.sin(2 * np.pi * 300 * t), 22050, "PCM_16")
+    ref_ph = "|".join(f"p{i}" for i in synth.synth_tokens(80, 8, 60))
+    gen_ph = "|".join(f"p{i}" for i in synth.synth_tokens(81, 9, 60))
+    before = set(glob.glob(os.path.join(tempfile.gettempdir(), "*.wav")))
+    common = ["--ref_audio", str(tmp_path / "ref.wav"), "--ref_phones", ref_ph, "--phones", gen_ph, "--nfe_step", "2", "--cfg_strength", "2.0",
+              "--sway_sampling_coef", "5", "--seed", "7", "--use_ema"]
+    with pytest.raises(NotImplementedError, match="denoise_model_factory"):
+        M.main(common + ["--denoise", "--output_wave", str(tmp_path / "x.wav")])
+    assert M.main(common + ["--denoise", "--denoise_model_factory", "fake_mdx:build", "--denoise_config", str(tmp_path / "mdx.json"),
+                            "--output_wave", str(tmp_path / "den.wav")]) == 0
+    assert M.main(common + ["--output_wave", str(tmp_path / "plain.wav")]) == 0
+    den, sr = load_wav(tmp_path / "den.wav")
+    plain, _ = load_wav(tmp_path / "plain.wav")
+    assert sr == 24000 and den.shape[1] > 2000 and np.isfinite(den.numpy()).all() and den.abs().max() > 0
+    assert abs(den.shape[1] - plain.shape[1]) <= 256 * 2          # same prompt length up to the 44.1 kHz round trip
+    assert set(glob.glob(os.path.join(tempfile.gettempdir(), "*.wav"))) == before, "the denoised temporary file must be removed"
