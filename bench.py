@@ -230,6 +230,7 @@ def main():
                     "utterance i+1 (default), 0 = strictly serial")
     ap.add_argument("--ln-fused", type=int, default=-1, help="engine option ln_fused (-1 = engine default)")
     ap.add_argument("--ln-fold", type=int, default=-1, help="engine option ln_fold (-1 = engine default)")
+    ap.add_argument("--no-clock-power", action="store_true", help="skip the rocm-smi clock / power sampling pass (profiler runs)")
     a = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -498,7 +499,7 @@ def main():
                                       "frac": voc_bytes / (voc_ms * 1e-3) / 8e12, "algorithmic_bytes": voc_bytes, "decode_ms": voc_ms,
                                       "frames": L_GEN, "traffic": None,
                                       "note": "launch-/latency-bound at batch 1: ~60 small fp32 launches for 25 GFLOP"}
-        result["clock_power"] = clock_power(step)
+        result["clock_power"] = None if a.no_clock_power else clock_power(step)
         if result["clock_power"]:
             # the MFMA peak the roofline prices against is the 2.4 GHz figure; what the package was clocked to deliver while this ran
             result["roofline"]["peak_at_measured_clock"] = result["roofline"]["peak"] * result["clock_power"]["sclk_mhz"] / 2400.0

@@ -16,7 +16,7 @@ LEMAS_FORCE_DIST=1 LEMAS_DIST_BACKEND=nccl python bench.py --no-cpu-baseline --s
 cd /tmp
 for w in configs1 configs3; do
   rm -rf /tmp/prof_$w
-  (cd $R && rocprofv3 --kernel-trace --stats -d /tmp/prof_$w -- python bench.py --workload $w --no-cpu-baseline > /tmp/prof_$w.out 2>/tmp/prof_$w.log)
+  (cd $R && rocprofv3 --kernel-trace --stats -d /tmp/prof_$w -- python bench.py --workload $w --no-cpu-baseline --no-clock-power > /tmp/prof_$w.out 2>/tmp/prof_$w.log)
   (cd $R && python tools/rocpd_summary.py $(find /tmp/prof_$w -name "*_results.db" | head -1) > $O/${TAG}_kernel_stats_$w.txt)
   tail -1 /tmp/prof_$w.out > $O/${TAG}_bench_under_rocprof_$w.json
 done
@@ -25,7 +25,7 @@ for w in configs1 configs3; do
   echo "### workload $w" >> $O/${TAG}_pmc.txt
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/pmc_${w}_$c
-    (cd $R && rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_${w}_$c -- python bench.py --workload $w --no-cpu-baseline --steps 1 --warmup 1 > /tmp/pmc_$c.out 2>/tmp/pmc_$c.log)
+    (cd $R && rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_${w}_$c -- python bench.py --workload $w --no-cpu-baseline --no-clock-power --steps 1 --warmup 1 > /tmp/pmc_$c.out 2>/tmp/pmc_$c.log)
     echo "## $c" >> $O/${TAG}_pmc.txt
     (cd $R && python tools/rocpd_pmc.py $(find /tmp/pmc_${w}_$c -name "*_results.db" | head -1) gemm_bf16 gemm_pp attn_fwd ln_mod gemm_qkv gemm_f32 convpos >> $O/${TAG}_pmc.txt)
   done
