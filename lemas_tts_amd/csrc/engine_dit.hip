@@ -71,7 +71,7 @@ struct lemas_dit {
   // residual epilogues write the scaled bf16 rows and per-row partial sums, the QKV / FF1 epilogues apply the row statistics, and c1 / c2
   // rows per ODE step live in the AdaLN table.  Two of the seven launches per block and lane disappear.  bf16 activations only (the
   // MXFP8 path keeps its quantising LayerNorm launch).  OFF: end to end it is a wash at configs[1] (95.9 = 95.9 audio-s/s) and 2-2.5 %
-  // slower at the batched and the short workload (profiles/r03_ln_fold_experiment.txt).  What the two removed launches cost a lane's
+  // slower at the batched and the short workload (profiles/r03_structural_attempts.txt).  What the two removed launches cost a lane's
   // chain the other lane was already hiding; what counts with two lanes on the chip is workgroup-time, and there the fold adds (1-2 us per
   // producer launch for the bf16 image and the statistics, 1-2.5 us per consumer launch for re-reading 256 B of statistics per row by
   // every column tile) about what the two small LayerNorm launches took.

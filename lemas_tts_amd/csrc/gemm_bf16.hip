@@ -774,9 +774,10 @@ __device__ __forceinline__ void ln_tail(const GemmParams& p, int m0, int n0) {
 }
 
 // ---------------------------------------------------------------- ln fold: row statistics on both sides of a GEMM (GemmParams)
-// consumer: thread t < TBM turns the LN_NP partial (sum, sum of squares) pairs of row m0 + t into (r, -r mu) in LDS.  The loads
-// are issued BEFORE the K loop's first LDS-DMA (so the counted vmcnt waits of the loops only ever see them as older operations)
-// and consumed after the prologue has been issued; the table lives behind the ring / slab area and is read by the epilogues.
+// consumer: the first TBM * TPR threads turn the LN_NP partial (sum, sum of squares) pairs of the tile's rows into (r, -r mu) in LDS.
+// The loads are issued BEFORE the K loop's first LDS-DMA (so the counted vmcnt waits of the loops only ever see them as older
+// operations) and consumed after the K loop (256 x 256 body: in the prologue); the table lives behind the ring / slab area and is read
+// by the epilogues.
 // TPR adjacent threads share a row (each takes LN_NP / TPR slots): thread t of the first TBM * TPR threads of the workgroup.
 template <int TPR> struct RowStatLoad { f32x4 v[LN_NP / 2 / TPR]; };
 template <int TPR>
@@ -793,8 +794,10 @@ __device__ __forceinline__ void ln_rowstat_load(const GemmParams& p, int m0, int
 template <int TPR>
 __device__ __forceinline__ void ln_rowstat_store(RowStatLoad<TPR>& L, float* rs, int t) {
 #pragma clang fp contract(off)
-  // the caller's s_waitcnt is a volatile asm just before this; these empty volatile asms stay behind it and make every use of the
-  // loaded registers depend on them (nothing that reads L.v can be scheduled above the wait)
+  // The loads must have landed: every caller has passed a volatile s_waitcnt vmcnt that covers them before it gets here (they are the
+  // OLDEST vector-memory operations of the wave, so the first counted wait of the K loop already retires them, and the loop's last
+  // wait is vmcnt(0); the 256 x 256 body waits explicitly in its prologue).  These empty volatile asms stay behind that wait in
+  // program order and make every use of the loaded registers depend on them: nothing that reads L.v can be scheduled above it.
 #pragma unroll
   for (int j = 0; j < LN_NP / 2 / TPR; ++j) asm volatile("" : "+v"(L.v[j]));
   // one balanced binary tree over the 16 slots whatever TPR is (pairs inside a float4, then inside the thread, then across the TPR
