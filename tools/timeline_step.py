@@ -30,6 +30,7 @@ NAMES_UNFUSED = ["qk", "v", "attn", "out", "ff1", "ff2"]       # batched shapes:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="configs1")
+    ap.add_argument("--opt", nargs="*", default=[], help="engine options key=value (e.g. ln_fold=1)")
     a = ap.parse_args()
     global NAMES
     w = dict(Bn.WORKLOADS[a.workload])
@@ -46,6 +47,9 @@ def main():
     buf = torch.zeros((slots, 4096), dtype=torch.int64, device=dev)
     m = CFM(arch, Bn.VOCAB, sd, device=dev)
     m.engine.set_option("table_cache", 0)
+    for kv in a.opt:
+        k, v = kv.split("=")
+        m.engine.set_option(k, int(v))
 
     def run():
         out, _ = m.sample(cond, text, N, steps=Bn.NFE, cfg_strength=Bn.CFG, sway_sampling_coef=Bn.SWAY, y0=y0, use_acc_grl=False)
