@@ -224,3 +224,44 @@ def test_baseline_config_full_size_full_nfe_vs_the_reference(golden_dir, name):
         mse8 = T._gen_mse(out8, fx["out"], fx)
         print(f"[{name}, fp8 GEMM operands] mel-MSE vs the reference {mse8:.3e}")
         assert mse8 <= 1e-4, mse8
+
+
+def test_config4_full_form_64_utterances_over_8_ranks_on_one_gpu():
+    """BASELINE configs[3] in its FULL form -- 64 utterances dealt to 8 ranks (lemas_tts_amd.parallel.shard_utterances, longest first),
+    each rank running its 8 as one CFM.sample batch -- with the eight ranks played one after the other on the one GPU of the box
+    (full depth, full NFE; the 8-GPU run itself is the driver's).  Checks the deal (every utterance exactly once, 8 per rank) and
+    that what a rank computes for an utterance inside its batch is bit-for-bit what that utterance gives alone: with configs[3]'s
+    equal-length utterances the result of the 64 does not depend on how they were dealt.  (Utterances of DIFFERENT lengths in one batch
+    follow the reference's B > 1 semantics -- filler-token text embeddings beyond an utterance's own end reach its last frames through
+    the text ConvNeXt blocks -- so there a batch-mate changes the result, in the reference as here; test_config3 covers that form
+    against the oracle's batch.)"""
+    from lemas_tts_amd.model.cfm import CFM
+    from lemas_tts_amd.parallel import shard_utterances
+    arch = DiTArch(depth=22)
+    sd = synth.synth_cfm_state_dict(arch, VOCAB, 1234)
+    m = CFM(arch, VOCAB, sd, device="cuda:0")
+    rng = np.random.default_rng(64)
+    U, world = 64, 8
+    Fs, Ns = [375] * U, [1125] * U                                   # configs[3]: 4 s prompt + 8 s generated, every utterance
+    nts = [int(v) for v in rng.integers(150, 192, U)]                # token counts differ (padded with fillers up to N either way)
+    shards = shard_utterances(Ns, world)
+    assert sorted(i for sh in shards for i in sh) == list(range(U)) and all(len(sh) == U // world for sh in shards)
+    results = {}
+    for rank in range(world):
+        idx = shards[rank]
+        cond = torch.zeros(len(idx), max(Fs[i] for i in idx), 100)
+        text = torch.full((len(idx), max(nts[i] for i in idx)), -1, dtype=torch.long)
+        y0 = torch.zeros(len(idx), max(Ns[i] for i in idx), 100)
+        for b, i in enumerate(idx):
+            cond[b, : Fs[i]] = torch.from_numpy(synth.synth_cond_mel(1000 + i, Fs[i]))
+            text[b, : nts[i]] = torch.from_numpy(synth.synth_tokens(1000 + i, nts[i], VOCAB))
+            y0[b, : Ns[i]] = torch.from_numpy(synth.synth_noise(1000 + i, Ns[i]))
+        out, _ = m.sample(cond, text, torch.tensor([Ns[i] for i in idx]), lens=torch.tensor([Fs[i] for i in idx]), steps=32, cfg_strength=2.0,
+                          sway_sampling_coef=5, y0=y0, use_acc_grl=False)
+        for b, i in enumerate(idx):
+            results[i] = out[b, : Ns[i]].cpu().numpy()
+    assert len(results) == U and all(np.isfinite(v).all() for v in results.values())
+    for i in (shards[0][0], shards[3][5], shards[7][7]):
+        cond1, text1, y01 = _inputs(1000 + i, 1, [Fs[i]], [Ns[i]], [nts[i]])
+        one, _ = m.sample(cond1, text1, Ns[i], steps=32, cfg_strength=2.0, sway_sampling_coef=5, y0=y01, use_acc_grl=False)
+        np.testing.assert_array_equal(one[0, : Ns[i]].cpu().numpy(), results[i], err_msg=f"utterance {i}")
