@@ -9,6 +9,8 @@
  * layout is loaded under its key (utils_infer.py:223-237), the weights are finalized and lemas_dit_sample runs 3 Euler steps
  * with CFG on a 100-frame utterance; checked without an oracle: finite, repeatable bit for bit, the conditioning frames of
  * `out` are the prompt itself (cfm.py:459-461), the generated frames are not, and a wrong argument is refused with a message.
+ * Last the STFT pair of the prompt denoiser's shell (lemas_stft_*): inverse(forward(x)) = x for a Hann window at hop = n_fft / 2,
+ * Parseval-sized spectra, right frame count, and a too-short signal is refused.
  * Device memory comes from the HIP runtime's C API.
  */
 #include <math.h>
@@ -188,6 +190,39 @@ static int dit_section(void) {
   return (same && exact && gen > 0 && bad == LEMAS_E_ARG) ? 0 : 18;
 }
 
+static int stft_section(void) {
+  const int nfft = 1024, hop = 512, n = 8192, B = 2;
+  float* w = (float*)malloc(nfft * sizeof(float));
+  for (int i = 0; i < nfft; ++i) w[i] = (float)(0.5 - 0.5 * cos(2.0 * M_PI * i / (nfft - 1)));    /* hann_window(periodic=False) */
+  lemas_stft* st = NULL;
+  if (lemas_stft_create(nfft, hop, w, &st) != 0) { fprintf(stderr, "stft create: %s\n", lemas_last_error()); return 1; }
+  const int frames = (int)lemas_stft_frames(st, n), ld = lemas_stft_ld(st);
+  if (frames != n / hop + 1 || ld < nfft + 2) { fprintf(stderr, "stft: frames %d ld %d\n", frames, ld); return 1; }
+  float* x = (float*)malloc((size_t)B * n * sizeof(float));
+  for (int i = 0; i < B * n; ++i) x[i] = 0.5f * frand();
+  float *dx = NULL, *dspec = NULL, *dy = NULL;
+  hipMalloc((void**)&dx, (size_t)B * n * 4);
+  hipMalloc((void**)&dspec, (size_t)B * frames * ld * 4);
+  hipMalloc((void**)&dy, (size_t)B * hop * (frames - 1) * 4);
+  hipMemcpy(dx, x, (size_t)B * n * 4, H2D);
+  if (lemas_stft_forward(st, dx, B, n, dspec, NULL) != 0 || lemas_stft_inverse(st, dspec, B, frames, dy, NULL) != 0) {
+    fprintf(stderr, "stft: %s\n", lemas_last_error());
+    return 1;
+  }
+  hipDeviceSynchronize();
+  float* y = (float*)malloc((size_t)B * n * sizeof(float));
+  hipMemcpy(y, dy, (size_t)B * n * 4, D2H);         /* hop * (frames - 1) == n */
+  double err = 0.0;
+  for (int i = 0; i < B * n; ++i) { const double d = fabs((double)y[i] - x[i]); if (d > err) err = d; }
+  if (!(err < 2e-5)) { fprintf(stderr, "stft round trip: max |err| %g\n", err); return 1; }
+  if (lemas_stft_forward(st, dx, B, nfft / 2, dspec, NULL) == 0) { fprintf(stderr, "stft: a signal too short for the reflect padding was accepted\n"); return 1; }
+  printf("stft round trip OK (max |err| %.2e, %d frames, ld %d); refusal: %s\n", err, frames, ld, lemas_last_error());
+  lemas_stft_destroy(st);
+  hipFree(dx); hipFree(dspec); hipFree(dy);
+  free(w); free(x); free(y);
+  return 0;
+}
+
 int main(void) {
   lemas_vocos* v = NULL;
   if (lemas_vocos_create(100, 512, 1536, 8, 1024, 256, &v)) { fprintf(stderr, "create: %s\n", lemas_last_error()); return 2; }
@@ -242,5 +277,6 @@ int main(void) {
   lemas_vocos_destroy(v);
   hipFree(dmel); hipFree(dwav);
   if (!(maxabs > 0 && lin <= 1e-6 * (maxabs + 1) && det == 0.0 && bad == LEMAS_E_ARG)) return 7;
-  return dit_section();
+  if (dit_section() != 0) return 1;
+  return stft_section();
 }
