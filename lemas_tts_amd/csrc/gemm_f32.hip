@@ -63,38 +63,68 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Params p) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], a[i], acc[i][j], 0, 0, 0);   // C^T: see the epilogue
     }
     __syncthreads();
   }
 
-  // C fragment: col = lane & 15, row = (lane >> 4) * 4 + reg
+  // The MFMA runs with its operands swapped (C^T = W . A^T; same products, same k order, same sums), so a lane owns ONE output row and
+  // FOUR CONSECUTIVE columns: row = lane & 15, columns (lane >> 4) * 4 + reg.  Bias / residual / add operands and the result move as
+  // 16-B vectors wherever the row pitch and the column count allow it (a quarter of the load / store instructions of the scalar form,
+  // which is what the K = 100 input-projection launch of every ODE step was made of); otherwise element by element.
+  auto finish = [&](float v, int m, int n, float bias, float cs) -> float {
+    v += bias;
+    if (EPI == F32_BIAS_GELU) v = gelu_erf_f(v);
+    if (EPI == F32_BIAS_SILU) v = silu_f(v);
+    if (EPI == F32_BIAS_RELU) v = fmaxf(v, 0.f);
+    if (EPI == F32_BIAS_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+    if (EPI == F32_BIAS_RES_SCALE) v = p.res[(size_t)m * p.ldres + n] + cs * v;
+    return v;
+  };
+  const bool vec_ok = (p.ldc & 3) == 0 && (reinterpret_cast<size_t>(outz) & 15) == 0 &&
+                      (EPI != F32_BIAS_ADD2 || (reinterpret_cast<size_t>(p.add) & 15) == 0);
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = n0 + wn * 32 + j * 16 + l15;
-    if (n >= p.N) continue;
-    const float bias = biasz ? biasz[n] : 0.f;
-    const float cs = (EPI == F32_BIAS_RES_SCALE && p.colscale) ? p.colscale[n] : 1.f;
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + wm * 32 + i * 16 + l15;
+    if (m >= p.M) continue;
+    const bool masked = EPI != F32_BIAS_ADD2 && p.rowmask && p.rowmask[m];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j) {
+      const int nb = n0 + wn * 32 + j * 16 + lk * 4;
+      if (nb >= p.N) continue;
+      float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wm * 32 + i * 16 + lk * 4 + r;
-        if (m >= p.M) continue;
-        float v = acc[i][j][r] + bias;
-        if (EPI == F32_BIAS_GELU) v = gelu_erf_f(v);
-        if (EPI == F32_BIAS_SILU) v = silu_f(v);
-        if (EPI == F32_BIAS_RELU) v = fmaxf(v, 0.f);
-        if (EPI == F32_BIAS_SIGMOID) v = 1.0f / (1.0f + expf(-v));
-        if (EPI == F32_BIAS_RES_SCALE) v = p.res[(size_t)m * p.ldres + n] + cs * v;
+        const int n = nb + r;
+        const bool in = n < p.N;
+        const float bias = (biasz && in) ? biasz[n] : 0.f;
+        const float cs = (EPI == F32_BIAS_RES_SCALE && p.colscale && in) ? p.colscale[n] : 1.f;
+        v[r] = in ? finish(acc[i][j][r], m, n, bias, cs) : 0.f;
+        if (masked) v[r] = 0.f;
+      }
+      if (vec_ok && nb + 3 < p.N) {
         if (EPI == F32_BIAS_ADD2) {
-          outz[(size_t)m * p.ldc + n] = v + p.add[(size_t)m * p.ldc + n];
-          outz[(size_t)(m + p.M) * p.ldc + n] = v + p.add[(size_t)(m + p.M) * p.ldc + n];
+          const float4 a0 = *reinterpret_cast<const float4*>(p.add + (size_t)m * p.ldc + nb);
+          const float4 a1 = *reinterpret_cast<const float4*>(p.add + (size_t)(m + p.M) * p.ldc + nb);
+          *reinterpret_cast<float4*>(outz + (size_t)m * p.ldc + nb) = make_float4(v[0] + a0.x, v[1] + a0.y, v[2] + a0.z, v[3] + a0.w);
+          *reinterpret_cast<float4*>(outz + (size_t)(m + p.M) * p.ldc + nb) = make_float4(v[0] + a1.x, v[1] + a1.y, v[2] + a1.z, v[3] + a1.w);
         } else {
-          if (p.rowmask && p.rowmask[m]) v = 0.f;
-          outz[(size_t)m * p.ldc + n] = v;
+          *reinterpret_cast<float4*>(outz + (size_t)m * p.ldc + nb) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = nb + r;
+          if (n >= p.N) continue;
+          if (EPI == F32_BIAS_ADD2) {
+            outz[(size_t)m * p.ldc + n] = v[r] + p.add[(size_t)m * p.ldc + n];
+            outz[(size_t)(m + p.M) * p.ldc + n] = v[r] + p.add[(size_t)(m + p.M) * p.ldc + n];
+          } else {
+            outz[(size_t)m * p.ldc + n] = v[r];
+          }
         }
       }
+    }
   }
 }
 
