@@ -109,7 +109,9 @@ constexpr int STAGE2 = 4 * TILE;
 //   4  s_setprio 1 around the MFMA clusters
 template <int VAR>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_fwd_splitkv_kernel(const AttnParams p) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE2 + 64];   // ring + 8 per-wave flags (VAR & 1)
+  // exactly 64 KB (the ring; the 8 range-check flags live inside it once the key loop is over), so that a workgroup of this kernel and a
+  // 96 KB workgroup of the other lane's 128 x 128 GEMM fit a CU's 160 KB together (measured: no effect either way)
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE2];
   ATTN_STAMP(0);
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
 
@@ -425,7 +427,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     m_run = -INFINITY;
     l_run = 0.f;
   };
-  int* flags = reinterpret_cast<int*>(smem + 2 * STAGE2);      // behind the ring: no wave's tile reads reach here
+  // inside the ring, behind the merge's exchange area (36 KB): written after the key loop's last barrier, when no tile is in flight; a
+  // workgroup that goes round again passes a barrier first, so no wave's refill DMA can land here before every wave has read the flags
+  int* flags = reinterpret_cast<int*>(smem + 40960);
+  static_assert(4 * 64 * 36 * 4 <= 40960 && 40960 + 64 <= 2 * STAGE2, "flags sit between the exchange area and the end of the ring");
   if constexpr ((VAR & 17) == 17) {
     m_run = 0.f;                                       // P = exp2(S) for every tile, the first included (see VAR & 16)
     key_loop(fast_t{}, fast_t{});
@@ -441,6 +446,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
     __syncthreads();                                   // xch consumed, flags visible
     if (__builtin_expect((VAR & (32 | 64 | 128 | 256 | 512 | 2048)) == 0 && (flags[0] | flags[1] | flags[2] | flags[3]) != 0, 0)) {     // (ablation builds never redo)
+      __syncthreads();                                 // every wave has read the flags before any refill DMA may overwrite them
       restart();                                       // two-pass softmax: every row's maximum over this wave's tiles ...
       key_loop_cold(maxonly_t{});
       key_loop_cold(fastsub_t{});                      // ... then P = exp2(S - max); the merge below reconciles the two key groups' maxima
@@ -461,6 +467,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
     for (int w = 0; w < 8; ++w) redo |= flags[w];
     if (__builtin_expect(redo != 0, 0)) {
+      __syncthreads();                                 // (as above)
       restart();
       key_loop(classic_t{}, classic_t{});
     }

@@ -1401,8 +1401,10 @@ struct LaunchPP2 {
   static hipError_t run(const GemmParams& p, hipStream_t s) {
     if (p.N % 128 != 0 || p.K % 64 != 0) return hipErrorInvalidValue;
     const dim3 grid(((p.M + 255) / 256) * (p.N / 128)), block(512);
-    if (p.ev_start) hipExtLaunchKernelGGL((gemm_pp2_kernel<EPI>), grid, block, lds, s, p.ev_start, p.ev_stop, 0, p);
-    else hipLaunchKernelGGL((gemm_pp2_kernel<EPI>), grid, block, lds, s, p);
+    // the (r, -r mu) table behind the ring is only there for a ln-fold consumer: every other launch keeps the ring's own footprint
+    const int lds_now = p.ln_part ? lds : lds - 256 * 8;
+    if (p.ev_start) hipExtLaunchKernelGGL((gemm_pp2_kernel<EPI>), grid, block, lds_now, s, p.ev_start, p.ev_stop, 0, p);
+    else hipLaunchKernelGGL((gemm_pp2_kernel<EPI>), grid, block, lds_now, s, p);
     return hipGetLastError();
   }
 };
@@ -1425,8 +1427,9 @@ struct LaunchPP {
   static hipError_t run(const GemmParams& p, hipStream_t s) {
     if (p.N % 256 != 0 || p.K % 64 != 0) return hipErrorInvalidValue;
     const dim3 grid(((p.M + 255) / 256) * (p.N / 256)), block(512);
-    if (p.ev_start) hipExtLaunchKernelGGL((gemm_pp_kernel<EPI>), grid, block, lds, s, p.ev_start, p.ev_stop, 0, p);
-    else hipLaunchKernelGGL((gemm_pp_kernel<EPI>), grid, block, lds, s, p);
+    const int lds_now = p.ln_part ? lds : lds - 256 * 8;
+    if (p.ev_start) hipExtLaunchKernelGGL((gemm_pp_kernel<EPI>), grid, block, lds_now, s, p.ev_start, p.ev_stop, 0, p);
+    else hipLaunchKernelGGL((gemm_pp_kernel<EPI>), grid, block, lds_now, s, p);
     return hipGetLastError();
   }
 };
@@ -1489,10 +1492,13 @@ struct Launch {
     if (p.N % C::BN != 0) return hipErrorInvalidValue;
     const int tiles_m = (p.M + C::BM - 1) / C::BM, tiles_n = p.N / C::BN;
     const dim3 grid(tiles_m * tiles_n), block(64 * C::WM * C::WN);
+    // without the ln-fold table the launch keeps the ring's own footprint (128 x 128: exactly 96 KB, which with the attention kernel's
+    // exact 64 KB is a CU's 160 KB -- measured: sharing or not sharing a CU that way changes nothing, profiles/r03_structural_attempts.txt)
+    const int lds_now = p.ln_part ? lds : lds - C::BM * 8;
     if (p.ev_start)
-      hipExtLaunchKernelGGL((gemm_bf16_kernel<EPI, C::BM, C::BN, C::ST, C::WM, C::WN, F8>), grid, block, lds, s, p.ev_start, p.ev_stop, 0, p);
+      hipExtLaunchKernelGGL((gemm_bf16_kernel<EPI, C::BM, C::BN, C::ST, C::WM, C::WN, F8>), grid, block, lds_now, s, p.ev_start, p.ev_stop, 0, p);
     else
-      hipLaunchKernelGGL((gemm_bf16_kernel<EPI, C::BM, C::BN, C::ST, C::WM, C::WN, F8>), grid, block, lds, s, p);
+      hipLaunchKernelGGL((gemm_bf16_kernel<EPI, C::BM, C::BN, C::ST, C::WM, C::WN, F8>), grid, block, lds_now, s, p);
     return hipGetLastError();
   }
 };
@@ -1603,10 +1609,11 @@ struct LaunchQkv {
   static hipError_t run(const GemmParams& pq, const GemmParams& pv, hipStream_t s) {
     const int tiles_q = ((pq.M + C::BM - 1) / C::BM) * (pq.N / C::BN), tiles_v = ((pv.M + C::BM - 1) / C::BM) * (pv.N / C::BN);
     const dim3 grid(tiles_q + tiles_v), block(64 * NW);
+    const int lds_now = (pq.ln_part || pv.ln_part) ? lds : lds - C::BM * 8;
     if (pq.ev_start)
-      hipExtLaunchKernelGGL((gemm_qkv_fused_kernel<F8, TILE>), grid, block, lds, s, pq.ev_start, pq.ev_stop, 0, pq, pv, tiles_q, tiles_v);
+      hipExtLaunchKernelGGL((gemm_qkv_fused_kernel<F8, TILE>), grid, block, lds_now, s, pq.ev_start, pq.ev_stop, 0, pq, pv, tiles_q, tiles_v);
     else
-      hipLaunchKernelGGL((gemm_qkv_fused_kernel<F8, TILE>), grid, block, lds, s, pq, pv, tiles_q, tiles_v);
+      hipLaunchKernelGGL((gemm_qkv_fused_kernel<F8, TILE>), grid, block, lds_now, s, pq, pv, tiles_q, tiles_v);
     return hipGetLastError();
   }
 };
