@@ -1,0 +1,52 @@
+"""CPU tier: the host-side pieces of bench.py that need no GPU -- the rocm-smi reader behind the ``clock_power`` field and the FLOP
+bookkeeping the roofline fields are priced with."""
+import os
+import stat
+import sys
+import types
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+FAKE_SMI = """#!/bin/sh
+cat <<'TXT'
+============================ ROCm System Management Interface ============================
+GPU[0]\t\t: fclk clock level: 0: (1250Mhz)
+GPU[0]\t\t: mclk clock level: 0: (2000Mhz)
+GPU[0]\t\t: sclk clock level: 1: (2184Mhz)
+=================================== Power Consumption ====================================
+GPU[0]\t\t: Current Socket Graphics Package Power (W): 1231.0
+TXT
+"""
+
+
+def test_clock_power_reads_rocm_smi(tmp_path, monkeypatch):
+    """``clock_power`` runs the timed work again (untimed) while a thread reads rocm-smi: with a stand-in rocm-smi on PATH and a
+    stand-in step it must report the averages of the busy samples and say where they came from."""
+    import bench
+    exe = tmp_path / "rocm-smi"
+    exe.write_text(FAKE_SMI)
+    exe.chmod(exe.stat().st_mode | stat.S_IEXEC)
+    monkeypatch.setenv("PATH", str(tmp_path) + os.pathsep + os.environ.get("PATH", ""))
+    monkeypatch.setattr(bench.torch.cuda, "synchronize", lambda *a, **k: None)
+    calls = []
+    cp = bench.clock_power(lambda: calls.append(1) or __import__("time").sleep(0.05), seconds=2.5)
+    assert cp is not None and calls
+    assert cp["sclk_mhz"] == 2184 and cp["package_w"] == 1231.0 and cp["samples"] >= 1
+    assert cp["sclk_ceiling_mhz"] == 2400 and "rocm-smi" in cp["source"]
+
+
+def test_clock_power_without_rocm_smi_is_none(tmp_path, monkeypatch):
+    import bench
+    monkeypatch.setenv("PATH", str(tmp_path))
+    monkeypatch.setattr(bench.os.path, "exists", lambda p: False)
+    assert bench.clock_power(lambda: None, seconds=0.1) is None
+
+
+def test_forward_flops_formula():
+    """F_fwd(B, N) = B (378 888 192 N + 90 112 N^2); the block GEMM classes add up to the linear part's share"""
+    import bench
+    assert bench.fwd_flops(1, 1875) == pytest.approx(378_888_192 * 1875 + 90_112 * 1875 ** 2)
+    assert bench.fwd_flops(8, 1125) == pytest.approx(8 * (378_888_192 * 1125 + 90_112 * 1125 ** 2))
