@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Headline benchmark of the MI355X-native LEMAS-TTS acoustic path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload configs1|configs3|short]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload configs1|configs2|configs3|configs4|short] [--job configs3_full]
 
 With ``--gpus N`` (N > 1) and no launcher environment, bench.py starts the N ranks ITSELF (one process per GPU, the reference's
 own multi-GPU precedent: uvr5/multiprocess_cuda_infer.py:404-420); started under ``python -m torch.distributed.run --nnodes=1
@@ -10,23 +10,31 @@ world size must equal ``--gpus``.
 
 Metric (BASELINE.json): audio-seconds/sec @24 kHz, NFE=32, CFG on.  A "step" is ONE pass of the hot path over one batch of
 synthetic input = one utterance batch per GPU: per-utterance hoists (text embedding, conditioning projection, time/AdaLN
-tables -- recomputed every utterance, nothing is cached across steps) + 32 Euler steps of the CFG-folded DiT + Vocos decode
+tables -- recomputed every utterance, nothing is cached across steps) + the Euler steps of the CFG-folded DiT + Vocos decode
 of the generated frames + device->host copy of the waveform.  Inputs (reference mel, token ids, noise) are resident in HBM
 when the timed region starts; model load is outside it.
 
 Workloads (per GPU and step; fixed as N grows = weak scaling):
   configs1  BASELINE configs[1] (the headline): multilingual_grl, batch 1, 10 s reference + 10 s target (F=938, N=1875)
+  configs2  BASELINE configs[2]: multilingual_prosody, batch 8 of MIXED lengths (prompts 375..938 frames, durations 900..1900: ragged
+            `lens` / masks), prosody conditioning, sway; every utterance vocoded on its own.  The line reports the padded-row waste
+            (real frames vs the rows the batched launches compute)
   configs3  BASELINE configs[3]'s per-GPU share: 8 utterances of 4 s reference + 8 s target (F=375, N=1125) as one batch
             (64 utterances over 8 GPUs)
+  configs4  BASELINE configs[4]: speech-edit infill of a 30 s source (N=2814), 3 edit spans, NFE 48, sway 3, fp8 MFMA weights (the
+            workload's own precision: --fp8 defaults to 1 here), the WHOLE utterance vocoded (speech_edit_multilingual.py:193-198)
   short     one short utterance, 4 s + 4 s (F=375, N=750): what the entry script mostly sees
-All: NFE 32, cfg 2.0, sway coef 5 (capped 3.486), bf16 MFMA operands with fp32 accumulate / residual / ODE state.
+All: cfg 2.0, bf16 MFMA operands with fp32 accumulate / residual / ODE state unless fp8 is on; NFE 32 and sway coef 5 (capped
+3.486) except configs4.
 Multi-GPU: utterance-level data parallelism, weights generated on rank 0 and broadcast over RCCL/xGMI into device memory
-(loaded device-to-device on every rank), no collective in the step loop.
+(loaded device-to-device on every rank), no collective in the step loop.  ``--job configs3_full`` runs the SHARDED JOB instead of
+the weak-scaling step: rank 0 owns BASELINE configs[3]'s 64 utterances, deals them (lemas_tts_amd.parallel.shard_utterances), every
+rank samples + vocodes its shard, the waveforms come back to rank 0's host, and the wall time of the job is reported (see run_job).
 
 CORRECTNESS inside the run: the mel the timed region produced last is compared with the committed output of the REFERENCE
-itself on the same inputs (tests/golden/configs1_nfe32.npz, configs3_share_nfe32.npz: 22 blocks, all 32 steps; the short
-workload against configs0_nfe16.npz, the same utterance over 16 steps, in one extra untimed solve; made by oracle/gen_golden.py
---full-size); the run FAILS above mel-MSE 1e-4 and the value is reported as ``mel_mse_vs_reference``.
+itself on the same inputs (tests/golden/configs*.npz: 22 blocks, full NFE; the short workload against configs0_nfe16.npz, the same
+utterance over 16 steps, in one extra untimed solve; made by oracle/gen_golden.py --full-size); the run FAILS above mel-MSE 1e-4
+and the value is reported as ``mel_mse_vs_reference``.
 
 Pipelining (``--overlap 1``, the default): the Vocos decode + D2H of utterance i run on a side stream under the step loop of
 utterance i+1 (the step loop itself still holds ONE utterance batch at a time: the B = 1 definition of configs[1] is unchanged;
@@ -36,12 +44,15 @@ The JSON line also carries
   roofline     -- the dominant kernel BY SYMBOL (what rocprofv3 --stats lists; out-proj and FF2 share one instantiation):
                   algorithmic FLOPs per launch / average launch duration, measured live with HIP event pairs stamped by the
                   dispatch itself (hipExtLaunchKernelGGL) in a short eager pass with the timed region's launch shapes, vs
-                  2.5 PFLOP/s dense bf16; ``roofline_gemm_family`` = all block GEMMs together, ``path_frac`` = whole path;
+                  2.5 PFLOP/s dense bf16, plus what the committed PMC passes say the kernel is bound BY (profiles/r04_kernel_bounds.json:
+                  matrix-pipe busy share, waves parked / stalled, L2 hit rate, fabric bytes); ``roofline_kernels`` = the same for every
+                  big launch; ``roofline_gemm_family`` = all block GEMMs together, ``path_frac`` = whole path;
   roofline_vocoder -- the HBM-bound phase: algorithmic bytes of one decode (fp32 weights + 400 L + 1024 (L-1)) over
                   its measured duration, vs 8 TB/s; ``phase_ms`` = hoists / step loop / vocoder / D2H of one utterance, measured
                   serially with stream events after the timed region;
   cpu_baseline -- the fp32 oracle (oracle/lemas_oracle.py, a port of the reference's path) timed on this box's host
-                  cores on a bounded sample (1 of the 32 Euler steps at full N, scaled x32, + the full vocoder).
+                  cores on a bounded sample: the FIRST Euler step (which also builds both branches' text embedding, cached afterwards)
+                  and a SECOND, warm one are timed apart; estimate = first + 31 x warm + the full vocoder.
 """
 from __future__ import annotations
 
@@ -71,12 +82,20 @@ MFMA_FP8_PEAK_TFLOPS = 5000.0
 MEL_MSE_TOL = 1e-4
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# vocode: "generated" = frames F-1.. of every utterance (utils_infer.py:520,546) | "each" = the same per utterance of a ragged batch |
+# "whole" = every frame (speech_edit_multilingual.py:193-198)
 WORKLOADS = {
-    "configs1": dict(B=1, F=938, N=1875, golden="configs1_nfe32.npz", golden_steps=32,
+    "configs1": dict(B=1, F=938, N=1875, golden="configs1_nfe32.npz", golden_steps=32, nfe=32, sway=5, wseed=1234, prosody=False, fp8=0, vocode="generated",
                      desc="BASELINE configs[1]: multilingual_grl, batch 1, 10 s ref + 10 s target"),
-    "configs3": dict(B=8, F=375, N=1125, golden="configs3_share_nfe32.npz", golden_steps=32,
+    "configs2": dict(B=8, F=938, N=1900, golden="configs2_prosody_b8.npz", golden_steps=32, nfe=32, sway=5, wseed=1235, prosody=True, fp8=0, vocode="each",
+                     desc="BASELINE configs[2]: multilingual_prosody, batch 8 of mixed lengths (prompts 375..938, durations 900..1900 frames), "
+                          "prosody conditioning, sway"),
+    "configs3": dict(B=8, F=375, N=1125, golden="configs3_share_nfe32.npz", golden_steps=32, nfe=32, sway=5, wseed=1234, prosody=False, fp8=0, vocode="generated",
                      desc="BASELINE configs[3] per-GPU share: multilingual_grl, 8 utterances of 4 s ref + 8 s target as one batch"),
-    "short": dict(B=1, F=375, N=750, golden="configs0_nfe16.npz", golden_steps=16,
+    "configs4": dict(B=1, F=2813, N=2814, golden="configs4_edit_nfe48.npz", golden_steps=48, nfe=48, sway=3.0, wseed=1234, prosody=False, fp8=1, vocode="whole",
+                     desc="BASELINE configs[4]: speech-edit infill of a 30 s source, 3 edit spans (7.5 s regenerated), NFE 48, sway 3, fp8 MFMA weights, "
+                          "whole utterance vocoded"),
+    "short": dict(B=1, F=375, N=750, golden="configs0_nfe16.npz", golden_steps=16, nfe=32, sway=5, wseed=1234, prosody=False, fp8=0, vocode="generated",
                   desc="one short utterance: multilingual_grl, batch 1, 4 s ref + 4 s target"),
 }
 
@@ -86,11 +105,12 @@ def fwd_flops(B: int, N: int) -> float:
     return B * (378_888_192.0 * N + 90_112.0 * N * N)
 
 
-def class_flops(cls: str, rows: int, n: int, bb: int, d: int = 1024, ff: int = 2048, heads: int = 16) -> float:
-    """Algorithmic FLOPs of one launch of a step-loop kernel class (rows = real frames of the launch, not the padded row space)."""
+def class_flops(cls: str, rows: float, nsq: float, d: int = 1024, ff: int = 2048, heads: int = 16) -> float:
+    """Algorithmic FLOPs of one launch of a step-loop kernel class: rows = REAL frames the launch covers (not the padded row space),
+    nsq = sum over its samples of (real frames)^2."""
     return {"gemm_qkv_fused": 2.0 * rows * 3 * d * d, "gemm_qk_rope": 2.0 * rows * 2 * d * d, "gemm_v_t": 2.0 * rows * d * d,
             "gemm_attn_out": 2.0 * rows * d * d, "gemm_ff1_gelu": 2.0 * rows * ff * d, "gemm_ff2": 2.0 * rows * d * ff,
-            "attention": 4.0 * n * n * 64 * bb * heads}[cls]
+            "attention": 4.0 * nsq * 64 * heads}[cls]
 
 
 # kernel classes of the profile pass -> the symbol rocprofv3 lists them under (out-proj and FF2 are ONE instantiation)
@@ -100,7 +120,8 @@ SYMBOL = {"gemm_qkv_fused": "gemm_qkv_fused_kernel", "gemm_qk_rope": "gemm_bf16_
 
 
 def build_inputs(w: dict, rank: int, device):
-    """rank 0 runs the utterance(s) of the committed reference fixture (so the result can be checked); the others seeded ones"""
+    """rank 0 runs the utterance(s) of the committed reference fixture (so the result can be checked); the others seeded ones
+    (equal-length workloads; tools/e2e_ab.py uses this form)"""
     B, F, N = w["B"], w["F"], w["N"]
     fx = None
     if w["golden"] and os.path.exists(os.path.join(GOLDEN, w["golden"])):
@@ -114,6 +135,49 @@ def build_inputs(w: dict, rank: int, device):
         text = torch.stack([torch.from_numpy(synth.synth_tokens(1234 + 97 * rank + b, nt, VOCAB)) for b in range(B)])
         y0 = torch.stack([torch.from_numpy(synth.synth_noise(1234 + 97 * rank + b, N)) for b in range(B)])
     return cond.to(device), text.to(device), y0.to(device), (fx if rank == 0 else None)
+
+
+def build_case(w: dict, rank: int, device):
+    """Everything one CFM.sample call of the workload takes.  The ragged / edit workloads (configs2, configs4) run the committed reference
+    fixture's own inputs on every rank (weak scaling: the same work everywhere); the equal-length ones as build_inputs."""
+    if w["vocode"] == "generated":
+        cond, text, y0, fx = build_inputs(w, rank, device)
+        B = w["B"]
+        return dict(cond=cond, text=text, y0=y0, duration=w["N"], lens=None, kw={}, lens_list=[w["F"]] * B, dur_list=[w["N"]] * B, fx=fx)
+    fx = synth.expand_reference_fixture(dict(np.load(os.path.join(GOLDEN, w["golden"]))))
+    B = int(fx["B"])
+    kw = {}
+    if "edit_mask" in fx:
+        kw["edit_mask"] = torch.from_numpy(fx["edit_mask"])
+    if "prosody_embeds" in fx:
+        kw["prosody_embeds"] = torch.from_numpy(fx["prosody_embeds"]).to(device)
+    dur = [int(v) for v in fx["duration"]]
+    return dict(cond=torch.from_numpy(fx["cond"]).to(device), text=torch.from_numpy(fx["text"]).to(device), y0=torch.from_numpy(fx["y0"]).to(device),
+                duration=dur[0] if B == 1 else torch.from_numpy(fx["duration"]), lens=torch.from_numpy(fx["lens"]), kw=kw,
+                lens_list=[int(v) for v in fx["lens"]], dur_list=dur, fx=(fx if rank == 0 else None))
+
+
+def vocode_segments(w: dict, case: dict, out_frames: int):
+    """(sample, first frame, end frame) of every waveform the workload produces; a decode of L frames yields HOP (L - 1) samples"""
+    if w["vocode"] == "whole":
+        return [(b, 0, out_frames) for b in range(w["B"])]
+    return [(b, case["lens_list"][b] - 1, min(case["dur_list"][b], out_frames)) for b in range(w["B"])]
+
+
+def gen_mse(out: np.ndarray, ref: np.ndarray, fx: dict) -> float:
+    """mel-MSE over the generated (non-conditioning) frames of every sample, as SURVEY.md 8d defines it (tests/test_gpu_00_sample.py)"""
+    se, cnt = 0.0, 0
+    for b in range(int(fx["B"])):
+        L, D = int(fx["lens"][b]), int(fx["duration"][b])
+        keep = np.ones(out.shape[1], bool)
+        keep[:L] = False
+        if "edit_mask" in fx:
+            keep = ~(np.pad(fx["edit_mask"][b], (0, out.shape[1] - fx["edit_mask"].shape[1])) & (np.arange(out.shape[1]) < L))
+        keep &= np.arange(out.shape[1]) < D
+        d = out[b, keep].astype(np.float64) - ref[b, keep].astype(np.float64)
+        se += float((d ** 2).sum())
+        cnt += d.size
+    return se / max(cnt, 1)
 
 
 def mel_mse(out: torch.Tensor, ref: np.ndarray, F: int) -> float:
@@ -135,29 +199,39 @@ def usable_cores() -> int:
 
 
 def cpu_baseline(sd, vsd, arch, w):
-    """Oracle on host cores, bounded sample of the same workload."""
+    """Oracle on host cores, bounded sample of the same workload: ONE utterance of the workload's prompt / target size, the first and a
+    second (warm) Euler step timed apart -- the first also builds both CFG branches' text embedding, which the reference caches for the
+    rest of the solve (dit.py:212-220) -- and the full vocoder."""
     from oracle import lemas_oracle as O  # checker / baseline only
     cores = usable_cores()
     torch.set_num_threads(cores)
-    F, N = w["F"], w["N"]
+    F, N, nfe = w["F"], w["N"], w["nfe"]
     cond = torch.from_numpy(synth.synth_cond_mel(1234, F))[None]
     text = torch.from_numpy(synth.synth_tokens(1234, round(N * 0.17), VOCAB))[None]
     y0 = torch.from_numpy(synth.synth_noise(1234, N))[None]
+    if "prosody_to_mel.weight" in sd:      # the prosody workload's weights: time the same DiT without the (B x 512) conditioning GEMVs
+        sd = {k: v for k, v in sd.items() if not (k.startswith("prosody_to_mel.") or ".prosody_text_proj." in k)}
     cfm = O.OracleCFM(sd, arch)
-    sub = 1
-    tg = O.time_grid(NFE, SWAY)[: sub + 1]
+    tg = O.time_grid(nfe, w["sway"])
     t0 = time.perf_counter()
-    out, _ = cfm.sample(cond, text, N, y0=y0, steps=sub, cfg_strength=CFG, sway_sampling_coef=SWAY, t_grid=tg)
-    t_steps = time.perf_counter() - t0
-    mel = out[:, F - 1:, :].permute(0, 2, 1)
+    cfm.sample(cond, text, N, y0=y0, steps=1, cfg_strength=CFG, sway_sampling_coef=w["sway"], t_grid=tg[:2])
+    t_first = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    out, _ = cfm.sample(cond, text, N, y0=y0, steps=2, cfg_strength=CFG, sway_sampling_coef=w["sway"], t_grid=tg[:3])
+    t_two = time.perf_counter() - t0
+    t_warm = max(t_two - t_first, 1e-3)
+    lo = 0 if w["vocode"] == "whole" else F - 1
+    mel = out[:, lo:, :].permute(0, 2, 1)
     t0 = time.perf_counter()
     O.OracleVocos(vsd).decode(mel)
     t_voc = time.perf_counter() - t0
     audio_s = HOP * (mel.shape[-1] - 1) / SR
-    est = t_steps * (NFE / sub) + t_voc
+    est = t_first + (nfe - 1) * t_warm + t_voc
     return {"value": audio_s / est, "unit": "audio-seconds/sec", "cores": cores, "kind": "port",
-            "sample": f"one utterance of the workload (F={F}, N={N}): {sub} of {NFE} Euler steps ({t_steps:.1f} s) scaled x{NFE // sub} "
-                      f"+ full Vocos decode ({t_voc:.2f} s); fp32 torch, {cores} threads"}
+            "first_step_s": t_first, "warm_step_s": t_warm, "vocoder_s": t_voc,
+            "sample": f"one utterance of the workload's size (F={F}, N={N}): Euler step 1 of {nfe} ({t_first:.1f} s, incl. both branches' text "
+                      f"embedding) and a warm step 2 ({t_warm:.1f} s, from a 2-step solve) timed apart, estimate = first + {nfe - 1} x warm + full Vocos "
+                      f"decode ({t_voc:.2f} s); fp32 torch, {cores} threads"}
 
 
 def clock_power(step_fn, seconds: float = 4.0):
@@ -215,6 +289,126 @@ def spawn_ranks(n: int) -> int:
     return max(abs(rc) for rc in rcs)
 
 
+def run_job(a, w, model, vocoder, rank, world, dist, comm_device, device, bcast):
+    """BASELINE configs[3] as a JOB (utterance shards scattered from the host, waveforms returned to it; precedent
+    uvr5/multiprocess_cuda_infer.py:404-420): rank 0 owns the 64 utterances (4 s prompt + 8 s target each), deals them longest-first
+    (lemas_tts_amd.parallel.shard_utterances), sends every rank its shard's inputs, each rank runs its shard as ONE CFM.sample batch
+    + one Vocos decode and the waveforms travel back to rank 0's HOST memory.  Reported: wall time of the job on rank 0 (inputs
+    leaving its host to last waveform back), per-rank compute, scatter and gather times.  No collective inside the step loop."""
+    from lemas_tts_amd.parallel import shard_utterances
+    U, F_, N = 64, w["F"], w["N"]
+    nt = round(N * 0.17)
+    L = N - F_ + 1
+    nfe, sway = w["nfe"], w["sway"]
+    shards = shard_utterances([N] * U, world)
+    mine = shards[rank]
+    per = len(mine)
+    assert sorted(i for sh in shards for i in sh) == list(range(U)) and all(len(sh) == U // world for sh in shards), "64 utterances deal evenly"
+
+    def make(i):          # utterance i of the job (seeded: every rank COULD build it, only rank 0 does)
+        return (torch.from_numpy(synth.synth_cond_mel(5000 + i, F_)), torch.from_numpy(synth.synth_tokens(5000 + i, nt, VOCAB)),
+                torch.from_numpy(synth.synth_noise(5000 + i, N)))
+    job = [make(i) for i in range(U)] if rank == 0 else None
+
+    MB = w["B"]           # utterances per CFM.sample batch: configs[3]'s per-GPU batch of 8; a rank with a longer shard runs it in turns
+
+    def once():
+        t = {}
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        # ---- scatter: rank 0 sends each rank its shard (cond | y0 as one fp32 buffer, tokens as int64), point to point
+        nf = per * (F_ + N) * 100
+
+        def pack(idx):
+            return (torch.cat([torch.stack([job[i][0] for i in idx]).reshape(-1), torch.stack([job[i][2] for i in idx]).reshape(-1)]),
+                    torch.stack([job[i][1] for i in idx]).reshape(-1))
+        if rank == 0:
+            for r in range(1, world):
+                fb, tb = pack(shards[r])
+                dist.send(fb.to(comm_device), dst=r)
+                dist.send(tb.to(comm_device), dst=r)
+            fbuf, tbuf = pack(shards[0])
+            fbuf, tbuf = fbuf.to(comm_device), tbuf.to(comm_device)
+        else:
+            fbuf = torch.empty(nf, dtype=torch.float32, device=comm_device)
+            tbuf = torch.empty(per * nt, dtype=torch.int64, device=comm_device)
+            dist.recv(fbuf, src=0)
+            dist.recv(tbuf, src=0)
+        cond = fbuf[: per * F_ * 100].reshape(per, F_, 100).to(device)
+        y0 = fbuf[per * F_ * 100:].reshape(per, N, 100).to(device)
+        text = tbuf.reshape(per, nt).cpu()
+        torch.cuda.synchronize()
+        t["scatter_ms"] = 1e3 * (time.perf_counter() - t0)
+        # ---- this rank's shard: batches of MB through the sampler and the vocoder
+        t1 = time.perf_counter()
+        wavs, out = [], None
+        for c0 in range(0, per, MB):
+            o, _ = model.sample(cond[c0:c0 + MB], text[c0:c0 + MB], N, steps=nfe, cfg_strength=CFG, sway_sampling_coef=sway, y0=y0[c0:c0 + MB],
+                                use_acc_grl=False)
+            wavs.append(vocoder.decode(o[:, F_ - 1:, :].permute(0, 2, 1)))
+            out = o if out is None else out
+        wav = torch.cat(wavs)
+        torch.cuda.synchronize()
+        t["compute_ms"] = 1e3 * (time.perf_counter() - t1)
+        # ---- gather: waveforms back to rank 0's host
+        t2 = time.perf_counter()
+        wbuf = wav.to(comm_device).contiguous()
+        host = None
+        if rank == 0:
+            host = torch.empty((U, HOP * (L - 1)), dtype=torch.float32)
+            host[torch.tensor(shards[0])] = wbuf.cpu()
+            for r in range(1, world):
+                got = torch.empty_like(wbuf)
+                dist.recv(got, src=r)
+                host[torch.tensor(shards[r])] = got.cpu()
+        else:
+            dist.send(wbuf, dst=0)
+        torch.cuda.synchronize()
+        t["gather_ms"] = 1e3 * (time.perf_counter() - t2)
+        t["job_ms"] = 1e3 * (time.perf_counter() - t0)
+        return t, host, out
+
+    for _ in range(max(a.warmup, 1)):
+        once()
+    runs = [once() for _ in range(max(a.steps, 1))]
+    times = [r[0] for r in runs]
+    host = runs[-1][1]
+    mine_t = torch.tensor([[t["scatter_ms"], t["compute_ms"], t["gather_ms"], t["job_ms"]] for t in times], dtype=torch.float64).mean(0)
+    every = [mine_t]
+    if dist and world > 1:
+        every = [torch.zeros_like(mine_t, device=comm_device) for _ in range(world)]
+        dist.all_gather(every, mine_t.to(comm_device))
+        every = [e.cpu() for e in every]
+    if rank != 0:
+        return None
+    assert host is not None and np.isfinite(host.numpy()).all() and float(host.abs().amax()) > 0
+    # parity inside the run: one utterance of rank 0's shard alone gives the bits it gave inside the batch (what makes the deal irrelevant)
+    i0 = shards[0][0]
+    c1, t1_, y1 = make(i0)
+    one, _ = model.sample(c1[None].to(device), t1_[None], N, steps=nfe, cfg_strength=CFG, sway_sampling_coef=sway, y0=y1[None].to(device), use_acc_grl=False)
+    same = bool(torch.equal(one[0].cpu(), runs[-1][2][0].cpu()))
+    assert same, "bench.py --job: an utterance inside its rank's batch differs from the same utterance alone"
+    job_ms = float(every[0][3])
+    audio = U * HOP * (L - 1) / SR
+    return {"metric": f"audio-seconds/sec @24kHz (NFE={nfe}, CFG on): sharded JOB", "value": audio / (job_ms * 1e-3), "unit": "audio-seconds/sec",
+            "n_gpus": world, "steps": max(a.steps, 1), "warmup": max(a.warmup, 1), "ms_per_step": job_ms, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "fp8" if a.fp8 else "bf16", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[3] as a job: {U} utterances of 4 s ref + 8 s target (F={F_}, N={N}) owned by rank 0, dealt to "
+                                   f"{world} rank(s) ({U // world} per rank as one batch), NFE={nfe}, CFG={CFG}, waveforms gathered on rank 0's host",
+                       "workload_key": "configs3_full", "utterances_total": U, "utterances_per_rank": U // world, "utterances_per_batch": MB,
+                       "batches_per_rank": (U // world + MB - 1) // MB,
+                       "parallelism": f"dp{world}: scatter inputs -> per-rank CFM.sample batch + Vocos decode -> gather waveforms; no step-loop collective",
+                       "audio_seconds_total": audio, "utterance_alone_equals_in_batch": same},
+            "job_ms": job_ms,
+            "per_rank_ms": {"scatter": [round(float(e[0]), 3) for e in every], "compute": [round(float(e[1]), 3) for e in every],
+                            "gather": [round(float(e[2]), 3) for e in every], "job": [round(float(e[3]), 3) for e in every]},
+            "weight_broadcast": bcast,
+            "weight_broadcast_note": "fp32 as loaded (1.35 GB): the per-step AdaLN tables and every per-utterance hoist are computed from fp32 masters; "
+                                     "only the block GEMM weights (0.37 GB of it in bf16 terms) could travel rounded -- a once-per-process saving of a few ms"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -223,8 +417,11 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="configs1")
     ap.add_argument("--depth", type=int, default=22, help="DiT depth (22 = the shipped model; smaller only for debugging, no parity check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--fp8", type=int, default=0, help="1 = block GEMMs on the fp8-e4m3 (MXFP8) path of BASELINE config 5; "
-                    "NOT the headline configuration (configs[1] is bf16): the line is then labelled dtype fp8")
+    ap.add_argument("--fp8", type=int, default=-1, help="1 = block GEMMs on the fp8-e4m3 (MXFP8) path of BASELINE config 5, 0 = bf16; default: the "
+                    "workload's own precision (bf16 everywhere but configs4).  The line is labelled with the dtype it ran")
+    ap.add_argument("--job", choices=["configs3_full"], default=None, help="run the SHARDED JOB instead of the weak-scaling step: rank 0 owns "
+                    "BASELINE configs[3]'s 64 utterances, deals them to the ranks, gathers the waveforms on its host (see run_job)")
+    ap.add_argument("--attn-variant", type=int, default=-1, help="engine option attn_variant (-1 = engine default)")
     ap.add_argument("--dual", type=int, default=1, help="1 = CFG branches as two concurrent lanes (default), 0 = one stream")
     ap.add_argument("--overlap", type=int, default=1, help="1 = Vocos decode + D2H of utterance i on a side stream under the step loop of "
                     "utterance i+1 (default), 0 = strictly serial")
@@ -282,22 +479,27 @@ def main():
     from lemas_tts_amd.model.cfm import CFM, time_grid  # noqa: E402
     from lemas_tts_amd.parallel import broadcast_state_dict  # noqa: E402
 
-    w = WORKLOADS[a.workload]
+    w = WORKLOADS["configs3" if a.job else a.workload]
     B, F_REF, N_TOT = w["B"], w["F"], w["N"]
+    nfe, sway = w["nfe"], w["sway"]
+    if a.fp8 < 0:
+        a.fp8 = w["fp8"]
     arch = DiTArch(depth=a.depth)
     # weights: generated on rank 0, broadcast over RCCL/xGMI; every rank loads them device-to-device from the received buffer
-    sd = synth.synth_cfm_state_dict(arch, VOCAB, 1234) if rank == 0 else None
+    sd = synth.synth_cfm_state_dict(arch, VOCAB, w["wseed"], prosody=w["prosody"]) if rank == 0 else None
     vsd = synth.synth_vocos_state_dict(1234) if rank == 0 else None
     sd_host, vsd_host = sd, vsd
     bcast = None
     if use_dist:
         t_b = time.perf_counter()
-        sd = broadcast_state_dict(sd, arch, VOCAB, comm_device, dist)
+        sd = broadcast_state_dict(sd, arch, VOCAB, comm_device, dist, prosody=w["prosody"])
         vsd = broadcast_state_dict(vsd, None, None, comm_device, dist, vocos=True)
         nbytes = 4 * (sum(int(np.prod(v.shape)) for v in sd.values()) + sum(int(np.prod(v.shape)) for v in vsd.values()))
         bcast = {"backend": backend, "bytes": nbytes, "seconds": time.perf_counter() - t_b,
                  "on_device": bool(comm_device.type == "cuda"), "world": world}
-    model = CFM(arch, VOCAB, sd, device=device)
+    model = CFM(arch, VOCAB, sd, device=device, use_prosody_encoder=w["prosody"])
+    if a.attn_variant >= 0:
+        model.engine.set_option("attn_variant", a.attn_variant)
     model.engine.set_option("dual", a.dual)
     model.engine.set_option("fp8", a.fp8)
     if a.ln_fused >= 0:
@@ -307,21 +509,47 @@ def main():
     model.engine.set_option("table_cache", 0)      # hoists are redone for every utterance: nothing cached across steps
     vocoder = VocosEngine(vsd, device=device)
     del sd, vsd                                     # the engines own their copies; the broadcast buffer can go
-    cond, text, y0, fx = build_inputs(w, rank, device)
-    text = text.cpu().pin_memory()                 # token ids arrive from the host frontend (api.py:201-204): no D2H sync per utterance
-    L_GEN = N_TOT - F_REF + 1
-    host_wav = torch.empty((B, HOP * (L_GEN - 1)), dtype=torch.float32).pin_memory()
+    if a.job:
+        result = run_job(a, w, model, vocoder, rank, world, dist, comm_device, device, bcast)
+        if dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        sys.stdout.flush()
+        if rank == 0:
+            os.write(json_fd, (json.dumps(result) + "\n").encode())
+        os.close(json_fd)
+        return
+    case = build_case(w, rank, device)
+    fx = case["fx"]
+    text = case["text"].cpu().pin_memory()          # token ids arrive from the host frontend (api.py:201-204): no D2H sync per utterance
+    segs = vocode_segments(w, case, N_TOT)           # (sample, first frame, end frame) of every waveform one step produces
+    host_wav = [torch.empty((1, HOP * (e - s - 1)), dtype=torch.float32).pin_memory() for _, s, e in segs]
+    if w["vocode"] == "generated":                   # equal lengths: ONE decode of the whole batch, as before
+        host_wav = [torch.empty((B, HOP * (segs[0][2] - segs[0][1] - 1)), dtype=torch.float32).pin_memory()]
+    audio_per_step = sum(HOP * (e - s - 1) for _, s, e in segs) / SR
     last = {}
     side = torch.cuda.Stream(device) if a.overlap else None
 
     def vocode(out):
-        # the driver vocodes generated[:, nw // 256:] = frames F-1.. (utils_infer.py:520,546): L_gen = N - F + 1
-        wav = vocoder.decode(out[:, F_REF - 1:, :].permute(0, 2, 1))
-        host_wav.copy_(wav, non_blocking=True)
+        # the driver vocodes generated[:, nw // 256:] = frames F-1.. (utils_infer.py:520,546): L_gen = N - F + 1; a ragged batch one
+        # utterance at a time; the speech-edit script every frame (speech_edit_multilingual.py:193-198).  The slices go to the library as
+        # strided views (VocosEngine.decode takes the frames-first layout in place): no torch copy kernel in between
+        if w["vocode"] == "generated":
+            wav = vocoder.decode(out[:, segs[0][1]:segs[0][2], :].permute(0, 2, 1))
+            host_wav[0].copy_(wav, non_blocking=True)
+            return wav
+        wav = None
+        for i, (b, s0, e0) in enumerate(segs):
+            wav = vocoder.decode(out[b:b + 1, s0:e0, :].permute(0, 2, 1))
+            host_wav[i].copy_(wav, non_blocking=True)
         return wav
 
-    def step(steps=NFE):
-        out, _ = model.sample(cond, text, N_TOT, steps=steps, cfg_strength=CFG, sway_sampling_coef=SWAY, y0=y0, use_acc_grl=False)
+    def sample(steps=nfe):
+        return model.sample(case["cond"], text, case["duration"], lens=case["lens"], steps=steps, cfg_strength=CFG, sway_sampling_coef=sway,
+                            y0=case["y0"], use_acc_grl=False, **case["kw"])[0]
+
+    def step(steps=nfe):
+        out = sample(steps)
         last["out"] = out
         if side is None:
             return vocode(out)
@@ -356,32 +584,31 @@ def main():
         tmax = mine.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    assert np.isfinite(host_wav.numpy()).all()
+    assert all(np.isfinite(hw.numpy()).all() for hw in host_wav)
 
     # ---- correctness of what was just timed (rank 0 holds the fixture's utterance): reference output on the same inputs
     mse = None
     if rank == 0 and fx is not None and a.depth == 22 and a.steps + a.warmup > 0:
-        if w["golden_steps"] == NFE:
-            mse = mel_mse(last["out"], fx["out"], F_REF)             # the timed region's own last result
+        if w["golden_steps"] == nfe:
+            mse = gen_mse(last["out"].detach().cpu().numpy(), fx["out"], fx)      # the timed region's own last result
         else:                                                        # the fixture is a short solve: one extra untimed sample
-            out, _ = model.sample(cond, text, N_TOT, steps=w["golden_steps"], cfg_strength=CFG, sway_sampling_coef=SWAY, y0=y0, use_acc_grl=False)
-            mse = mel_mse(out, fx["out"], F_REF)
+            mse = gen_mse(sample(w["golden_steps"]).detach().cpu().numpy(), fx["out"], fx)
         tol = MEL_MSE_TOL
         assert mse <= tol, f"bench.py: the timed path is WRONG: mel-MSE vs the reference's output {mse:.3e} > {tol:g}"
 
     result = None
     if rank == 0:
-        audio_per_step = B * HOP * (L_GEN - 1) / SR
         value = world * a.steps * audio_per_step / elapsed
-        flops_step = 2 * NFE * fwd_flops(B, N_TOT) * (a.depth / 22.0)
+        real_rows, rows_computed = sum(case["dur_list"]), B * ((N_TOT + 127) // 128 * 128)
+        flops_step = 2 * nfe * sum(fwd_flops(1, n) for n in case["dur_list"]) * (a.depth / 22.0)
         path_tflops = flops_step / (elapsed / a.steps) / 1e12
         result = {
-            "metric": "audio-seconds/sec @24kHz (NFE=32, CFG on)", "value": value, "unit": "audio-seconds/sec",
+            "metric": f"audio-seconds/sec @24kHz (NFE={nfe}, CFG on)", "value": value, "unit": "audio-seconds/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp8" if a.fp8 else "bf16", "data": "synthetic",
             "rtf": elapsed / (a.steps * audio_per_step),
             "mel_mse_vs_reference": mse,
-            "config": {"workload": f"{w['desc']} (F={F_REF}, N={N_TOT}), NFE={NFE}, CFG={CFG}, sway coef {SWAY} (capped), "
+            "config": {"workload": f"{w['desc']} (F={F_REF}, N={N_TOT}), NFE={nfe}, CFG={CFG}, sway coef {sway} (capped), "
                                    + ("fp8-e4m3 (MXFP8) GEMM operands, bf16 attention" if a.fp8 else "bf16 MFMA operands")
                                    + " / fp32 state, Vocos decode + D2H included",
                        "workload_key": a.workload,
@@ -393,7 +620,10 @@ def main():
                                       if a.overlap else "none (strictly serial)"),
                        "parallelism": f"dp{world} ({world} process(es), one per GPU; utterance sharding, RCCL weight broadcast into "
                                       "device memory, no step-loop collectives)",
-                       "depth": a.depth, "weights": "synthetic N(0,0.02^2), seed 1234",
+                       "depth": a.depth, "weights": f"synthetic N(0,0.02^2), seed {w['wseed']}",
+                       "real_frames_per_step": real_rows, "rows_computed_per_step": rows_computed,
+                       "padded_row_waste": 1.0 - real_rows / rows_computed,       # the batched launches run every sample at the batch's 128-row pitch
+                       "waveforms_per_step": len(segs), "vocode": w["vocode"],
                        "parity_fixture": w["golden"] if mse is not None else None},
             "path_tflops": path_tflops,
             "path_frac": path_tflops / (MFMA_BF16_PEAK_TFLOPS if not a.fp8 else MFMA_FP8_PEAK_TFLOPS),
@@ -408,44 +638,48 @@ def main():
     if rank == 0 and world == 1:
         eng = model.engine
         eng.set_option("profile", 1)
-        sub = 4
-        tg = time_grid(NFE, SWAY)[: sub + 1]
-        cm = torch.zeros(B, N_TOT, dtype=torch.bool)
-        cm[:, :F_REF] = True
-        eng.prepare(torch.nn.functional.pad(cond, (0, 0, 0, N_TOT - F_REF)), cm, text, tg.numpy(), cond_frames=F_REF, cfg_strength=CFG)
-        eng.solve(y0, want_out=False)
+        sample(4)                                  # four Euler steps of the same batch, eager, every big launch stamped by its dispatch
         prof = eng.profile_read()
         eng.set_option("profile", 0)
         lanes = 2 if a.dual else 1                 # dual: each launch covers one CFG branch (B of the 2B branch-rows)
-        rows, bb = 2 * B * N_TOT // lanes, 2 * B // lanes
+        # algorithmic work of one launch: the REAL frames of the samples it covers (a ragged batch computes more rows than that: the waste
+        # is reported, not credited)
+        rows = 2.0 * real_rows / lanes
+        nsq = 2.0 * sum(n * n for n in case["dur_list"]) / lanes
+        bb = 2 * B // lanes
         mm = {k: v for k, v in prof.items() if k in SYMBOL and v[1] > 0}
         by_sym = {}
         for k, (ms, cnt) in mm.items():
             e = by_sym.setdefault(SYMBOL[k], {"ms": 0.0, "launches": 0, "flops": 0.0, "classes": []})
-            e["ms"] += ms; e["launches"] += int(cnt); e["flops"] += class_flops(k, rows, N_TOT, bb) * cnt; e["classes"].append(k)
+            e["ms"] += ms; e["launches"] += int(cnt); e["flops"] += class_flops(k, rows, nsq) * cnt; e["classes"].append(k)
         dom = max(by_sym, key=lambda s: by_sym[s]["ms"])      # dominant kernel = the symbol with the largest total time
         d = by_sym[dom]
         avg_us = 1e3 * d["ms"] / d["launches"]
         fl = d["flops"] / d["launches"]
         ach = fl / (avg_us * 1e-6) / 1e12
         total_ms = sum(v[0] for v in prof.values())
-        # HBM-side bytes per launch and the rocprofv3 average of the same symbol come from COMMITTED profiler passes over this very
-        # command (rocprofv3 cannot run inside bench.py); both are labelled with the file they were read from
-        traffic, traffic_src, rocprof_us, rocprof_src = None, None, None, None
-        for name in ("r03_traffic.json", "r02_traffic.json"):
-            try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", name)))
-                traffic, traffic_src = tj[a.workload][dom]["hbm_bytes_per_launch"], f"profiles/{name} <- {tj.get('_source', '?')}"
-                break
-            except (OSError, KeyError, ValueError, TypeError):
-                continue
-        try:
-            kj = json.load(open(os.path.join(ROOT, "profiles", "r03_kernel_avgs.json")))
-            rocprof_us, rocprof_src = kj[a.workload][dom]["avg_us"], f"profiles/r03_kernel_avgs.json <- {kj.get('_source', '?')}"
-        except (OSError, KeyError, ValueError, TypeError):
-            pass
+        # HBM-side bytes per launch, the rocprofv3 average of the same symbol and the counter-backed bound come from COMMITTED profiler
+        # passes over this very command (rocprofv3 cannot run inside bench.py); each is labelled with the file it was read from
+        def committed(names, *path):
+            for name in names:
+                try:
+                    j = json.load(open(os.path.join(ROOT, "profiles", name)))
+                    v = j
+                    for k_ in path:
+                        v = v[k_]
+                    return v, f"profiles/{name} <- {j.get('_source', '?')}"
+                except (OSError, KeyError, ValueError, TypeError):
+                    continue
+            return None, None
+        wkey = a.workload + ("_fp8" if a.fp8 and a.workload != "configs4" else "")
+        traffic_e, traffic_src = committed(("r04_traffic.json", "r03_traffic.json", "r02_traffic.json"), wkey, dom)
+        traffic = traffic_e.get("hbm_bytes_per_launch") if traffic_e else None
+        rocprof_e, rocprof_src = committed(("r04_kernel_avgs.json", "r03_kernel_avgs.json"), wkey, dom)
+        rocprof_us = rocprof_e.get("avg_us") if rocprof_e else None
+        bounds_all, bounds_src = committed(("r04_kernel_bounds.json",), wkey)
         is_gemm = dom != "attn_fwd_splitkv_kernel"
         peak = MFMA_FP8_PEAK_TFLOPS if (a.fp8 and is_gemm) else MFMA_BF16_PEAK_TFLOPS   # attention stays bf16
+        dom_bound = (bounds_all or {}).get(dom)
         result["roofline"] = {"bound": "mfma", "kernel": dom, "classes": d["classes"], "achieved": ach, "peak": peak,
                               "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src,
                               "avg_launch_us": avg_us, "avg_launch_us_source": "this run: eager pass, per-launch HIP event pairs, lanes serialised",
@@ -453,13 +687,18 @@ def main():
                               "frac_rocprof": (fl / (rocprof_us * 1e-6) / 1e12 / peak) if rocprof_us else None,
                               "launches": d["launches"], "flops_per_launch": fl,
                               "time_share": d["ms"] / total_ms,
-                              "launch_shape": f"{bb} x {N_TOT} frames per launch ({lanes} concurrent lane(s) in the timed region)"}
+                              "launch_shape": f"{bb} sample(s), {rows:.0f} real frames per launch ({lanes} concurrent lane(s) in the timed region)",
+                              # the MFMA peak is the roof the figure of merit is priced against (arithmetic intensity ~2 700
+                              # flop/B); what the kernel is held up BY, from the counters, is `limited_by`
+                              "limited_by": dom_bound, "limited_by_source": bounds_src}
+        if bounds_all:
+            result["roofline_kernels"] = {k: v for k, v in bounds_all.items() if not k.startswith("_")}
         g_ms = sum(v["ms"] for s, v in by_sym.items() if s != "attn_fwd_splitkv_kernel")
         g_fl = sum(v["flops"] for s, v in by_sym.items() if s != "attn_fwd_splitkv_kernel")
         gpeak = MFMA_FP8_PEAK_TFLOPS if a.fp8 else MFMA_BF16_PEAK_TFLOPS
         result["roofline_gemm_family"] = {"achieved": g_fl / (g_ms * 1e-3) / 1e12, "peak": gpeak, "frac": g_fl / (g_ms * 1e-3) / 1e12 / gpeak,
                                           "time_share": g_ms / total_ms, "unit": "TFLOP/s"}
-        result["kernel_tflops"] = {k: round(class_flops(k, rows, N_TOT, bb) / (1e3 * v[0] / v[1] * 1e-6) / 1e12, 1) for k, v in mm.items()}
+        result["kernel_tflops"] = {k: round(class_flops(k, rows, nsq) / (1e3 * v[0] / v[1] * 1e-6) / 1e12, 1) for k, v in mm.items()}
         result["kernel_time_share"] = {k: round(v[0] / total_ms, 4) for k, v in prof.items() if v[1] > 0}
         result["kernel_avg_us"] = {k: round(1e3 * v[0] / v[1], 2) for k, v in prof.items() if v[1] > 0}
 
@@ -477,13 +716,19 @@ def main():
                 best = ms if best is None else min(best, ms)
             return best, r
 
-        tgf = time_grid(NFE, SWAY)
-        condp = torch.nn.functional.pad(cond, (0, 0, 0, N_TOT - F_REF))
-        hoist_ms, _ = timed_ms(lambda: eng.prepare(condp, cm, text, tgf.numpy(), cond_frames=F_REF, cfg_strength=CFG))
-        loop_ms, (o_, _y) = timed_ms(lambda: eng.solve(y0), reps=2)
-        mel_in = o_[:, F_REF - 1:, :].permute(0, 2, 1).contiguous()
-        voc_ms, wav_ = timed_ms(lambda: vocoder.decode(mel_in))
-        d2h_ms, _ = timed_ms(lambda: host_wav.copy_(wav_, non_blocking=True))
+        ec = model.last_engine_call          # the engine-level inputs of the timed region's CFM.sample call
+        prep = lambda: eng.prepare(ec["cond"], ec["cond_mask"], ec["text"], ec["t_grid"], cond_frames=ec["cond_frames"], cfg_strength=ec["cfg_strength"],
+                                   seq_len=ec["seq_len"], prosody=ec["prosody"])
+        sample(nfe)                                # last_engine_call of a full-NFE solve
+        ec = model.last_engine_call
+        hoist_ms, _ = timed_ms(prep)
+        loop_ms, (o_, _y) = timed_ms(lambda: eng.solve(ec["y0"]), reps=2)
+        voc_ms, wav_ = timed_ms(lambda: vocode(o_))
+        b0, s0, e0 = segs[0]
+        one_mel = o_[b0:b0 + 1, s0:e0, :].permute(0, 2, 1) if w["vocode"] != "generated" else o_[:, s0:e0, :].permute(0, 2, 1)
+        dec_ms, wav1 = timed_ms(lambda: vocoder.decode(one_mel))
+        d2h_ms, _ = timed_ms(lambda: host_wav[0].copy_(wav1, non_blocking=True))
+        voc_ms = max(voc_ms - d2h_ms * len(host_wav), dec_ms)        # vocode() also issued the D2H copies: the decode share of it
         tot = hoist_ms + loop_ms + voc_ms + d2h_ms
         result["hoist_ms"] = hoist_ms
         result["phase_ms"] = {"hoists": hoist_ms, "step_loop": loop_ms, "vocoder": voc_ms, "d2h": d2h_ms, "sum_serial": tot,
@@ -494,11 +739,15 @@ def main():
         result["kernel_time_share_utterance"] = dict({k: round(v * loop_ms / tot, 4) for k, v in result["kernel_time_share"].items()},
                                                      hoists=round(hoist_ms / tot, 4), vocoder=round(voc_ms / tot, 4), d2h=round(d2h_ms / tot, 4))
         wbytes = 4 * sum(int(np.prod(np.shape(v))) for v in vsd_host.values())
-        voc_bytes = B * (400.0 * L_GEN + 1024.0 * (L_GEN - 1)) + wbytes      # weights + mel in + wav out
-        result["roofline_vocoder"] = {"bound": "hbm", "achieved": voc_bytes / (voc_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                                      "frac": voc_bytes / (voc_ms * 1e-3) / 8e12, "algorithmic_bytes": voc_bytes, "decode_ms": voc_ms,
-                                      "frames": L_GEN, "traffic": None,
-                                      "note": "launch-/latency-bound at batch 1: ~60 small fp32 launches for 25 GFLOP"}
+        L1 = e0 - s0                                                          # frames of the decode timed alone above
+        nb1 = one_mel.shape[0]
+        voc_bytes = nb1 * (400.0 * L1 + 1024.0 * (L1 - 1)) + wbytes           # weights + mel in + wav out
+        voc_traffic, voc_traffic_src = committed(("r04_traffic.json",), a.workload, "vocoder")
+        result["roofline_vocoder"] = {"bound": "hbm", "achieved": voc_bytes / (dec_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                      "frac": voc_bytes / (dec_ms * 1e-3) / 8e12, "algorithmic_bytes": voc_bytes, "decode_ms": dec_ms,
+                                      "frames": L1, "batch": nb1, "decodes_per_step": len(segs) if w["vocode"] != "generated" else 1,
+                                      "traffic": voc_traffic.get("hbm_bytes_per_decode") if voc_traffic else None, "traffic_source": voc_traffic_src,
+                                      "note": "latency-bound at batch 1: a chain of small fp32 launches (25 GFLOP at L = 938) replayed as one hipGraph"}
         result["clock_power"] = None if a.no_clock_power else clock_power(step)
         if result["clock_power"]:
             # the MFMA peak the roofline prices against is the 2.4 GHz figure; what the package was clocked to deliver while this ran

@@ -161,6 +161,7 @@ static int dit_section(void) {
   hipMemcpy(dtext, htext, sizeof htext, H2D);
   lemas_sample_args a;
   memset(&a, 0, sizeof a);
+  a.struct_size = sizeof a;                 /* ABI 200: the library refuses a struct of another layout */
   a.batch = B; a.frames = N; a.cond_frames = F; a.text_len = NT; a.steps = S; a.cfg_strength = 2.0f;
   a.cond = (const float*)dcond; a.cond_mask = (const uint8_t*)dmask; a.text = (const int64_t*)dtext; a.t_grid = tgrid;
   a.y = (float*)dy; a.out = (float*)dout;

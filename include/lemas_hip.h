@@ -59,7 +59,11 @@ typedef struct {
   int32_t has_prosody;      /* prosody_to_mel / prosody_text_proj present */
 } lemas_dit_config;
 
+/* ABI version 200 (lemas_version()): lemas_sample_args opens with its own size, checked by every entry point that takes it -- a client
+ * compiled against another layout of the struct is refused (LEMAS_E_ARG) instead of being read past its end.  Initialise with
+ * `lemas_sample_args a = {0}; a.struct_size = sizeof a;`. */
 typedef struct {
+  uint32_t struct_size; /* sizeof(lemas_sample_args) */
   int32_t batch;        /* B */
   int32_t frames;       /* N  = max duration (cfm.py:305) */
   int32_t cond_frames;  /* F  = frames of the reference mel before padding (cfm.py:240) */
@@ -82,6 +86,11 @@ typedef struct {
   int32_t prosody_text_only;  /* != 0: `prosody` conditions the TEXT side only (dit.py:225-233) and `cond` is final as given.  The
                                * no_ref_audio path of the reference overwrites the prosody-shifted mel with its random conditioning
                                * (cfm.py:313-324), so the prosody-to-mel projection has no effect there. */
+  int32_t cond_rows;          /* rows per sample present in `cond` / `step_cond`: [B,cond_rows,mel], 1 <= cond_rows <= N; rows beyond it
+                               * read as zero, which is the reference's right-padding (cfm.py:311) done by the library instead of a
+                               * caller-side pad copy.  0 = N (the buffers are already padded). */
+  const float* y_init;        /* device [B,N,mel] or NULL.  When set, the ODE starts from y_init (left untouched) and `y` is output
+                               * only; NULL = `y` is in/out as described above. */
 } lemas_sample_args;
 
 const char* lemas_last_error(void);
@@ -107,7 +116,8 @@ int lemas_dit_finalize(lemas_dit* m);
  *        activations (one E8M0 scale per 32 K); attention, norms, residual stream and ODE state unchanged; default 0;
  *        takes effect at the next prepare()/sample().  2 = accuracy point, not a speed path: the same e4m3 weights with bf16
  *        ACTIVATIONS (weights-only fp8), computed by the bf16 kernels on the dequantised weights),
- * "ln_fused" (1 = the AdaLN LayerNorms that follow the gated residual updates (modules.py:637, the next block's :314, the final
+ * "ln_fused" (needs EXCLUSIVE use of the device -- its co-residency estimate does not see other tenants; a wait that times out flags the
+ *        engine, see lemas_dit_health.  1 = the AdaLN LayerNorms that follow the gated residual updates (modules.py:637, the next block's :314, the final
  *        :335) run as the tail of the out-projection / FF2 launches whenever all workgroups of those launches fit the chip at
  *        once; default 0 = separate ln_mod launches: the fused form measured slower),
  * "ln_fold" (1 = those LayerNorms folded ACROSS the GEMMs on either side -- the gate + residual epilogues write the scaled bf16 rows and
@@ -120,6 +130,12 @@ int lemas_dit_finalize(lemas_dit* m);
  *        grid of the tile order (8, 4, 2, 1), "attn_variant" = schedule variant of the attention kernel (csrc/attention.hip; default
  *        19, 0 = classical online softmax).  Per engine: there is no process-global dispatch switch. */
 int lemas_dit_set_option(lemas_dit* m, const char* key, int64_t value);
+/* further options: "graph_cache" (step-graph buckets kept, least recently used evicted; default 16), "graph_update" (1 = a new
+ * frame count inside a cached bucket -- same batch, same 128-row pitch -- patches one of the bucket's instantiated graphs with
+ * hipGraphExecUpdate instead of instantiating another; default 1), "fp8_outlier_guard" (see below).
+ * counters since creation, for tools and tests: "graph_captures", "graph_instantiates", "graph_updates", "graph_update_failures",
+ * "graph_evictions", "graph_buckets", "fp8_gemms_kept_bf16" */
+int lemas_dit_get_stat(lemas_dit* m, const char* key, int64_t* value);
 /* synchronises the device and returns 0, or LEMAS_E_STATE when a device-side wait of this engine gave up (fused LayerNorm tail):
  * every result since then is invalid and prepare() / solve() refuse to run */
 int lemas_dit_health(lemas_dit* m);
@@ -145,6 +161,15 @@ int lemas_vocos_finalize(lemas_vocos* v);
 /* mel device [B, C, L] fp32 -> wav device [B, hop*(L-1)] fp32; `gain` multiplies the waveform (rms rescale,
  * utils_infer.py:552-553; pass 1.0 for none) */
 int lemas_vocos_decode(lemas_vocos* v, const float* mel, int32_t batch, int32_t frames, float gain, float* wav, void* stream);
+/* the same on the FRAMES-FIRST layout the sampler produces: mel_rows device [B][frames][C] fp32, sample b starting at mel_rows + b *
+ * batch_stride (elements) -- e.g. `out + (F - 1) * C` with batch_stride N * C decodes frames F-1.. of lemas_dit_sample's `out` in
+ * place, which is what the reference's `vocoder.decode(generated[:, F-1:, :].permute(0, 2, 1))` computes after its permute copy
+ * (lemas_tts/infer/utils_infer.py:546-549) */
+int lemas_vocos_decode_rows(lemas_vocos* v, const float* mel_rows, int32_t batch, int32_t frames, int64_t batch_stride, float gain, float* wav,
+                            void* stream);
+/* options: "graph" (1 = the backbone + head of a decode shape seen twice is replayed as one hipGraph, default 1), "graph_cache" (decode
+ * shapes kept, least recently used evicted; default 8) */
+int lemas_vocos_set_option(lemas_vocos* v, const char* key, int64_t value);
 
 /* ---- reference wav -> log-mel front edge (lemas_tts/model/modules.py:75-143 MelSpec, call site cfm.py:232-236) ----
  * wav device [B, samples] fp32 at `sample_rate` -> mel device [B, samples/hop + 1, n_mels] fp32 (already in the

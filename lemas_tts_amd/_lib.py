@@ -15,6 +15,7 @@ TEST_LIB_PATH = os.path.join(_HERE, "lib", "liblemas_hip_test.so")
 
 _lib = None
 _testlib = None
+ABI_VERSION = 200          # include/lemas_hip.h: lemas_sample_args opens with struct_size
 
 
 class DitConfig(C.Structure):
@@ -31,13 +32,18 @@ class ProsodyConfig(C.Structure):
 
 class SampleArgs(C.Structure):
     _fields_ = [
+        ("struct_size", C.c_uint32),
         ("batch", C.c_int32), ("frames", C.c_int32), ("cond_frames", C.c_int32), ("text_len", C.c_int32),
         ("steps", C.c_int32), ("cfg_strength", C.c_float),
         ("cond", C.c_void_p), ("cond_mask", C.c_void_p), ("text", C.c_void_p), ("seq_len", C.c_void_p),
         ("prosody", C.c_void_p), ("t_grid", C.POINTER(C.c_float)),
         ("y", C.c_void_p), ("out", C.c_void_p), ("trajectory", C.c_void_p), ("step_cond", C.c_void_p),
-        ("prosody_text_only", C.c_int32),
+        ("prosody_text_only", C.c_int32), ("cond_rows", C.c_int32), ("y_init", C.c_void_p),
     ]
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.struct_size = C.sizeof(SampleArgs)      # ABI 200: checked by the library
 
 
 class LemasError(RuntimeError):
@@ -61,6 +67,10 @@ def lib():
         raise LemasError(f"{LIB_PATH} is missing: build it with `python -m lemas_tts_amd.build` "
                          "(there is no CPU fallback for the acoustic path)")
     L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)      # the test library resolves its references against this one
+    L.lemas_version.restype = C.c_int
+    if L.lemas_version() != ABI_VERSION:
+        raise LemasError(f"{LIB_PATH} reports ABI {L.lemas_version()}, this binding is written against {ABI_VERSION}: rebuild with "
+                         "`python -m lemas_tts_amd.build --force`")
     vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
     sig = {
         "lemas_last_error": (C.c_char_p, []),
@@ -72,6 +82,7 @@ def lib():
         "lemas_dit_finalize": (C.c_int, [vp]),
         "lemas_dit_set_option": (C.c_int, [vp, C.c_char_p, i64]),
         "lemas_dit_health": (C.c_int, [vp]),
+        "lemas_dit_get_stat": (C.c_int, [vp, C.c_char_p, C.POINTER(i64)]),
         "lemas_dit_sample": (C.c_int, [vp, C.POINTER(SampleArgs), vp]),
         "lemas_dit_prepare": (C.c_int, [vp, C.POINTER(SampleArgs), vp]),
         "lemas_dit_solve": (C.c_int, [vp, C.POINTER(SampleArgs), vp]),
@@ -83,6 +94,8 @@ def lib():
         "lemas_vocos_load_weight_device": (C.c_int, [vp, C.c_char_p, vp, C.POINTER(i64), i32]),
         "lemas_vocos_finalize": (C.c_int, [vp]),
         "lemas_vocos_decode": (C.c_int, [vp, vp, i32, i32, f32, vp, vp]),
+        "lemas_vocos_decode_rows": (C.c_int, [vp, vp, i32, i32, i64, f32, vp, vp]),
+        "lemas_vocos_set_option": (C.c_int, [vp, C.c_char_p, i64]),
         "lemas_mel_create": (C.c_int, [i32, i32, i32, i32, C.POINTER(vp)]),
         "lemas_mel_destroy": (None, [vp]),
         "lemas_mel_forward": (C.c_int, [vp, vp, i32, i32, vp, vp]),
@@ -155,9 +168,9 @@ def testlib():
 
 EXPORTED = [      # include/lemas_hip.h: the product library
     "lemas_last_error", "lemas_version", "lemas_dit_create", "lemas_dit_destroy", "lemas_dit_load_weight", "lemas_dit_load_weight_device", "lemas_vocos_load_weight_device",
-    "lemas_dit_finalize", "lemas_dit_set_option", "lemas_dit_health", "lemas_dit_sample", "lemas_dit_prepare", "lemas_dit_solve",
+    "lemas_dit_finalize", "lemas_dit_set_option", "lemas_dit_get_stat", "lemas_dit_health", "lemas_dit_sample", "lemas_dit_prepare", "lemas_dit_solve",
     "lemas_dit_forward", "lemas_dit_profile_read", "lemas_vocos_create", "lemas_vocos_destroy",
-    "lemas_vocos_load_weight", "lemas_vocos_finalize", "lemas_vocos_decode", "lemas_mel_create", "lemas_mel_destroy",
+    "lemas_vocos_load_weight", "lemas_vocos_finalize", "lemas_vocos_decode", "lemas_vocos_decode_rows", "lemas_vocos_set_option", "lemas_mel_create", "lemas_mel_destroy",
     "lemas_mel_forward", "lemas_resample_create", "lemas_resample_destroy", "lemas_resample_out_len", "lemas_resample_forward",
     "lemas_prosody_create", "lemas_prosody_destroy", "lemas_prosody_load_weight", "lemas_prosody_finalize", "lemas_prosody_fbank_frames",
     "lemas_prosody_fbank", "lemas_prosody_encode",

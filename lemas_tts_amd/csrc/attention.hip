@@ -534,6 +534,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
 }  // namespace
 
+bool attention_variant_ok(int v) {
+  if ((v & ATTN_Q64) != 0) return (v & ~(ATTN_Q64 | 16 | 3)) == 0 && (v & 16) != 0;
+  switch (v) {
+    case 0: case 1: case 2: case 3: case 4: case 5: case 7: case 17: case 19: case 17 + 1024: case 19 + 1024: return true;
+    default: return false;
+  }
+}
+
 hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
   // K rows are loaded up to the next multiple of 64 without clamping: the row pitch must cover them
   if (p.npad % 64 != 0 || p.n <= 0 || p.pitch < ((p.n + 63) & ~63) || p.npad < ((p.n + 63) & ~63)) return hipErrorInvalidValue;
@@ -544,12 +552,15 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
     if (p.ev_start) hipExtLaunchKernelGGL(attn_fwd_splitkv_kernel<V>, grid, dim3(512), 0, s, p.ev_start, p.ev_stop, 0, p);    \
     else hipLaunchKernelGGL(attn_fwd_splitkv_kernel<V>, grid, dim3(512), 0, s, p);                                             \
     break;
+  if ((p.variant & ATTN_Q64) != 0) return (p.variant & 16) != 0 ? launch_attention_q64(p, s) : hipErrorInvalidValue;
   switch (p.variant) {
     LEMAS_ATTN_LAUNCH(0) LEMAS_ATTN_LAUNCH(1) LEMAS_ATTN_LAUNCH(2) LEMAS_ATTN_LAUNCH(3) LEMAS_ATTN_LAUNCH(4) LEMAS_ATTN_LAUNCH(5)
-    LEMAS_ATTN_LAUNCH(7) LEMAS_ATTN_LAUNCH(8) LEMAS_ATTN_LAUNCH(10) LEMAS_ATTN_LAUNCH(17) LEMAS_ATTN_LAUNCH(19)
+    LEMAS_ATTN_LAUNCH(7) LEMAS_ATTN_LAUNCH(17) LEMAS_ATTN_LAUNCH(19) LEMAS_ATTN_LAUNCH(17 + 1024) LEMAS_ATTN_LAUNCH(19 + 1024)
+#ifdef LEMAS_PHASE_TIMESTAMPS      // measurement builds only: ablations (wrong results by construction) and the forms without a fallback pass
+    LEMAS_ATTN_LAUNCH(8) LEMAS_ATTN_LAUNCH(10)
     LEMAS_ATTN_LAUNCH(17 + 32) LEMAS_ATTN_LAUNCH(17 + 64) LEMAS_ATTN_LAUNCH(17 + 128) LEMAS_ATTN_LAUNCH(17 + 256) LEMAS_ATTN_LAUNCH(17 + 256 + 512)
-    LEMAS_ATTN_LAUNCH(17 + 128 + 256 + 512) LEMAS_ATTN_LAUNCH(17 + 1024) LEMAS_ATTN_LAUNCH(19 + 1024)
-    LEMAS_ATTN_LAUNCH(19 + 2048) LEMAS_ATTN_LAUNCH(19 + 1024 + 2048)      // 2048: MEASUREMENT ONLY, no fallback pass compiled in
+    LEMAS_ATTN_LAUNCH(17 + 128 + 256 + 512) LEMAS_ATTN_LAUNCH(19 + 2048) LEMAS_ATTN_LAUNCH(19 + 1024 + 2048)
+#endif
     default: return hipErrorInvalidValue;
   }
 #undef LEMAS_ATTN_LAUNCH

@@ -90,6 +90,58 @@ __global__ __launch_bounds__(256) void ln_affine_kernel(const float* __restrict_
   }
 }
 
+// ---- depthwise Conv1d k = 7 followed by the affine LayerNorm, one wave per row (the first two operations of a vocos ConvNeXtBlock): the
+// arithmetic of dwconv7_kernel and ln_affine_kernel, statement for statement, without the [rows, C] round trip between them
+template <int D>
+__global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                         const float* __restrict__ lnw, const float* __restrict__ lnb, float* __restrict__ out,
+                                                         int B, int N) {
+  constexpr int PER = D / 256;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= B * N) return;
+  const int lane = threadIdx.x & 63;
+  const int n = row % N;
+  float4 v[PER];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    float acc[4];
+    const float4 b4 = *reinterpret_cast<const float4*>(bias + c);
+    acc[0] = b4.x; acc[1] = b4.y; acc[2] = b4.z; acc[3] = b4.w;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const int nn = n + j - 3;
+      if (nn >= 0 && nn < N) {
+        const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)(row + j - 3) * D + c);
+        acc[0] = fmaf(w[(c + 0) * 7 + j], xv.x, acc[0]); acc[1] = fmaf(w[(c + 1) * 7 + j], xv.y, acc[1]);
+        acc[2] = fmaf(w[(c + 2) * 7 + j], xv.z, acc[2]); acc[3] = fmaf(w[(c + 3) * 7 + j], xv.w, acc[3]);
+      }
+    }
+    v[i] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    s += v[i].x + v[i].y + v[i].z + v[i].w;
+  }
+  const float mean = wave_sum(s) * (1.0f / D);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const float a = v[i].x - mean, bb = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+    q += a * a + bb * bb + c * c + d * d;
+  }
+  const float rstd = rsqrtf(wave_sum(q) * (1.0f / D) + 1e-6f);
+  float4* orow = reinterpret_cast<float4*>(out + (size_t)row * D);
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const float4 ww = reinterpret_cast<const float4*>(lnw)[lane + 64 * i], bv = reinterpret_cast<const float4*>(lnb)[lane + 64 * i];
+    float4 o;
+    o.x = (v[i].x - mean) * rstd * ww.x + bv.x;
+    o.y = (v[i].y - mean) * rstd * ww.y + bv.y;
+    o.z = (v[i].z - mean) * rstd * ww.z + bv.z;
+    o.w = (v[i].w - mean) * rstd * ww.w + bv.w;
+    orow[lane + 64 * i] = o;
+  }
+}
+
 // ---- GRN (modules.py:225-234): Gx[b,c] = ||x[b,:,c]||_2 over the SEQUENCE; Nx = Gx / (mean_c Gx + 1e-6);
 // out = gamma * (x * Nx) + beta + x.   Kernel 1: column norms; kernel 2: apply.
 // partial sums of squares: grid (C/64, B, GRN_SPLIT); chunk z covers rows z, z + GRN_SPLIT*4, ... (fixed order: deterministic)
@@ -163,14 +215,14 @@ __global__ void add_rowvec_kernel(float* __restrict__ x, const float* __restrict
 // conditioning setup (cfm.py:311-318,326-327,388-390): cond_eff = pad(cond) [+ Linear(pad(prosody))]; step_cond = mask ? cond_eff : 0
 __global__ void cond_prepare_kernel(const float* __restrict__ cond, const uint8_t* __restrict__ mask,
                                     const float* __restrict__ pm /*[B,100] W.e (no bias) or null*/,
-                                    const float* __restrict__ pbias, int B, int N, int F, int md,
+                                    const float* __restrict__ pbias, int B, int N, int F, int md, int crows /* rows per sample in cond */,
                                     float* __restrict__ cond_eff, float* __restrict__ step_cond) {
   const size_t total = (size_t)B * N * md;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % md);
     const size_t row = i / md;
     const int n = (int)(row % N), b = (int)(row / N);
-    float v = cond[i];
+    float v = n < crows ? cond[((size_t)b * crows + n) * md + c] : 0.f;      // rows past crows: the reference's zero right-padding (cfm.py:311)
     if (pm) v += (n < F ? pm[(size_t)b * md + c] : 0.f) + pbias[c];
     cond_eff[i] = v;
     step_cond[i] = mask[row] ? v : 0.f;
@@ -213,7 +265,9 @@ __global__ void silu_kernel(const float* __restrict__ x, float* __restrict__ out
 }
 
 // ---- Vocos: mel [B, C, L] -> im2col rows for Conv1d(C -> 512, k=7, pad=3): col[b*L+n][ci*7+j] = mel[b][ci][n+j-3]
-__global__ void im2col7_kernel(const float* __restrict__ mel, int B, int C, int L, float* __restrict__ col) {
+// mel element (b, ci, n) at mel[b * sb + ci * sc + n * sl]: [B, C, L] is (C L, L, 1); a frames-first slice [B][L][C] of the sampler's output is
+// (rows per sample * C, 1, C) -- the vocoder then reads the generated frames in place, no permute copy in between
+__global__ void im2col7_kernel(const float* __restrict__ mel, int B, int C, int L, long sb, long sc, long sl, float* __restrict__ col) {
   const int W = C * 7;
   const size_t total = (size_t)B * L * W;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -222,7 +276,7 @@ __global__ void im2col7_kernel(const float* __restrict__ mel, int B, int C, int 
     const int n = (int)(row % L), b = (int)(row / L);
     const int ci = k / 7, j = k - ci * 7;
     const int nn = n + j - 3;
-    col[i] = (nn >= 0 && nn < L) ? mel[((size_t)b * C + ci) * L + nn] : 0.f;
+    col[i] = (nn >= 0 && nn < L) ? mel[(long)b * sb + (long)ci * sc + (long)nn * sl] : 0.f;
   }
 }
 
@@ -319,8 +373,8 @@ hipError_t launch_add_rowvec(float* x, const float* vec, int BB, int B, int N, i
   LAUNCH(add_rowvec_kernel, (size_t)BB * N * C, x, vec, BB, B, N, C, nlim)
 }
 hipError_t launch_cond_prepare(const float* cond, const uint8_t* mask, const float* pm, const float* pbias, int B, int N,
-                               int F, int md, float* cond_eff, float* step_cond, hipStream_t s) {
-  LAUNCH(cond_prepare_kernel, (size_t)B * N * md, cond, mask, pm, pbias, B, N, F, md, cond_eff, step_cond)
+                               int F, int md, int crows, float* cond_eff, float* step_cond, hipStream_t s) {
+  LAUNCH(cond_prepare_kernel, (size_t)B * N * md, cond, mask, pm, pbias, B, N, F, md, crows, cond_eff, step_cond)
 }
 hipError_t launch_concat_ct(const float* step_cond, const float* te, int B, int N, int md, int td, int branches, int pitch,
                             float* ct, hipStream_t s) {
@@ -331,8 +385,14 @@ hipError_t launch_time_sinus(const float* t, const float* freqs, int S, int half
   return hipGetLastError();
 }
 hipError_t launch_silu(const float* x, float* out, size_t n, hipStream_t s) { LAUNCH(silu_kernel, n, x, out, n) }
-hipError_t launch_im2col7(const float* mel, int B, int C, int L, float* col, hipStream_t s) {
-  LAUNCH(im2col7_kernel, (size_t)B * L * C * 7, mel, B, C, L, col)
+hipError_t launch_im2col7(const float* mel, int B, int C, int L, long sb, long sc, long sl, float* col, hipStream_t s) {
+  LAUNCH(im2col7_kernel, (size_t)B * L * C * 7, mel, B, C, L, sb, sc, sl, col)
+}
+hipError_t launch_dwconv7_ln(const float* x, const float* w, const float* bias, const float* lnw, const float* lnb, float* out, int B, int N,
+                             int C, hipStream_t s) {
+  if (C != 512) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(dwconv7_ln_kernel<512>, dim3((B * N + 3) / 4), dim3(256), 0, s, x, w, bias, lnw, lnb, out, B, N);
+  return hipGetLastError();
 }
 hipError_t launch_spec(const float* head, int rows, int nb, int ldh, int lds_, float* spec, hipStream_t s) {
   LAUNCH(spec_kernel, (size_t)rows * nb, head, rows, nb, ldh, lds_, spec)

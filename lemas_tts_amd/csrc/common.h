@@ -199,6 +199,14 @@ struct AttnParams {
 #endif
 };
 hipError_t launch_attention(const AttnParams& p, hipStream_t s);
+// AttnParams::variant with this bit (and bit 16: q prescaled): the 64-queries-per-wave kernel of attention_q64.hip; bits 0-1 pick its
+// schedule (1 = blocks skewed, 2 = static priority for the younger half-workgroup)
+constexpr int ATTN_Q64 = 4096;
+hipError_t launch_attention_q64(const AttnParams& p, hipStream_t s);
+hipError_t attention_q64_init();
+// the variants a product engine may select (lemas_dit_set_option "attn_variant"); the measurement-only instantiations of attention.hip
+// (ablations, the no-fallback forms) exist in -DLEMAS_PHASE_TIMESTAMPS builds only
+bool attention_variant_ok(int variant);
 
 // out_bf16[m][c] = LN(x[m][:])[c] * (1 + scale[c]) + shift[c]; scale/shift read from the AdaLN table row of the current step
 hipError_t launch_ln_mod(const float* x, bf16_t* out, int M, int D, const float* tab, int tab_stride,

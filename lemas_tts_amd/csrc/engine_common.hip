@@ -33,6 +33,8 @@ int kernels_init() {
   if (done[dev]) return 0;
   const hipError_t err = gemm_bf16_init();
   if (err != hipSuccess) return hip_fail(err, "gemm_bf16_init()", __FILE__, __LINE__);
+  const hipError_t err2 = attention_q64_init();
+  if (err2 != hipSuccess) return hip_fail(err2, "attention_q64_init()", __FILE__, __LINE__);
   done[dev] = true;
   return 0;
 }
@@ -70,6 +72,9 @@ int WeightStore::load(const char* name, const float* src, const int64_t* shape, 
     HIP_TRY(zero_fill_sync(arena, total));
     arena_bytes = total;
   }
+  // a RE-load overwrites the slot in place: nothing of the owning engine may still be reading it (a decode / encode in flight on a
+  // non-blocking stream is not ordered against the NULL-stream copy below)
+  if (t.find(name) != t.end()) HIP_TRY(hipDeviceSynchronize());
   Tensor& x = t[name];
   x.dev = reinterpret_cast<float*>(arena + slot[name]);
   // synchronous on the NULL stream in both cases; a device source written on another stream must be complete before the call
@@ -101,5 +106,5 @@ void WeightStore::release() {
 
 extern "C" {
 const char* lemas_last_error(void) { return lemas::g_err; }
-int lemas_version(void) { return 100; }
+int lemas_version(void) { return 200; }   // 200: lemas_sample_args carries struct_size (include/lemas_hip.h)
 }

@@ -109,7 +109,19 @@ struct lemas_dit {
   int tab_stride = 0;
   int n_cus = 0;
 
-  std::map<std::string, hipGraphExec_t> graphs;
+  // Step graphs are cached per BUCKET: everything that fixes the graph's topology and buffer addresses (batch, the 128-row pitch of the
+  // activation row space, CFG / length / lane / precision switches).  The frame count N inside a bucket only changes kernel ARGUMENTS
+  // (mask bounds, valid rows), so a never-seen N in a seen bucket re-captures the launches (host work, ~1 ms) and patches one of the
+  // bucket's instantiated graphs in place with hipGraphExecUpdate instead of instantiating a new one.  A bucket holds up to two
+  // instantiated graphs, used alternately for new lengths, so that the one being patched is never the one still in flight (its last
+  // launch is fenced by an event).  Buckets are evicted least-recently-used beyond `graph_cap`.
+  struct StepGraph { hipGraphExec_t exec = nullptr; int N = 0; unsigned long long used = 0; hipEvent_t done = nullptr; };
+  struct GraphBucket { StepGraph g[2]; unsigned long long used = 0; };
+  std::map<std::string, GraphBucket> graphs;
+  unsigned long long graph_tick = 0;
+  int graph_cap = 16;                       // option "graph_cache": buckets kept (LRU)
+  bool graph_update = true;                 // option "graph_update": 0 = always instantiate (measurement)
+  long long n_capture = 0, n_instantiate = 0, n_update = 0, n_update_fail = 0, n_evict = 0;   // lemas_dit_get_stat
   unsigned long long moved = 1;             // bumped by this engine's DevBufs when one of them is (re)allocated
   unsigned long long graph_generation = 0;  // value of `moved` the cached graphs were captured under
 
@@ -126,10 +138,19 @@ struct lemas_dit {
   static std::vector<DevBuf*> block_bufs(BlockW& b) {
     return {&b.wqkv, &b.wo, &b.w1, &b.w2, &b.bqkv, &b.wqkv8, &b.wo8, &b.w18, &b.w28, &b.sqkv, &b.so, &b.s1, &b.s2, &b.wqkvq, &b.woq, &b.w1q, &b.w2q};
   }
+  static void drop_bucket(GraphBucket& b) {
+    for (auto& g : b.g) {
+      if (g.done) { (void)hipEventSynchronize(g.done); (void)hipEventDestroy(g.done); }
+      if (g.exec) (void)hipGraphExecDestroy(g.exec);
+      g = StepGraph{};
+    }
+  }
   void drop_graphs() {
-    for (auto& g : graphs) (void)hipGraphExecDestroy(g.second);
+    for (auto& b : graphs) drop_bucket(b.second);
     graphs.clear();
   }
+  int capture_step(hipStream_t s, hipGraph_t* out);
+  int step_graph(hipStream_t s, hipGraphExec_t* exec, hipEvent_t* done);
   lemas_dit() {
     for (DevBuf* b : own_bufs()) b->moved = &moved;
   }
@@ -449,8 +470,11 @@ int lemas_dit::build_tables(const lemas_sample_args* a, hipStream_t s) {
   }
   if (rope_n != a->frames) {
     const int half = cfg.dim_head / 2;
-    RC_TRY(d_rope_cos.ensure((size_t)a->frames * half * 4));
-    RC_TRY(d_rope_sin.ensure((size_t)a->frames * half * 4));
+    // sized by the 128-row bucket (as every per-shape buffer below): a new length inside a bucket must not move a buffer, which would
+    // invalidate the engine's cached step graphs
+    const size_t rope_rows = ((size_t)a->frames + 127) & ~(size_t)127;
+    RC_TRY(d_rope_cos.ensure(rope_rows * half * 4));
+    RC_TRY(d_rope_sin.ensure(rope_rows * half * 4));
     HIP_TRY(launch_rope_table(d_rope_cos.as<float>(), d_rope_sin.as<float>(), a->frames, half, ws.ptr(T("rotary_embed.inv_freq")), s));
     rope_n = a->frames;
   }
@@ -504,14 +528,15 @@ int lemas_dit::build_fold_tables(int Snew, hipStream_t s) {
 // TextEmbedding for both CFG branches (dit.py:51-81) + prosody text conditioning (dit.py:225-233)
 int lemas_dit::text_embed(const lemas_sample_args* a, hipStream_t s) {
   const int td = cfg.text_dim, rows = BB * N, branches = BB / B;
-  RC_TRY(d_te.ensure((size_t)rows * td * 4));
-  RC_TRY(d_rowmask.ensure((size_t)rows));
+  const size_t arows = (size_t)BB * pitch;        // allocation size: the bucket's rows (see build_tables)
+  RC_TRY(d_te.ensure(arows * td * 4));
+  RC_TRY(d_rowmask.ensure(arows));
   HIP_TRY(launch_text_gather(a->text, B, Nt, N, td, branches, ws.ptr(T("text_embed.text_embed.weight")), cfg.vocab_rows,
                              ws.ptr(T("text_embed.freqs_cis")), 4096, d_te.as<float>(), d_rowmask.as<uint8_t>(), s));
   if (cfg.conv_layers > 0) {
-    RC_TRY(d_t1.ensure((size_t)rows * td * 4));
-    RC_TRY(d_t2.ensure((size_t)rows * td * 4));
-    RC_TRY(d_t3.ensure((size_t)rows * 2 * td * 4));
+    RC_TRY(d_t1.ensure(arows * td * 4));
+    RC_TRY(d_t2.ensure(arows * td * 4));
+    RC_TRY(d_t3.ensure(arows * 2 * td * 4));
     RC_TRY(d_gx.ensure((size_t)BB * 16 * 2 * td * 4));   // [BB][GRN_SPLIT = 16][2 td] partial sums of squares
     for (int i = 0; i < cfg.conv_layers; ++i) {
       const std::string p = T("text_embed.text_blocks." + std::to_string(i) + ".");
@@ -544,6 +569,12 @@ int lemas_dit::text_embed(const lemas_sample_args* a, hipStream_t s) {
 int lemas_dit::prepare(const lemas_sample_args* a, hipStream_t s) {
   if (!finalized) { set_error("lemas_dit_prepare: weights not finalized"); return LEMAS_E_STATE; }
   RC_TRY(health());
+  if (a->struct_size != sizeof(lemas_sample_args)) {
+    set_error("lemas_dit_prepare: lemas_sample_args.struct_size is %u, this library (ABI %d) expects %zu -- set struct_size = sizeof(lemas_sample_args) "
+              "and rebuild the client against include/lemas_hip.h", a->struct_size, lemas_version(), sizeof(lemas_sample_args));
+    return LEMAS_E_ARG;
+  }
+  if (a->cond_rows < 0 || a->cond_rows > a->frames) { set_error("lemas_dit_prepare: cond_rows %d outside [0, frames = %d]", a->cond_rows, a->frames); return LEMAS_E_ARG; }
   if (a->batch <= 0 || a->frames <= 0 || a->frames > 4096 || a->steps <= 0 || a->text_len <= 0 || !a->cond || !a->cond_mask ||
       !a->text || !a->t_grid || a->cond_frames <= 0 || a->cond_frames > a->frames) {
     set_error("lemas_dit_prepare: bad arguments (B=%d N=%d F=%d Nt=%d S=%d)", a->batch, a->frames, a->cond_frames, a->text_len, a->steps);
@@ -574,8 +605,8 @@ int lemas_dit::prepare(const lemas_sample_args* a, hipStream_t s) {
     HIP_TRY(hipMemcpyAsync(d_len.p, a->seq_len, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
   }
   // conditioning
-  RC_TRY(d_cond_eff.ensure((size_t)B * N * md * 4));
-  RC_TRY(d_step_cond.ensure((size_t)B * N * md * 4));
+  RC_TRY(d_cond_eff.ensure((size_t)B * pitch * md * 4));
+  RC_TRY(d_step_cond.ensure((size_t)B * pitch * md * 4));
   const float* pm = nullptr;
   if (a->prosody && cfg.has_prosody && !a->prosody_text_only) {   // text-only: cond is final as given (cfm.py:320-324 overwrote the shifted mel)
     RC_TRY(d_pm.ensure((size_t)B * md * 4));
@@ -585,11 +616,12 @@ int lemas_dit::prepare(const lemas_sample_args* a, hipStream_t s) {
     HIP_TRY(launch_gemm_f32(F32_BIAS, g, s));
     pm = d_pm.as<float>();
   }
-  HIP_TRY(launch_cond_prepare(a->cond, a->cond_mask, pm, pm ? ws.ptr("prosody_to_mel.bias") : nullptr, B, N, F, md,
+  const int crows = a->cond_rows > 0 ? a->cond_rows : N;
+  HIP_TRY(launch_cond_prepare(a->cond, a->cond_mask, pm, pm ? ws.ptr("prosody_to_mel.bias") : nullptr, B, N, F, md, crows,
                               d_cond_eff.as<float>(), d_step_cond.as<float>(), s));
   if (a->step_cond) {   // accent-GRL conditioning: step_cond = where(cond_mask, cond_grl, 0)  (cfm.py:387-388)
-    RC_TRY(d_t1.ensure((size_t)B * N * md * 4));
-    HIP_TRY(launch_cond_prepare(a->step_cond, a->cond_mask, nullptr, nullptr, B, N, F, md, d_t1.as<float>(), d_step_cond.as<float>(), s));
+    RC_TRY(d_t1.ensure((size_t)B * pitch * md * 4));
+    HIP_TRY(launch_cond_prepare(a->step_cond, a->cond_mask, nullptr, nullptr, B, N, F, md, crows, d_t1.as<float>(), d_step_cond.as<float>(), s));
   }
   RC_TRY(text_embed(a, s));
   // hoisted [cond | text] part of the input projection
@@ -911,15 +943,89 @@ int lemas_dit::enqueue_update(float* traj, hipStream_t s) {
   return 0;
 }
 
+// one ODE step (DiT forward of both CFG branches + CFG / clamp / Euler update) captured from stream s
+int lemas_dit::capture_step(hipStream_t s, hipGraph_t* out) {
+  hipGraph_t graph = nullptr;
+  HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+  int rc = enqueue_forward(s);
+  if (rc == 0) rc = enqueue_update(nullptr, s);
+  hipError_t e = hipStreamEndCapture(s, &graph);
+  if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+  HIP_TRY(e);
+  ++n_capture;
+  *out = graph;
+  return 0;
+}
+
+// the instantiated step graph for the prepared shape (see the cache's comment in the struct)
+int lemas_dit::step_graph(hipStream_t s, hipGraphExec_t* exec, hipEvent_t* done) {
+  if (graph_generation != moved) {  // one of THIS engine's buffers moved: every captured address is suspect
+    drop_graphs();
+    graph_generation = moved;
+  }
+  char key[112];
+  snprintf(key, sizeof key, "B%d_P%d_cfg%d_len%d_dual%d_f8%d_ln%d_av%d", B, pitch, (int)use_cfg, (int)has_len, (int)dual, fp8 ? 1 : fp8_wonly ? 2 : 0,
+           (int)ln_fused + 2 * (int)fold_on(), attn_variant);
+  auto it = graphs.find(key);
+  if (it == graphs.end()) {
+    while ((int)graphs.size() >= (graph_cap > 0 ? graph_cap : 1)) {       // evict the least recently used bucket
+      auto lru = graphs.begin();
+      for (auto j = graphs.begin(); j != graphs.end(); ++j)
+        if (j->second.used < lru->second.used) lru = j;
+      drop_bucket(lru->second);
+      graphs.erase(lru);
+      ++n_evict;
+    }
+    it = graphs.emplace(key, GraphBucket{}).first;
+  }
+  GraphBucket& b = it->second;
+  b.used = ++graph_tick;
+  StepGraph* g = nullptr;
+  for (auto& c : b.g)
+    if (c.exec && c.N == N) g = &c;
+  if (!g) {
+    // an empty slot first (the bucket's second instantiated graph costs one instantiate, once), else the slot used longer ago
+    g = !b.g[0].exec ? &b.g[0] : !b.g[1].exec ? &b.g[1] : (b.g[0].used <= b.g[1].used ? &b.g[0] : &b.g[1]);
+    hipGraph_t graph = nullptr;
+    RC_TRY(capture_step(s, &graph));
+    bool patched = false;
+    if (g->exec && graph_update) {
+      HIP_TRY(hipEventSynchronize(g->done));          // its last launch (two lengths ago in this bucket) has long finished
+      hipGraphNode_t bad = nullptr;
+      hipGraphExecUpdateResult res = hipGraphExecUpdateError;
+      patched = hipGraphExecUpdate(g->exec, graph, &bad, &res) == hipSuccess && res == hipGraphExecUpdateSuccess;
+      if (patched) ++n_update;
+      else { (void)hipGetLastError(); ++n_update_fail; }
+    }
+    if (!patched) {
+      if (g->exec) { HIP_TRY(hipEventSynchronize(g->done)); (void)hipGraphExecDestroy(g->exec); g->exec = nullptr; }
+      hipGraphExec_t ex = nullptr;
+      hipError_t e = hipGraphInstantiate(&ex, graph, nullptr, nullptr, 0);
+      if (e != hipSuccess) { (void)hipGraphDestroy(graph); HIP_TRY(e); }
+      g->exec = ex;
+      ++n_instantiate;
+    }
+    HIP_TRY(hipGraphDestroy(graph));
+    if (!g->done) HIP_TRY(hipEventCreateWithFlags(&g->done, hipEventDisableTiming));
+    g->N = N;
+  }
+  g->used = graph_tick;
+  *exec = g->exec;
+  *done = g->done;
+  return 0;
+}
+
 int lemas_dit::solve(const lemas_sample_args* a, hipStream_t s) {
   if (!finalized || !prepared) { set_error("lemas_dit_solve: prepare() has not run on the finalized weights"); return LEMAS_E_STATE; }
   RC_TRY(health());
+  if (a->struct_size != sizeof(lemas_sample_args)) { set_error("lemas_dit_solve: lemas_sample_args.struct_size mismatch (see lemas_dit_prepare)"); return LEMAS_E_ARG; }
   if (a->batch != B || a->frames != N || a->steps != S || !a->y) { set_error("lemas_dit_solve: arguments differ from prepare()"); return LEMAS_E_ARG; }
+  const float* y_src = a->y_init ? a->y_init : a->y;
   const size_t ybytes = (size_t)B * N * cfg.mel_dim * 4;
   const size_t yw = (size_t)N * cfg.mel_dim * 4, ypitch = (size_t)pitch * cfg.mel_dim * 4;
   HIP_TRY(hipMemsetAsync(d_y.p, 0, (size_t)B * ypitch, s));   // padding rows restart from 0 every utterance
-  HIP_TRY(hipMemcpy2DAsync(d_y.p, ypitch, a->y, yw, yw, B, hipMemcpyDeviceToDevice, s));
-  if (a->trajectory) HIP_TRY(hipMemcpyAsync(a->trajectory, a->y, ybytes, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipMemcpy2DAsync(d_y.p, ypitch, y_src, yw, yw, B, hipMemcpyDeviceToDevice, s));
+  if (a->trajectory) HIP_TRY(hipMemcpyAsync(a->trajectory, y_src, ybytes, hipMemcpyDeviceToDevice, s));
   HIP_TRY(launch_step_set(d_step.as<int>(), 0, s));
 
   const bool graph_ok = use_graph && !profile && !a->trajectory && s != nullptr;  // the legacy NULL stream cannot be captured
@@ -928,24 +1034,11 @@ int lemas_dit::solve(const lemas_sample_args* a, hipStream_t s) {
       drop_graphs();
       graph_generation = moved;
     }
-    char key[96];
-    snprintf(key, sizeof key, "B%d_N%d_cfg%d_len%d_dual%d_f8%d_ln%d", B, N, (int)use_cfg, (int)has_len, (int)dual, fp8 ? 1 : fp8_wonly ? 2 : 0, (int)ln_fused + 2 * (int)fold_on());
-    auto it = graphs.find(key);
-    if (it == graphs.end()) {
-      if (graphs.size() >= 32) drop_graphs();   // a serving process sees a new length almost every utterance: bound the cache (a capture costs ~3 ms)
-      hipGraph_t graph = nullptr;
-      HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-      int rc = enqueue_forward(s);
-      if (rc == 0) rc = enqueue_update(nullptr, s);
-      hipError_t e = hipStreamEndCapture(s, &graph);
-      if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-      HIP_TRY(e);
-      hipGraphExec_t exec = nullptr;
-      HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-      HIP_TRY(hipGraphDestroy(graph));
-      it = graphs.emplace(key, exec).first;
-    }
-    for (int k = 0; k < S; ++k) HIP_TRY(hipGraphLaunch(it->second, s));
+    hipGraphExec_t exec = nullptr;
+    hipEvent_t done = nullptr;
+    RC_TRY(step_graph(s, &exec, &done));
+    for (int k = 0; k < S; ++k) HIP_TRY(hipGraphLaunch(exec, s));
+    HIP_TRY(hipEventRecord(done, s));
   } else {
     for (int k = 0; k < S; ++k) {
       RC_TRY(enqueue_forward(s));
@@ -1016,6 +1109,11 @@ int lemas_dit_set_option(lemas_dit* m, const char* key, int64_t value) {
               : !strcmp(key, "tile_qkv") ? &m->opt_tile_qkv : !strcmp(key, "xcd_gx") ? &m->opt_xcd_gx
               : !strcmp(key, "attn_variant") ? &m->attn_variant : !strcmp(key, "lane_skew") ? &m->lane_skew : nullptr;
     if (slot) {
+      if (slot == &m->attn_variant && !attention_variant_ok((int)value)) {
+        set_error("lemas_dit_set_option: attn_variant %lld is not a product variant (csrc/attention.hip; measurement-only variants exist in "
+                  "-DLEMAS_PHASE_TIMESTAMPS builds of the test library only)", (long long)value);
+        return LEMAS_E_ARG;
+      }
       *slot = (int)value;
       m->drop_graphs();     // a captured graph baked the kernels of the old choice
       return 0;
@@ -1040,6 +1138,12 @@ int lemas_dit_set_option(lemas_dit* m, const char* key, int64_t value) {
     m->fp8_wonly = value == 2;
     return 0;
   }
+  if (!strcmp(key, "graph_cache")) {
+    if (value < 1 || value > 1024) { set_error("lemas_dit_set_option: graph_cache is the number of step-graph buckets kept, 1 .. 1024"); return LEMAS_E_ARG; }
+    m->graph_cap = (int)value;
+    return 0;
+  }
+  if (!strcmp(key, "graph_update")) { m->graph_update = value != 0; return 0; }
   if (!strcmp(key, "profile")) {
     m->profile = value != 0;
     for (auto& r : m->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -1047,6 +1151,18 @@ int lemas_dit_set_option(lemas_dit* m, const char* key, int64_t value) {
     return 0;
   }
   set_error("lemas_dit_set_option: unknown option '%s'", key);
+  return LEMAS_E_ARG;
+}
+
+int lemas_dit_get_stat(lemas_dit* m, const char* key, int64_t* value) {
+  if (!m || !key || !value) return LEMAS_E_ARG;
+  if (!strcmp(key, "graph_captures")) { *value = m->n_capture; return 0; }
+  if (!strcmp(key, "graph_instantiates")) { *value = m->n_instantiate; return 0; }
+  if (!strcmp(key, "graph_updates")) { *value = m->n_update; return 0; }
+  if (!strcmp(key, "graph_update_failures")) { *value = m->n_update_fail; return 0; }
+  if (!strcmp(key, "graph_evictions")) { *value = m->n_evict; return 0; }
+  if (!strcmp(key, "graph_buckets")) { *value = (int64_t)m->graphs.size(); return 0; }
+  set_error("lemas_dit_get_stat: unknown counter '%s'", key);
   return LEMAS_E_ARG;
 }
 

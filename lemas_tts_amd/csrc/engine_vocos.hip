@@ -6,6 +6,7 @@
 //   ISTFT                      = head GEMM -> (mag, phase) -> spectrum -> windowed inverse-rDFT as a GEMM against a
 //                                precomputed [1024 x 1026] basis -> overlap-add / window-envelope normalisation.
 #include <cstring>
+#include <utility>
 
 #include "engine_common.h"
 
@@ -18,8 +19,27 @@ struct lemas_vocos {
   DevBuf basis;  // [nfft][ldk]
   int ldk = 0;
   DevBuf d_col, d_a, d_b, d_c, d_mid, d_head, d_spec, d_frames;
+  // The backbone + head (everything between the im2col of the caller's mel and the overlap-add into the caller's waveform: ~36 launches on
+  // the engine's own buffers) is replayed as ONE hipGraph per (batch, frames) shape.  A shape is captured the SECOND time it is seen (a
+  // serving process decodes a different length almost every utterance: a capture costs about what the decode does); at most `graph_cap`
+  // shapes are kept, least recently used evicted; a (re)allocated workspace or reloaded weight drops them all.
+  struct Slot { hipGraphExec_t exec = nullptr; unsigned long long used = 0; int seen = 0; };
+  std::map<std::pair<int, int>, Slot> graphs;
+  unsigned long long tick = 0, moved = 1, generation = 0;
+  int graph_cap = 8;
+  bool use_graph = true;
 
+  lemas_vocos() {
+    for (DevBuf* b : {&basis, &d_col, &d_a, &d_b, &d_c, &d_mid, &d_head, &d_spec, &d_frames}) b->moved = &moved;
+  }
+  void drop_graphs() {
+    for (auto& g : graphs)
+      if (g.second.exec) (void)hipGraphExecDestroy(g.second.exec);
+    graphs.clear();
+  }
   ~lemas_vocos() {
+    (void)hipDeviceSynchronize();
+    drop_graphs();
     for (DevBuf* b : {&basis, &d_col, &d_a, &d_b, &d_c, &d_mid, &d_head, &d_spec, &d_frames}) b->release();
     ws.release();
   }
@@ -49,6 +69,8 @@ struct lemas_vocos {
   int finalize() {
     RC_TRY(ws.check_complete());
     if (dim != 512) { set_error("lemas_vocos: LayerNorm kernel is specialised for dim 512"); return LEMAS_E_ARG; }
+    HIP_TRY(hipDeviceSynchronize());
+    drop_graphs();
     ldk = ((nfft + 2) + 3) & ~3;
     RC_TRY(basis.ensure((size_t)nfft * ldk * 4));
     HIP_TRY(launch_dft_basis(ws.ptr("head.istft.window"), nfft, ldk, basis.as<float>(), nullptr));
@@ -56,21 +78,10 @@ struct lemas_vocos {
     finalized = true;
     return 0;
   }
-  int decode(const float* mel, int B, int L, float gain, float* wav, hipStream_t s) {
-    if (!finalized) { set_error("lemas_vocos_decode: weights not finalized"); return LEMAS_E_STATE; }
-    if (B <= 0 || L < 2 || !mel || !wav) { set_error("lemas_vocos_decode: bad arguments (B=%d L=%d)", B, L); return LEMAS_E_ARG; }
+  // d_col (im2col of the mel) -> d_frames (windowed inverse-rDFT frames): the part of a decode that only touches the engine's buffers
+  int body(int B, int L, hipStream_t s) {
     const int rows = B * L, kcol = C * 7;
-    RC_TRY(d_col.ensure((size_t)rows * kcol * 4));
-    RC_TRY(d_a.ensure((size_t)rows * dim * 4));
-    RC_TRY(d_b.ensure((size_t)rows * dim * 4));
-    RC_TRY(d_c.ensure((size_t)rows * dim * 4));
-    RC_TRY(d_mid.ensure((size_t)rows * idim * 4));
-    RC_TRY(d_head.ensure((size_t)rows * (nfft + 2) * 4));
-    RC_TRY(d_spec.ensure((size_t)rows * ldk * 4));
-    RC_TRY(d_frames.ensure((size_t)rows * nfft * 4));
     float *xa = d_a.as<float>(), *xb = d_b.as<float>(), *xc = d_c.as<float>();
-
-    HIP_TRY(launch_im2col7(mel, B, C, L, d_col.as<float>(), s));
     GemmF32Params g{};
     g.A = d_col.as<float>(); g.lda = kcol; g.W = ws.ptr("backbone.embed.weight"); g.ldw = kcol; g.bias = ws.ptr("backbone.embed.bias");
     g.out = xb; g.ldc = dim; g.M = rows; g.N = dim; g.K = kcol;
@@ -78,8 +89,9 @@ struct lemas_vocos {
     HIP_TRY(launch_ln_affine(xb, ws.ptr("backbone.norm.weight"), ws.ptr("backbone.norm.bias"), xa, rows, dim, s));
     for (int i = 0; i < layers; ++i) {
       const std::string p = "backbone.convnext." + std::to_string(i) + ".";
-      HIP_TRY(launch_dwconv7(xa, ws.ptr(p + "dwconv.weight"), ws.ptr(p + "dwconv.bias"), xb, B, L, dim, s));
-      HIP_TRY(launch_ln_affine(xb, ws.ptr(p + "norm.weight"), ws.ptr(p + "norm.bias"), xc, rows, dim, s));
+      // dwconv -> LayerNorm in one launch (round 4; same statements, no [rows, 512] round trip)
+      HIP_TRY(launch_dwconv7_ln(xa, ws.ptr(p + "dwconv.weight"), ws.ptr(p + "dwconv.bias"), ws.ptr(p + "norm.weight"), ws.ptr(p + "norm.bias"), xc, B, L,
+                                dim, s));
       GemmF32Params g1{};
       g1.A = xc; g1.lda = dim; g1.W = ws.ptr(p + "pwconv1.weight"); g1.ldw = dim; g1.bias = ws.ptr(p + "pwconv1.bias");
       g1.out = d_mid.as<float>(); g1.ldc = idim; g1.M = rows; g1.N = idim; g1.K = dim;
@@ -99,6 +111,50 @@ struct lemas_vocos {
     gd.A = d_spec.as<float>(); gd.lda = ldk; gd.W = basis.as<float>(); gd.ldw = ldk; gd.bias = nullptr;
     gd.out = d_frames.as<float>(); gd.ldc = nfft; gd.M = rows; gd.N = nfft; gd.K = ldk;
     HIP_TRY(launch_gemm_f32(F32_BIAS, gd, s));
+    return 0;
+  }
+  // mel element (b, c, n) at mel[b * sb + c * sc + n * sl]
+  int decode(const float* mel, long sb, long sc, long sl, int B, int L, float gain, float* wav, hipStream_t s) {
+    if (!finalized) { set_error("lemas_vocos_decode: weights not finalized"); return LEMAS_E_STATE; }
+    if (B <= 0 || L < 2 || !mel || !wav) { set_error("lemas_vocos_decode: bad arguments (B=%d L=%d)", B, L); return LEMAS_E_ARG; }
+    const int rows = B * L, kcol = C * 7;
+    RC_TRY(d_col.ensure((size_t)rows * kcol * 4));
+    RC_TRY(d_a.ensure((size_t)rows * dim * 4));
+    RC_TRY(d_b.ensure((size_t)rows * dim * 4));
+    RC_TRY(d_c.ensure((size_t)rows * dim * 4));
+    RC_TRY(d_mid.ensure((size_t)rows * idim * 4));
+    RC_TRY(d_head.ensure((size_t)rows * (nfft + 2) * 4));
+    RC_TRY(d_spec.ensure((size_t)rows * ldk * 4));
+    RC_TRY(d_frames.ensure((size_t)rows * nfft * 4));
+    if (generation != moved) { drop_graphs(); generation = moved; }     // a workspace moved: every captured address is stale
+
+    HIP_TRY(launch_im2col7(mel, B, C, L, sb, sc, sl, d_col.as<float>(), s));
+    hipGraphExec_t exec = nullptr;
+    if (use_graph && s != nullptr) {               // the legacy NULL stream cannot be captured
+      Slot& slot = graphs[{B, L}];
+      slot.used = ++tick;
+      if (!slot.exec && ++slot.seen >= 2) {
+        hipGraph_t graph = nullptr;
+        HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        const int rc = body(B, L, s);
+        const hipError_t e = hipStreamEndCapture(s, &graph);
+        if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        HIP_TRY(e);
+        const hipError_t ei = hipGraphInstantiate(&slot.exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        HIP_TRY(ei);
+      }
+      exec = slot.exec;
+      while ((int)graphs.size() > graph_cap) {     // evict the least recently used shape (never the one just touched)
+        auto lru = graphs.begin();
+        for (auto j = graphs.begin(); j != graphs.end(); ++j)
+          if (j->second.used < lru->second.used) lru = j;
+        if (lru->second.exec) { HIP_TRY(hipStreamSynchronize(s)); (void)hipGraphExecDestroy(lru->second.exec); }
+        graphs.erase(lru);
+      }
+    }
+    if (exec) HIP_TRY(hipGraphLaunch(exec, s));
+    else RC_TRY(body(B, L, s));
     HIP_TRY(launch_overlap_add(d_frames.as<float>(), ws.ptr("head.istft.window"), B, L, nfft, hop, wav, s));
     if (gain != 1.0f) HIP_TRY(launch_scale(wav, gain, (size_t)B * hop * (L - 1), s));
     return 0;
@@ -126,7 +182,9 @@ void lemas_vocos_destroy(lemas_vocos* v) { delete v; }
 static int vocos_load(lemas_vocos* v, const char* name, const float* src, const int64_t* shape, int32_t ndim, bool on_device) {
   if (!v || !name || !src) return LEMAS_E_ARG;
   if (strncmp(name, "feature_extractor.", 18) == 0) return 0;  // mel front-end of the vocos checkpoint: not used by decode
+  if (v->finalized || !v->graphs.empty()) HIP_TRY(hipDeviceSynchronize());   // a reload while a decode is in flight: wait before touching what it uses
   v->finalized = false;
+  v->drop_graphs();                                // captured launches baked this tensor's address
   return v->ws.load(name, src, shape, ndim, on_device);
 }
 int lemas_vocos_load_weight(lemas_vocos* v, const char* name, const float* host, const int64_t* shape, int32_t ndim) {
@@ -138,7 +196,24 @@ int lemas_vocos_load_weight_device(lemas_vocos* v, const char* name, const float
 int lemas_vocos_finalize(lemas_vocos* v) { return v ? v->finalize() : LEMAS_E_ARG; }
 int lemas_vocos_decode(lemas_vocos* v, const float* mel, int32_t batch, int32_t frames, float gain, float* wav, void* stream) {
   if (!v) return LEMAS_E_ARG;
-  return v->decode(mel, batch, frames, gain, wav, (hipStream_t)stream);
+  return v->decode(mel, (long)v->C * frames, frames, 1, batch, frames, gain, wav, (hipStream_t)stream);
+}
+int lemas_vocos_decode_rows(lemas_vocos* v, const float* mel_rows, int32_t batch, int32_t frames, int64_t batch_stride, float gain, float* wav,
+                            void* stream) {
+  if (!v) return LEMAS_E_ARG;
+  if (batch_stride < (int64_t)v->C * frames && batch > 1) { set_error("lemas_vocos_decode_rows: batch_stride %lld is smaller than frames * channels", (long long)batch_stride); return LEMAS_E_ARG; }
+  return v->decode(mel_rows, (long)batch_stride, 1, v->C, batch, frames, gain, wav, (hipStream_t)stream);
+}
+int lemas_vocos_set_option(lemas_vocos* v, const char* key, int64_t value) {
+  if (!v || !key) return LEMAS_E_ARG;
+  if (!strcmp(key, "graph")) { v->use_graph = value != 0; return 0; }
+  if (!strcmp(key, "graph_cache")) {
+    if (value < 1 || value > 1024) { set_error("lemas_vocos_set_option: graph_cache is the number of decode shapes kept, 1 .. 1024"); return LEMAS_E_ARG; }
+    v->graph_cap = (int)value;
+    return 0;
+  }
+  set_error("lemas_vocos_set_option: unknown option '%s'", key);
+  return LEMAS_E_ARG;
 }
 
 }  // extern "C"

@@ -719,8 +719,10 @@ __device__ __forceinline__ void ln_wait_row(u32x4 (&v)[LN_PER][2]) {
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0][0]), "+v"(v[0][1]), "+v"(v[1][0]), "+v"(v[1][1]) : : "memory");
 }
 
+// The option needs the device to itself: the co-residency estimate that enables it (engine_dit.hip: lanes x workgroups <= CUs x workgroups
+// per CU) knows nothing of other tenants (a second process sharing the GPU, CU masks, a side-stream kernel holding CUs).  It is off by default.
 template <int TBM, int TBN, int NW>
-__device__ __forceinline__ void ln_tail(const GemmParams& p, int m0, int n0) {
+__device__ __forceinline__ void ln_tail(const GemmParams& p, int m0, int n0, char* ln_lds) {
   constexpr int TILES_N = LN_D / TBN, R = TBM / TILES_N, RW = R / NW;
   static_assert(TILES_N * TBN == LN_D && R * TILES_N == TBM && RW * NW == R && RW >= 1, "rows of a panel must divide over its workgroups and waves");
   constexpr int ROWS = RW >= 2 ? 2 : 1;     // rows in flight per wave (as the stand-alone kernel)
@@ -737,17 +739,24 @@ __device__ __forceinline__ void ln_tail(const GemmParams& p, int m0, int n0) {
   float4 a[LN_PER][2], b[LN_PER][2];
   ln_load_vec(base + p.ln_scale_off, lane, a);
   ln_load_vec(base + p.ln_shift_off, lane, b);
+  // `gave_up` travels through LDS (the ring is free by now): a workgroup whose wait timed out must NOT normalise rows of a panel that is
+  // incomplete -- it flags the engine (sticky, host-visible) and leaves ln_out alone
+  int* gave_up = reinterpret_cast<int*>(ln_lds);
   if (tid == 0) {
     unsigned spins = 0;
+    int fail = 0;
     while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)TILES_N) {
       __builtin_amdgcn_s_sleep(8);
       if (++spins > (1u << 16)) {
         __hip_atomic_store((gu32*)p.ln_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        fail = 1;
         break;
       }
     }
+    *gave_up = fail;
   }
   __syncthreads();
+  if (*gave_up) return;
   const int row0 = m0 + tn * R + wave * RW;
 #pragma unroll
   for (int r = 0; r < RW; r += ROWS) {
@@ -1038,7 +1047,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, int m
     }
   }
   if constexpr (EPI == EPI_GATE_RES && SWAP && !F8) {
-    if (p.ln_out) ln_tail<TBM, TBN, NW>(p, m0, n0);
+    if (p.ln_out) ln_tail<TBM, TBN, NW>(p, m0, n0, smem);      // (its first barrier retires every wave's epilogue slab: LDS is free behind it)
   }
   PHASE_STAMP_END();
 }

@@ -8,63 +8,96 @@
 //     step (modules.py:311,332,727-731) -- the t-grid is known up front;
 //   * once per ODE step: the K=100 "x" part of the input projection (keeps the ODE state path in fp32);
 //   * the Vocos vocoder (all of it: embed conv as im2col GEMM, pointwise convs, head, inverse DFT).
-// Tile 64x64x16, 4 waves as 2x2, each wave 32x32 = 2x2 MFMA tiles.  LDS tiles are stored K-major so the
-// one-float-per-lane fragments are consecutive words (conflict-free ds_read_b32).
+// Tile TM x 64 x 32 (TM = 64, or 32 when a 64-row grid would leave most CUs idle), 4 waves as 2x2, each wave (TM/2) x 32 outputs.
+// LDS tiles are row-major [row][32 k + 4 pad]: a thread parks the float4 it loaded with ONE ds_write_b128 and a lane fetches the four k
+// values of its (row, k-group) with ONE ds_read_b128 (the 16 lanes of a read group hit 16 different 4-bank groups: row pitch 36 words), i.e.
+// MFMA j of a 16-k half takes k = 4 lk + j instead of 4 j + lk -- A and W use the same assignment, so every product meets its partner and only
+// the order of the fp32 additions inside a 16-k group differs from the textbook one.  Two LDS buffers: the global loads of tile t+1 are in
+// registers while tile t is multiplied, one __syncthreads per K-tile.  (Round 4: the previous form -- 16-k tiles, scalar LDS traffic, two
+// barriers per tile -- ran the vocoder's pointwise convolutions at 16-24 % of the fp32 matrix peak.)
 #include "common.h"
 
 namespace {
 
-constexpr int TM = 64, TN = 64, TK = 16, LD = TM + 4;
+constexpr int TN = 64, TK = 32, LDK = TK + 4;
 
-template <int EPI>
+template <int EPI, int TM>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Params p) {
-  __shared__ float As[TK][LD];
-  __shared__ float Bs[TK][LD];
+  constexpr int TI = TM / 32;                       // 16-row MFMA tiles per wave (wave tile = TM/2 x 32)
+  constexpr int AQ = TM / 32;                       // float4 loads per thread and K-tile for the A tile (TM rows x 8 float4)
+  __shared__ __attribute__((aligned(16))) float As[2][TM][LDK];
+  __shared__ __attribute__((aligned(16))) float Bs[2][TN][LDK];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int l15 = lane & 15, lk = lane >> 4;
   const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
 
-  const int lrow = tid >> 2, lk4 = (tid & 3) * 4;
-  const bool a_ok = (m0 + lrow) < p.M, b_ok = (n0 + lrow) < p.N;
+  const int lrow = tid >> 3, lk4 = (tid & 7) * 4;   // loader: rows lrow (+ 32), k offset lk4 inside the tile
   const float* Wz = p.nbatch > 0 ? p.Wv[blockIdx.z] : p.W;
   const float* biasz = p.nbatch > 0 ? p.biasv[blockIdx.z] : p.bias;
   float* outz = p.out + (p.nbatch > 0 ? (size_t)blockIdx.z * p.out_bstride : 0);
-  const float* ap = p.A + (size_t)(a_ok ? m0 + lrow : 0) * p.lda + lk4;
-  const float* bp = Wz + (size_t)(b_ok ? n0 + lrow : 0) * p.ldw + lk4;
-
-  f32x4 acc[2][2];
+  const float* ap[AQ];
+  const float* bp[2];
+  bool a_ok[AQ], b_ok[2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int q = 0; q < AQ; ++q) {
+    a_ok[q] = (m0 + lrow + 32 * q) < p.M;
+    ap[q] = p.A + (size_t)(a_ok[q] ? m0 + lrow + 32 * q : 0) * p.lda + lk4;
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    b_ok[q] = (n0 + lrow + 32 * q) < p.N;
+    bp[q] = Wz + (size_t)(b_ok[q] ? n0 + lrow + 32 * q : 0) * p.ldw + lk4;
+  }
+
+  f32x4 acc[TI][2];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = (p.K + TK - 1) / TK;
-  float4 ra, rb;
+  float4 ra[AQ], rb[2];
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   auto gload = [&](int kt) {
-    const int k = kt * TK + lk4;
-    ra = (a_ok && k < p.K) ? *reinterpret_cast<const float4*>(ap + kt * TK) : make_float4(0.f, 0.f, 0.f, 0.f);
-    rb = (b_ok && k < p.K) ? *reinterpret_cast<const float4*>(bp + kt * TK) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool kin = kt * TK + lk4 < p.K;           // K % 4 == 0: a float4 is inside or outside as a whole
+#pragma unroll
+    for (int q = 0; q < AQ; ++q) ra[q] = (a_ok[q] && kin) ? *reinterpret_cast<const float4*>(ap[q] + kt * TK) : z4;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) rb[q] = (b_ok[q] && kin) ? *reinterpret_cast<const float4*>(bp[q] + kt * TK) : z4;
+  };
+  auto park = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < AQ; ++q) *reinterpret_cast<float4*>(&As[buf][lrow + 32 * q][lk4]) = ra[q];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) *reinterpret_cast<float4*>(&Bs[buf][lrow + 32 * q][lk4]) = rb[q];
   };
   gload(0);
+  park(0);
+  __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
-    As[lk4 + 0][lrow] = ra.x; As[lk4 + 1][lrow] = ra.y; As[lk4 + 2][lrow] = ra.z; As[lk4 + 3][lrow] = ra.w;
-    Bs[lk4 + 0][lrow] = rb.x; Bs[lk4 + 1][lrow] = rb.y; Bs[lk4 + 2][lrow] = rb.z; Bs[lk4 + 3][lrow] = rb.w;
-    __syncthreads();
+    const int cur = kt & 1;
     if (kt + 1 < nk) gload(kt + 1);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      float a[2], b[2];
+    for (int h = 0; h < 2; ++h) {                    // two 16-k halves of the tile
+      float4 a[TI], b[2];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        a[t] = As[ks * 4 + lk][wm * 32 + t * 16 + l15];
-        b[t] = Bs[ks * 4 + lk][wn * 32 + t * 16 + l15];
+      for (int t = 0; t < TI; ++t) a[t] = *reinterpret_cast<const float4*>(&As[cur][wm * (TM / 2) + t * 16 + l15][h * 16 + lk * 4]);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) b[t] = *reinterpret_cast<const float4*>(&Bs[cur][wn * 32 + t * 16 + l15][h * 16 + lk * 4]);
+#pragma unroll
+      for (int j4 = 0; j4 < 4; ++j4) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const float av = j4 == 0 ? a[i].x : j4 == 1 ? a[i].y : j4 == 2 ? a[i].z : a[i].w;
+            const float bv = j4 == 0 ? b[j].x : j4 == 1 ? b[j].y : j4 == 2 ? b[j].z : b[j].w;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av, acc[i][j], 0, 0, 0);   // C^T: see the epilogue
+          }
       }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j], a[i], acc[i][j], 0, 0, 0);   // C^T: see the epilogue
     }
+    if (kt + 1 < nk) park(cur ^ 1);                  // that buffer was last read in iteration kt - 1: every wave is past the barrier that ended it
     __syncthreads();
   }
 
@@ -84,8 +117,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Params p) {
   const bool vec_ok = (p.ldc & 3) == 0 && (reinterpret_cast<size_t>(outz) & 15) == 0 &&
                       (EPI != F32_BIAS_ADD2 || (reinterpret_cast<size_t>(p.add) & 15) == 0);
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int m = m0 + wm * 32 + i * 16 + l15;
+  for (int i = 0; i < TI; ++i) {
+    const int m = m0 + wm * (TM / 2) + i * 16 + l15;
     if (m >= p.M) continue;
     const bool masked = EPI != F32_BIAS_ADD2 && p.rowmask && p.rowmask[m];
 #pragma unroll
@@ -130,8 +163,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Params p) {
 
 template <int EPI>
 hipError_t launch(const GemmF32Params& p, hipStream_t s) {
-  dim3 grid((p.N + TN - 1) / TN, (p.M + TM - 1) / TM, p.nbatch > 0 ? p.nbatch : 1);
-  hipLaunchKernelGGL(gemm_f32_kernel<EPI>, grid, dim3(256), 0, s, p);
+  const int gn = (p.N + TN - 1) / TN, nb = p.nbatch > 0 ? p.nbatch : 1;
+  // 64-row tiles unless they leave the chip mostly idle (the vocoder's N = 512 convolutions at L ~ 900: 120 workgroups): then 32-row tiles
+  if ((long)gn * ((p.M + 63) / 64) * nb < 200 && p.M > 32) {
+    hipLaunchKernelGGL((gemm_f32_kernel<EPI, 32>), dim3(gn, (p.M + 31) / 32, nb), dim3(256), 0, s, p);
+  } else {
+    hipLaunchKernelGGL((gemm_f32_kernel<EPI, 64>), dim3(gn, (p.M + 63) / 64, nb), dim3(256), 0, s, p);
+  }
   return hipGetLastError();
 }
 

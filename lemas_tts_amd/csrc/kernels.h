@@ -15,12 +15,17 @@ hipError_t launch_ln_affine(const float* x, const float* w, const float* b, floa
 hipError_t launch_grn(float* x, float* gx_scratch, const float* gamma, const float* beta, int B, int N, int C, hipStream_t s);
 hipError_t launch_add_rowvec(float* x, const float* vec, int BB, int B, int N, int C, int nlim, hipStream_t s);
 hipError_t launch_cond_prepare(const float* cond, const uint8_t* mask, const float* pm, const float* pbias, int B, int N,
-                               int F, int md, float* cond_eff, float* step_cond, hipStream_t s);
+                               int F, int md, int crows /* rows per sample present in cond, <= N */, float* cond_eff, float* step_cond,
+                               hipStream_t s);
 hipError_t launch_concat_ct(const float* step_cond, const float* te, int B, int N, int md, int td, int branches, int pitch,
                             float* ct, hipStream_t s);
 hipError_t launch_time_sinus(const float* t, const float* freqs, int S, int half, float* out, hipStream_t s);
 hipError_t launch_silu(const float* x, float* out, size_t n, hipStream_t s);
-hipError_t launch_im2col7(const float* mel, int B, int C, int L, float* col, hipStream_t s);
+// mel element (b, ci, n) at mel[b * sb + ci * sc + n * sl] (strides in elements): [B, C, L] or a frames-first slice in place
+hipError_t launch_im2col7(const float* mel, int B, int C, int L, long sb, long sc, long sl, float* col, hipStream_t s);
+// dwconv7 + affine LayerNorm of one ConvNeXt block in one launch (C == 512)
+hipError_t launch_dwconv7_ln(const float* x, const float* w, const float* bias, const float* lnw, const float* lnb, float* out, int B, int N,
+                             int C, hipStream_t s);
 hipError_t launch_spec(const float* head, int rows, int nb, int ldh, int lds_, float* spec, hipStream_t s);
 hipError_t launch_dft_basis(const float* window, int nfft, int ld, float* basis, hipStream_t s);
 hipError_t launch_overlap_add(const float* frames, const float* window, int B, int L, int nfft, int hop, float* wav, hipStream_t s);

@@ -108,14 +108,20 @@ class DiTEngine(_Streamed):
     def set_option(self, key: str, value: int):
         _lib.check(_lib.lib().lemas_dit_set_option(self._h, key.encode(), int(value)), f"set_option({key})")
 
+    def stat(self, key: str) -> int:
+        """counters of the engine's step-graph cache etc. (``lemas_dit_get_stat``)"""
+        v = C.c_int64()
+        _lib.check(_lib.lib().lemas_dit_get_stat(self._h, key.encode(), C.byref(v)), f"get_stat({key})")
+        return int(v.value)
+
     def check_health(self):
         """Synchronise and raise if a device-side wait of this engine gave up (results since then would be invalid)."""
         _lib.check(_lib.lib().lemas_dit_health(self._h), "lemas_dit_health")
 
     # ------------------------------------------------------------------------------------------
     def _args(self, cond, cond_mask, text, seq_len, prosody, t_grid, cfg_strength, cond_frames, y, out, traj, step_cond=None,
-              prosody_text_only=False):
-        B, N, _ = cond.shape
+              prosody_text_only=False, y_init=None):
+        B, N = cond_mask.shape                          # cond may hold fewer rows than N (cond_rows): the library pads
         tg = np.ascontiguousarray(np.asarray(t_grid, dtype=np.float32))
         self._tg_keep = tg
         a = _lib.SampleArgs()
@@ -130,6 +136,10 @@ class DiTEngine(_Streamed):
         a.trajectory = traj.data_ptr() if traj is not None else None
         a.step_cond = step_cond.data_ptr() if step_cond is not None else None
         a.prosody_text_only = 1 if prosody_text_only else 0
+        a.cond_rows = cond.shape[1]
+        if step_cond is not None:
+            assert step_cond.shape[1] == cond.shape[1], "cond and step_cond share cond_rows"
+        a.y_init = y_init.data_ptr() if y_init is not None else None
         return a
 
     def _canon(self, cond, cond_mask, text, seq_len, prosody):
@@ -144,19 +154,21 @@ class DiTEngine(_Streamed):
     def sample(self, cond, cond_mask, text, t_grid, y0, *, cond_frames: int, cfg_strength: float,
                seq_len: Optional[torch.Tensor] = None, prosody: Optional[torch.Tensor] = None,
                want_trajectory: bool = False, step_cond: Optional[torch.Tensor] = None, prosody_text_only: bool = False):
-        """cond [B,N,mel] zero-padded mel; cond_mask [B,N] bool; text [B,Nt] int64 (-1 pad); y0 [B,N,mel];
-        step_cond [B,N,mel] or None: the accent-GRL conditioning (cfm.py:387-388) when it differs from cond.
+        """cond [B,R,mel] reference mel, R <= N rows per sample (rows R..N-1 are the reference's zero padding, applied by the
+        library); cond_mask [B,N] bool; text [B,Nt] int64 (-1 pad); y0 [B,N,mel] (left untouched);
+        step_cond [B,R,mel] or None: the accent-GRL conditioning (cfm.py:387-388) when it differs from cond.
         Returns (out, y_final, trajectory|None) as device tensors."""
         cond, cond_mask, text, seq_len, prosody = self._canon(cond, cond_mask, text, seq_len, prosody)
         step_cond = None if step_cond is None else step_cond.to(self.device, torch.float32).contiguous()
         with torch.cuda.device(self.device):
-            y = y0.to(self.device, torch.float32).contiguous().clone()
+            y_init = y0.to(self.device, torch.float32).contiguous()     # no copy when the caller's noise is already a device tensor
+            y = torch.empty_like(y_init)
             out = torch.empty_like(y)
             S = len(t_grid) - 1
             traj = torch.empty((S + 1,) + tuple(y.shape), device=self.device, dtype=torch.float32) if want_trajectory else None
             a = self._args(cond, cond_mask, text, seq_len, prosody, t_grid, cfg_strength, cond_frames, y, out, traj, step_cond,
-                           prosody_text_only)
-            s = self._enter(cond, cond_mask, text, seq_len, prosody, y, out, traj, step_cond)
+                           prosody_text_only, y_init=y_init)
+            s = self._enter(cond, cond_mask, text, seq_len, prosody, y, y_init, out, traj, step_cond)
             _lib.check(_lib.lib().lemas_dit_sample(self._h, C.byref(a), s), "lemas_dit_sample")
             self._exit()
         return out, y, traj
@@ -176,11 +188,12 @@ class DiTEngine(_Streamed):
         """Step loop on the prepared state (bench hot region).  Returns (out|None, y_final)."""
         cond, cond_mask, *_ = self._prep_keep
         with torch.cuda.device(self.device):
-            y = y0.to(self.device, torch.float32).contiguous().clone()
+            y_init = y0.to(self.device, torch.float32).contiguous()
+            y = torch.empty_like(y_init)
             out = torch.empty_like(y) if want_out else None
             a = self._prep_args
-            a.y, a.out, a.trajectory = y.data_ptr(), (out.data_ptr() if out is not None else None), None
-            s = self._enter(y, out)
+            a.y, a.out, a.trajectory, a.y_init = y.data_ptr(), (out.data_ptr() if out is not None else None), None, y_init.data_ptr()
+            s = self._enter(y, y_init, out)
             _lib.check(_lib.lib().lemas_dit_solve(self._h, C.byref(a), s), "lemas_dit_solve")
             self._exit()
         return out, y
@@ -235,15 +248,27 @@ class VocosEngine(_Streamed):
         except Exception:
             pass
 
+    def set_option(self, key: str, value: int):
+        _lib.check(_lib.lib().lemas_vocos_set_option(self._h, key.encode(), int(value)), f"vocos set_option({key})")
+
     def decode(self, mel: torch.Tensor, gain: float = 1.0) -> torch.Tensor:
-        """mel [B, 100, L] -> wav [B, 256 (L-1)] on the engine's device."""
+        """mel [B, 100, L] -> wav [B, 256 (L-1)] on the engine's device.  A ``permute(0, 2, 1)`` VIEW of frames-first rows -- how every
+        caller of the reference builds the argument (utils_infer.py:546-549, speech_edit_multilingual.py:196-198) -- is decoded in
+        place through ``lemas_vocos_decode_rows``: no permute copy."""
         with torch.cuda.device(self.device):
-            mel = mel.to(self.device, torch.float32).contiguous()
-            B, _, L = mel.shape
+            mel = mel.to(self.device, torch.float32)
+            B, Cc, L = mel.shape
             wav = torch.empty((B, self.arch.hop_length * (L - 1)), device=self.device, dtype=torch.float32)
+            rows_view = mel.stride(1) == 1 and mel.stride(2) == Cc and (B == 1 or mel.stride(0) >= Cc * L) and not mel.is_contiguous()
+            if not rows_view:
+                mel = mel.contiguous()
             s = self._enter(mel, wav)
-            _lib.check(_lib.lib().lemas_vocos_decode(self._h, mel.data_ptr(), B, L, float(gain), wav.data_ptr(), s),
-                       "lemas_vocos_decode")
+            if rows_view:
+                _lib.check(_lib.lib().lemas_vocos_decode_rows(self._h, mel.data_ptr(), B, L, mel.stride(0), float(gain), wav.data_ptr(), s),
+                           "lemas_vocos_decode_rows")
+            else:
+                _lib.check(_lib.lib().lemas_vocos_decode(self._h, mel.data_ptr(), B, L, float(gain), wav.data_ptr(), s),
+                           "lemas_vocos_decode")
             self._exit()
         return wav
 

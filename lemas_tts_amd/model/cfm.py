@@ -136,7 +136,7 @@ class CFM:
         assert cond.shape[-1] == self.num_channels
         cond = cond.to(dev, torch.float32)
         batch, cond_seq_len = cond.shape[:2]
-        cond_mean = cond.mean(dim=1, keepdim=True)                           # cfm.py:239
+        cond_mean = cond.mean(dim=1, keepdim=True) if no_ref_audio else None    # cfm.py:239 (only the no_ref_audio branch reads it)
         cond_grl = None
         if use_acc_grl:                                                      # cfm.py:266-283: built from the RAW prompt mel
             if ref_ratio < 1:
@@ -166,7 +166,10 @@ class CFM:
         duration = torch.maximum(torch.maximum((text != -1).sum(dim=-1), lens) + 1, duration).clamp(max=max_duration)
         n = int(duration.amax())
 
-        cond = F.pad(cond, (0, 0, 0, n - cond_seq_len), value=0.0)
+        # cfm.py:311 right-pads the prompt mel with zeros up to n (and CROPS it when `lens` lets the duration fall below the prompt
+        # length: negative pad).  The padding is the library's (lemas_sample_args.cond_rows): no pad copy here
+        if cond_seq_len > n:
+            cond = cond[:, :n].contiguous()
         pros = prosody_embeds if (use_prosody_encoder and self.use_prosody_encoder) else None
         if no_ref_audio:
             # cfm.py:320-324: the conditioning becomes noise around the prompt's mean (the draw is an explicit input here,
@@ -196,7 +199,12 @@ class CFM:
         if cond_grl is not None and (pros is not None or no_ref_audio or ref_ratio < 1):
             # the flow is conditioned on cond_grl, not on the (prosody-shifted / replaced) cond (cfm.py:329-330, 387-388);
             # when the two coincide the engine's default is already right
-            step_cond = F.pad(cond_grl, (0, 0, 0, n - cond_seq_len), value=0.0)
+            step_cond = cond_grl[:, :n].contiguous() if cond_seq_len > n else cond_grl
+            if step_cond.shape[1] != cond.shape[1]:          # no_ref_audio replaced cond by a full-length tensor
+                step_cond = F.pad(step_cond, (0, 0, 0, cond.shape[1] - step_cond.shape[1]), value=0.0)
+        # what the engine was handed, for measurement tools that time its prepare() / solve() halves on the same inputs (bench.py)
+        self.last_engine_call = dict(cond=cond, cond_mask=cond_mask, text=text, t_grid=t.numpy(), y0=y0, cond_frames=min(cond_seq_len, n),
+                                     cfg_strength=float(cfg_strength), seq_len=seq_len, prosody=pros)
         out, y_final, traj = self.engine.sample(
             cond, cond_mask, text, t.numpy(), y0, cond_frames=min(cond_seq_len, n), cfg_strength=float(cfg_strength),   # F.pad above CROPS the
             # prompt when `lens` lets the duration fall below the prompt length (negative pad, as cfm.py:311 does)

@@ -139,14 +139,14 @@ def main(argv=None) -> int:
         network = resolve_callable(args.denoise_model_factory, "denoise model factory")()
         tmp_denoised = UVR5(network, cfg, device=args.device or "cuda:0").denoise_file(ref_audio)
         ref_audio = tmp_denoised
-    tts = build_tts(args.model, ckpt_file, vocab_file, args.device, args.use_ema, None if phones_given else args.frontend,
-                    args.enable_prosody_encoder, args.prosody_cfg_path, args.prosody_ckpt_path, args.vocoder_local_path)
-    if phones_given:
-        ref_text, gen_text = _phone_lines(args.ref_phones)[0], _phone_lines(args.phones)
-    else:
-        ref_text, gen_text = args.ref_text.strip(), args.text.strip()
-    seed = None if args.seed == -1 else args.seed
-    try:
+    try:                         # everything after the temporary file exists runs under the finally that removes it
+        tts = build_tts(args.model, ckpt_file, vocab_file, args.device, args.use_ema, None if phones_given else args.frontend,
+                        args.enable_prosody_encoder, args.prosody_cfg_path, args.prosody_ckpt_path, args.vocoder_local_path)
+        if phones_given:
+            ref_text, gen_text = _phone_lines(args.ref_phones)[0], _phone_lines(args.phones)
+        else:
+            ref_text, gen_text = args.ref_text.strip(), args.text.strip()
+        seed = None if args.seed == -1 else args.seed
         tts.infer(ref_file=ref_audio, ref_text=ref_text, gen_text=gen_text, nfe_step=int(args.nfe_step),
                   cfg_strength=float(args.cfg_strength), sway_sampling_coef=float(args.sway_sampling_coef),
                   use_acc_grl=bool(args.use_acc_grl), ref_ratio=float(args.ref_ratio), no_ref_audio=bool(args.no_ref_audio),

@@ -190,7 +190,8 @@ def run_full_size_cases(which=None):
       configs1_nfe32        configs[1]: batch 1, 10 s + 10 s (F = 938, N = 1875), NFE 32            <- the headline
       configs2_prosody_b8   configs[2]: multilingual_prosody, batch 8 of mixed lengths (ragged lens / durations), sway, NFE 32
       configs3_share_nfe32  configs[3]: the per-GPU share of the 64-utterance batch, 8 x (4 s + 8 s) (N = 1125), NFE 32
-      configs4_edit_nfe48   configs[4]: speech-edit infill of a 30 s source (F = 2813), 3 edit spans, NFE 48, sway 3"""
+      configs4_edit_nfe48   configs[4]: speech-edit infill of a 30 s source (F = 2813), 3 edit spans, NFE 48, sway 3
+      configs0_outlier_nfe32  configs[0]'s shape at NFE 32 on weights with activation outliers (fp8 stress at a production step count)"""
     cases = {
         "configs0_nfe16": dict(arch=FULL, wseed=1234, B=1, F=375, lens=None, Nt=[128], duration=750, steps=16, cfg=2.0, coef=5, noise_seed=1230),
         "configs1_nfe32": dict(arch=FULL, wseed=1234, B=1, F=938, lens=None, Nt=[319], duration=1875, steps=32, cfg=2.0, coef=5, noise_seed=1234),
@@ -201,6 +202,11 @@ def run_full_size_cases(which=None):
                                      noise_seed=4321),
         "configs4_edit_nfe48": dict(arch=FULL, wseed=1234, B=1, F=2813, lens=None, Nt=[400], duration=2813, steps=48, cfg=2.0, coef=3.0,
                                     noise_seed=1236, edit_spans=[(4.0, 6.5), (12.0, 15.0), (22.0, 24.0)]),
+        # round 4: the activation-outlier stress of `full_outlier` (1 % of the residual channels x30 in every block) on a PRODUCTION solve --
+        # full depth, NFE 32 -- so that the fp8 path is judged on outliers at the step count it ships with, not on a short solve whose
+        # coarse steps integrate the e4m3 flow error undamped with or without outliers (full_plain: 3 steps, full_outlier: 8)
+        "configs0_outlier_nfe32": dict(arch=FULL, wseed=24, B=1, F=375, lens=None, Nt=[128], duration=750, steps=32, cfg=2.0, coef=5,
+                                       noise_seed=1237, outlier=(0.01, 30.0)),
     }
     for name, kw in cases.items():
         if which and name not in which:

@@ -454,9 +454,11 @@ def test_ln_fold_rows_with_a_large_mean():
     print(f"\n[ln fold, mean/std = 10] emulation err {ea:.2e}, textbook err {eb:.2e}")
 
 
-@pytest.mark.parametrize("B,H,N", [(8, 16, 1900), (16, 16, 1875), (3, 16, 2814)])
-def test_attention_large_ragged_batches(B, H, N):
-    """BH = 128 / 256 per launch with ragged key lengths at N ~ 1900 (config3's lane) and config 5's N = 2814"""
+@pytest.mark.parametrize("variant", [0, 4113])
+@pytest.mark.parametrize("B,H,N", [(8, 16, 1900), (16, 16, 1875), (3, 16, 2814), (2, 16, 130), (1, 16, 64), (5, 16, 257)])
+def test_attention_large_ragged_batches(B, H, N, variant):
+    """BH = 128 / 256 per launch with ragged key lengths at N ~ 1900 (config3's lane) and config 5's N = 2814; short sequences around
+    the 256-query workgroup of the q64 kernel (one key tile, one and a bit query blocks)"""
     L, lib = _lib()
     dev = "cuda:0"
     g = torch.Generator(device=dev).manual_seed(B * 1000 + N)
@@ -465,12 +467,14 @@ def test_attention_large_ragged_batches(B, H, N):
     lens = torch.randint(N // 3, N + 1, (B,), generator=g, device=dev, dtype=torch.int32)
     lens[0], lens[-1] = N, max(1, N // 2 + 1)
     out = torch.empty(B, N, H * 64, device=dev)
-    L.check(lib.lemas_k_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), lens.data_ptr(), out.data_ptr(), B, H, N, None))
-    qb, kb, vb = _bf(q), _bf(k), _bf(v)
+    L.check(lib.lemas_k_attention_variant(q.data_ptr(), k.data_ptr(), v.data_ptr(), lens.data_ptr(), out.data_ptr(), B, H, N, variant, None))
+    pres = bool(variant & 16)          # "prescaled q" variants round q * scale * log2(e) to bf16 and work in base 2
+    c = float(np.float32(0.125) * np.float32(1.4426950408889634))
+    qb, kb, vb = (_bf(q * c) if pres else _bf(q)), _bf(k), _bf(v)
     worst = 0.0
     for b in range(B):      # one sample at a time: the score matrix of a sample is H x N x N fp32
         n = int(lens[b])
-        s = (qb[b, :, :n] @ kb[b, :, :n].transpose(-1, -2)) / 8.0
+        s = (qb[b, :, :n] @ kb[b, :, :n].transpose(-1, -2)) * (math.log(2.0) if pres else 0.125)
         ref = (torch.softmax(s, -1) @ vb[b, :, :n]).transpose(0, 1).reshape(n, H * 64)
         worst = max(worst, float((out[b, :n] - ref).abs().max()))
     assert worst < 3e-2, worst
@@ -497,7 +501,8 @@ def _attn_ref(q, k, v, lens, prescaled=False):
     return out
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 7, 17, 19, 17 + 1024, 19 + 1024])
+# 4096 + 16 + s: the 64-queries-per-wave kernel (csrc/attention_q64.hip), s = schedule bits
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 7, 17, 19, 17 + 1024, 19 + 1024, 4112, 4113, 4114, 4115])
 @pytest.mark.parametrize("case", ["plain", "late_spike", "overflow", "early_peak", "ragged", "deep_negative"])
 def test_attention_variants(variant, case):
     L, lib = _lib()

@@ -61,3 +61,37 @@ def test_bench_refuses_a_world_size_that_is_not_gpus():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1"], capture_output=True, text=True, timeout=120,
                        env=dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
     assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
+
+
+@pytest.mark.timeout(900)
+def test_bench_sharded_job_two_ranks_on_one_gpu():
+    """``--job configs3_full``: rank 0 owns the 64 utterances, deals them (shard_utterances), the ranks sample + vocode their shards in
+    batches of 8 and the waveforms come back to rank 0's host (precedent uvr5/multiprocess_cuda_infer.py:404-420).  Two
+    ranks share the one GPU over gloo; reduced depth.  bench.py itself asserts that an utterance alone equals the utterance in its batch."""
+    two = _bench(["--gpus", "2", "--steps", "1", "--warmup", "1", "--depth", "2", "--job", "configs3_full"],
+                 env={"LEMAS_SHARE_GPU": "1", "LEMAS_DIST_BACKEND": "gloo"})
+    c = two["config"]
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and c["workload_key"] == "configs3_full"
+    assert c["utterances_total"] == 64 and c["utterances_per_rank"] == 32 and c["utterances_per_batch"] == 8 and c["batches_per_rank"] == 4
+    assert c["utterance_alone_equals_in_batch"] is True and c["audio_seconds_total"] == pytest.approx(64 * 8.0, rel=1e-6)
+    pr = two["per_rank_ms"]
+    assert len(pr["compute"]) == 2 and min(pr["compute"]) > 0 and two["job_ms"] >= max(pr["compute"]) and two["value"] > 0
+    one = _bench(["--steps", "1", "--warmup", "1", "--depth", "2", "--job", "configs3_full"])
+    assert one["n_gpus"] == 1 and one["config"]["batches_per_rank"] == 8 and one["per_rank_ms"]["scatter"][0] >= 0
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("wl", ["configs2", "configs4"])
+def test_bench_times_the_ragged_prosody_batch_and_the_speech_edit_case(wl):
+    """the two BASELINE configurations beside the headline that bench.py times since round 4 (reduced depth here: launch shapes, vocoder
+    segments and bookkeeping; the full-depth parity of the same fixtures is tests/test_gpu_06_configs.py and the full bench run)"""
+    line = _bench(["--steps", "1", "--warmup", "1", "--depth", "2", "--no-cpu-baseline", "--no-clock-power", "--workload", wl])
+    c = line["config"]
+    assert c["workload_key"] == wl and line["value"] > 0 and line["roofline"]["frac"] > 0
+    if wl == "configs2":
+        assert c["utterances_per_gpu_per_step"] == 8 and c["waveforms_per_step"] == 8 and c["vocode"] == "each"
+        assert c["real_frames_per_step"] == 10910 and c["rows_computed_per_step"] == 15360 and c["padded_row_waste"] == pytest.approx(1 - 10910 / 15360)
+        assert line["dtype"] == "bf16" and "NFE=32" in line["metric"]
+    else:
+        assert c["waveforms_per_step"] == 1 and c["vocode"] == "whole" and c["audio_seconds_per_step"] == pytest.approx(256 * 2813 / 24000)
+        assert line["dtype"] == "fp8" and "NFE=48" in line["metric"]

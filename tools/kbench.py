@@ -36,6 +36,8 @@ def main():
     a.add_argument("--N", type=int, nargs="+", default=[1875])
     a.add_argument("--BH", type=int, nargs="+", default=[16, 32, 256])
     a.add_argument("--iters", type=int, default=20)
+    a.add_argument("--variants", type=int, nargs="+", default=[19], help="attention schedule variants (csrc/attention.hip; 4112 + s = the "
+                   "64-queries-per-wave kernel of attention_q64.hip, s = 0..3)")
     o = sub.add_parser("one")
     o.add_argument("what"); o.add_argument("M", type=int); o.add_argument("N", type=int); o.add_argument("K", type=int)
     o.add_argument("tile", type=int, nargs="?", default=0)
@@ -54,8 +56,11 @@ def main():
     elif args.cmd == "attn":
         for n in args.N:
             for bh in args.BH:
-                us = bench(L, "attention", n, bh, 0, args.iters, 0)
-                print(f"attention N={n} BH={bh}: {us:.1f} us ({4.0 * n * n * 64 * bh / us / 1e6:.0f} TF)")
+                cells = []
+                for v in args.variants:
+                    us = bench(L, "attention", n, bh, 0, args.iters, v)
+                    cells.append(f"v{v}:      n/a      " if us is None else f"v{v}: {us:6.1f} us ({4.0 * n * n * 64 * bh / us / 1e6:4.0f} TF)")
+                print(f"attention N={n} BH={bh}: " + "   ".join(cells))
     else:
         us = bench(L, args.what, args.M, args.N, args.K, args.iters, args.tile)
         if us is None:
