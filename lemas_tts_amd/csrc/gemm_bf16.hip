@@ -58,6 +58,27 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // is (about) one block: it fetches 1/gx of the A panels and 1/gy of the W panels.  With the plain row-major sequence (gx = 8,
 // gy = 1) every XCD streamed ALL of W: PMC FETCH 45.8 MB for the QK GEMM against 15.8 MB algorithmic (profiles/r01o_traffic.json).
 // The host picks (gx, gy) to minimise gy * |A| + gx * |W| (GemmParams::xcd_gx).  Ragged grids: blocks at the edges are smaller.
+// Round 4: the run of an XCD and its block are the SAME thing.  xcd_remap hands every XCD an equal share of the sequence, but the blocks of a
+// ragged grid are not equal (15 x 8 tiles cut 4 x 2: blocks of 16, 16, 16, 16, 16, 16, 12, 12), so an XCD's run started inside one block and
+// ended in the next and fetched both blocks' panels (out-projection / FF2 at configs[1]: 41.9 MB of fabric reads per launch against 31.3 MB
+// for aligned blocks).  Here workgroup `bid` belongs to XCD bid & 7 = block bid & 7 and takes tile (bid >> 3) of that block; the launch holds
+// 8 x (largest block) workgroups and the few beyond a smaller block's end return at once (xcd_grid / xcd_tile_coords).
+__host__ __device__ __forceinline__ int xcd_grid(int tiles_m, int tiles_n, int gx) {
+  const int gy = 8 / gx;
+  const int bm = (tiles_m + gx - 1) / gx, bn = (tiles_n + gy - 1) / gy;
+  return 8 * bm * bn;
+}
+__device__ __forceinline__ bool xcd_tile_coords(int bid, int tiles_m, int tiles_n, int gx, int& tm, int& tn) {
+  const int gy = 8 / gx;
+  const int bm = (tiles_m + gx - 1) / gx, bn = (tiles_n + gy - 1) / gy;
+  const int blk = bid & 7, idx = bid >> 3;
+  const int bi = blk / gy, bj = blk - bi * gy;
+  const int rows = min(bm, tiles_m - bi * bm), cols = min(bn, tiles_n - bj * bn);
+  if (rows <= 0 || cols <= 0 || idx >= rows * cols) return false;
+  tm = bi * bm + idx / cols;
+  tn = bj * bn + idx % cols;
+  return true;
+}
 __device__ __forceinline__ void tile_coords(int seq, int tiles_m, int tiles_n, int gx, int& tm, int& tn) {
   const int gy = 8 / gx;
   const int bm = (tiles_m + gx - 1) / gx, bn = (tiles_n + gy - 1) / gy;
@@ -1397,7 +1418,7 @@ template <int EPI>
 __global__ __launch_bounds__(512) void gemm_pp2_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int tm, tn;
-  tile_coords(xcd_remap(blockIdx.x, gridDim.x), (p.M + 255) / 256, p.N / 128, p.xcd_gx, tm, tn);
+  if (!xcd_tile_coords(blockIdx.x, (p.M + 255) / 256, p.N / 128, p.xcd_gx, tm, tn)) return;
   gemm_body_pp2<EPI, EPI != EPI_V_T>(p, smem, tm * 256, tn * 128, reinterpret_cast<float*>(smem + 3 * (256 + 128) * 128));
 }
 
@@ -1409,7 +1430,7 @@ struct LaunchPP2 {
   }
   static hipError_t run(const GemmParams& p, hipStream_t s) {
     if (p.N % 128 != 0 || p.K % 64 != 0) return hipErrorInvalidValue;
-    const dim3 grid(((p.M + 255) / 256) * (p.N / 128)), block(512);
+    const dim3 grid(xcd_grid((p.M + 255) / 256, p.N / 128, p.xcd_gx)), block(512);
     // the (r, -r mu) table behind the ring is only there for a ln-fold consumer: every other launch keeps the ring's own footprint
     const int lds_now = p.ln_part ? lds : lds - 256 * 8;
     if (p.ev_start) hipExtLaunchKernelGGL((gemm_pp2_kernel<EPI>), grid, block, lds_now, s, p.ev_start, p.ev_stop, 0, p);
@@ -1422,7 +1443,7 @@ template <int EPI>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int tm, tn;
-  tile_coords(xcd_remap(blockIdx.x, gridDim.x), (p.M + 255) / 256, p.N / 256, p.xcd_gx, tm, tn);
+  if (!xcd_tile_coords(blockIdx.x, (p.M + 255) / 256, p.N / 256, p.xcd_gx, tm, tn)) return;
   gemm_body_pp<EPI, EPI != EPI_V_T>(p, smem, tm * 256, tn * 256, reinterpret_cast<float*>(smem + 8 * 16384));
 }
 
@@ -1435,7 +1456,7 @@ struct LaunchPP {
   }
   static hipError_t run(const GemmParams& p, hipStream_t s) {
     if (p.N % 256 != 0 || p.K % 64 != 0) return hipErrorInvalidValue;
-    const dim3 grid(((p.M + 255) / 256) * (p.N / 256)), block(512);
+    const dim3 grid(xcd_grid((p.M + 255) / 256, p.N / 256, p.xcd_gx)), block(512);
     const int lds_now = p.ln_part ? lds : lds - 256 * 8;
     if (p.ev_start) hipExtLaunchKernelGGL((gemm_pp_kernel<EPI>), grid, block, lds_now, s, p.ev_start, p.ev_stop, 0, p);
     else hipLaunchKernelGGL((gemm_pp_kernel<EPI>), grid, block, lds_now, s, p);
@@ -1455,7 +1476,7 @@ template <int EPI, int TBM, int TBN, int NSTAGE, int NWM, int NWN, bool F8>
 __global__ __launch_bounds__(64 * NWM * NWN) void gemm_bf16_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int tm, tn;
-  tile_coords(xcd_remap(blockIdx.x, gridDim.x), (p.M + TBM - 1) / TBM, p.N / TBN, p.xcd_gx, tm, tn);
+  if (!xcd_tile_coords(blockIdx.x, (p.M + TBM - 1) / TBM, p.N / TBN, p.xcd_gx, tm, tn)) return;
   gemm_body<EPI, TBM, TBN, NSTAGE, NWM, NWN, EPI != EPI_V_T, F8>(p, smem, tm * TBM, tn * TBN,
       reinterpret_cast<float*>(smem + body_lds_base<EPI, TBM, TBN, NSTAGE, NWM, NWN, F8>()));
 }
@@ -1500,7 +1521,7 @@ struct Launch {
   static hipError_t run(const GemmParams& p, hipStream_t s) {
     if (p.N % C::BN != 0) return hipErrorInvalidValue;
     const int tiles_m = (p.M + C::BM - 1) / C::BM, tiles_n = p.N / C::BN;
-    const dim3 grid(tiles_m * tiles_n), block(64 * C::WM * C::WN);
+    const dim3 grid(xcd_grid(tiles_m, tiles_n, p.xcd_gx)), block(64 * C::WM * C::WN);
     // without the ln-fold table the launch keeps the ring's own footprint (128 x 128: exactly 96 KB, which with the attention kernel's
     // exact 64 KB is a CU's 160 KB -- measured: sharing or not sharing a CU that way changes nothing, profiles/r03_structural_attempts.txt)
     const int lds_now = p.ln_part ? lds : lds - C::BM * 8;
@@ -1539,19 +1560,24 @@ int pick_tile(const GemmParams& p) {
   return tile;
 }
 
+// the ping-pong bodies share the block-pipelined row epilogues, which do not write MXFP8: bf16 operands with EPI_BIAS_GELU_F8 (the fp8 path's
+// FF1 under the outlier guard) run on the lock-step tiles
+template <int EPI> constexpr bool pp_ok() { return EPI != EPI_BIAS_GELU_F8; }
+
 template <int EPI, bool F8>
 hipError_t dispatch(const GemmParams& p, int tile, hipStream_t s) {
   if (tile == 0) tile = pick_tile(p);
+  if (!F8 && !pp_ok<EPI>() && tile == T256x256) tile = T256x128;
   switch (tile) {
     case T256x128:
-      if constexpr (!F8) return LaunchPP2<EPI>::run(p, s);       // bf16: the ping-pong form (5-9 % faster alone, +0.9 % end to end for FF1)
-      else return Launch<EPI, T256x128, true>::run(p, s);
+      if constexpr (!F8 && pp_ok<EPI>()) return LaunchPP2<EPI>::run(p, s);       // bf16: the ping-pong form (5-9 % faster alone, +0.9 % end to end for FF1)
+      else return Launch<EPI, T256x128, F8>::run(p, s);
     case T128x128: return Launch<EPI, T128x128, F8>::run(p, s);
     case T128x64: return Launch<EPI, T128x64, F8>::run(p, s);
     case T64x64: return Launch<EPI, T64x64, F8>::run(p, s);
     case T128x128W4: return Launch<EPI, T128x128W4, F8>::run(p, s);
     case T256x256:
-      if constexpr (!F8) return LaunchPP<EPI>::run(p, s);
+      if constexpr (!F8 && pp_ok<EPI>()) return LaunchPP<EPI>::run(p, s);
       else return hipErrorInvalidValue;
     default: return hipErrorInvalidValue;
   }
@@ -1565,7 +1591,7 @@ hipError_t init_epi() {
   if ((e = Launch<EPI, T128x64, F8>::init()) != hipSuccess) return e;
   if ((e = Launch<EPI, T64x64, F8>::init()) != hipSuccess) return e;
   if ((e = Launch<EPI, T128x128W4, F8>::init()) != hipSuccess) return e;
-  if constexpr (!F8) {
+  if constexpr (!F8 && pp_ok<EPI>()) {
     if ((e = LaunchPP<EPI>::init()) != hipSuccess) return e;
     if ((e = LaunchPP2<EPI>::init()) != hipSuccess) return e;
   }
@@ -1595,12 +1621,12 @@ __global__ __launch_bounds__(64 * TileCfg<TILE>::WM * TileCfg<TILE>::WN) void ge
   const int bid = blockIdx.x;
   float* rs = reinterpret_cast<float*>(smem + QkvLds<F8, TILE>::base);
   int tm, tn;
-  if (bid < tiles_q) {
-    tile_coords(xcd_remap(bid, tiles_q), (pq.M + C::BM - 1) / C::BM, pq.N / C::BN, pq.xcd_gx, tm, tn);
+  if (bid < tiles_q) {       // tiles_q / tiles_v: the PADDED workgroup counts of the two parts (multiples of 8: both parts keep the XCD phase)
+    if (!xcd_tile_coords(bid, (pq.M + C::BM - 1) / C::BM, pq.N / C::BN, pq.xcd_gx, tm, tn)) return;
     if constexpr (!F8 && TILE == T256x128) gemm_body_pp2<EPI_QK_ROPE, true>(pq, smem, tm * 256, tn * 128, rs);
     else gemm_body<EPI_QK_ROPE, C::BM, C::BN, C::ST, C::WM, C::WN, true, F8>(pq, smem, tm * C::BM, tn * C::BN, rs);
   } else {
-    tile_coords(xcd_remap(bid - tiles_q, tiles_v), (pv.M + C::BM - 1) / C::BM, pv.N / C::BN, pv.xcd_gx, tm, tn);
+    if (!xcd_tile_coords(bid - tiles_q, (pv.M + C::BM - 1) / C::BM, pv.N / C::BN, pv.xcd_gx, tm, tn)) return;
     if constexpr (!F8 && TILE == T256x128) gemm_body_pp2<EPI_V_T, false>(pv, smem, tm * 256, tn * 128, rs);
     else gemm_body<EPI_V_T, C::BM, C::BN, C::ST, C::WM, C::WN, false, F8>(pv, smem, tm * C::BM, tn * C::BN, rs);
   }
@@ -1616,7 +1642,7 @@ struct LaunchQkv {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_qkv_fused_kernel<F8, TILE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   }
   static hipError_t run(const GemmParams& pq, const GemmParams& pv, hipStream_t s) {
-    const int tiles_q = ((pq.M + C::BM - 1) / C::BM) * (pq.N / C::BN), tiles_v = ((pv.M + C::BM - 1) / C::BM) * (pv.N / C::BN);
+    const int tiles_q = xcd_grid((pq.M + C::BM - 1) / C::BM, pq.N / C::BN, pq.xcd_gx), tiles_v = xcd_grid((pv.M + C::BM - 1) / C::BM, pv.N / C::BN, pv.xcd_gx);
     const dim3 grid(tiles_q + tiles_v), block(64 * NW);
     const int lds_now = (pq.ln_part || pv.ln_part) ? lds : lds - C::BM * 8;
     if (pq.ev_start)
@@ -1660,6 +1686,7 @@ hipError_t gemm_bf16_init() {
   LEMAS_INIT(EPI_V_T)
 #undef LEMAS_INIT
   if ((e = init_epi<EPI_BIAS_GELU_F8, true>()) != hipSuccess) return e;
+  if ((e = init_epi<EPI_BIAS_GELU_F8, false>()) != hipSuccess) return e;
   if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_group_kernel<EPI_BIAS_F32>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                Launch<EPI_BIAS_F32, T128x128, false>::lds)) != hipSuccess) return e;
   if ((e = LaunchQkv<false, T256x128>::init()) != hipSuccess) return e;
@@ -1768,6 +1795,9 @@ hipError_t launch_gemm_bf16_tile(int epi, const GemmParams& p_in, int tile, hipS
     return hipErrorInvalidValue;
   }
   switch (epi) {
+    case EPI_BIAS_GELU_F8:      // bf16 operands, MXFP8 output: FF1 of the fp8 path when the outlier guard keeps its operands bf16
+      if (!p.out_f8 || !p.out_mx) return hipErrorInvalidValue;
+      return dispatch<EPI_BIAS_GELU_F8, false>(p, tile, s);
     case EPI_BIAS_BF16: return dispatch<EPI_BIAS_BF16, false>(p, tile, s);
     case EPI_BIAS_GELU_BF16: return dispatch<EPI_BIAS_GELU_BF16, false>(p, tile, s);
     case EPI_BIAS_F32: return dispatch<EPI_BIAS_F32, false>(p, tile, s);

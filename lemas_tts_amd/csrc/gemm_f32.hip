@@ -25,6 +25,7 @@ template <int EPI, int TM>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Params p) {
   constexpr int TI = TM / 32;                       // 16-row MFMA tiles per wave (wave tile = TM/2 x 32)
   constexpr int AQ = TM / 32;                       // float4 loads per thread and K-tile for the A tile (TM rows x 8 float4)
+  static_assert(TM == 32 || TM == 64, "tile heights");
   __shared__ __attribute__((aligned(16))) float As[2][TM][LDK];
   __shared__ __attribute__((aligned(16))) float Bs[2][TN][LDK];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -36,70 +37,74 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Params p) {
   const float* Wz = p.nbatch > 0 ? p.Wv[blockIdx.z] : p.W;
   const float* biasz = p.nbatch > 0 ? p.biasv[blockIdx.z] : p.bias;
   float* outz = p.out + (p.nbatch > 0 ? (size_t)blockIdx.z * p.out_bstride : 0);
-  const float* ap[AQ];
-  const float* bp[2];
-  bool a_ok[AQ], b_ok[2];
-#pragma unroll
-  for (int q = 0; q < AQ; ++q) {
-    a_ok[q] = (m0 + lrow + 32 * q) < p.M;
-    ap[q] = p.A + (size_t)(a_ok[q] ? m0 + lrow + 32 * q : 0) * p.lda + lk4;
-  }
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    b_ok[q] = (n0 + lrow + 32 * q) < p.N;
-    bp[q] = Wz + (size_t)(b_ok[q] ? n0 + lrow + 32 * q : 0) * p.ldw + lk4;
-  }
+  // (named scalars, not arrays: per-thread arrays touched from a lambda ended up in scratch memory -- 64-96 B per lane, and 35 % slower)
+  const bool a_ok0 = (m0 + lrow) < p.M, a_ok1 = AQ == 2 && (m0 + lrow + 32) < p.M;
+  const bool b_ok0 = (n0 + lrow) < p.N, b_ok1 = (n0 + lrow + 32) < p.N;
+  const float* ap0 = p.A + (size_t)(a_ok0 ? m0 + lrow : 0) * p.lda + lk4;
+  const float* ap1 = p.A + (size_t)(a_ok1 ? m0 + lrow + 32 : 0) * p.lda + lk4;
+  const float* bp0 = Wz + (size_t)(b_ok0 ? n0 + lrow : 0) * p.ldw + lk4;
+  const float* bp1 = Wz + (size_t)(b_ok1 ? n0 + lrow + 32 : 0) * p.ldw + lk4;
 
-  f32x4 acc[TI][2];
-#pragma unroll
-  for (int i = 0; i < TI; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 acc00 = {0.f, 0.f, 0.f, 0.f}, acc01 = acc00, acc10 = acc00, acc11 = acc00;      // [16-row tile of the wave][16-column tile]
 
   const int nk = (p.K + TK - 1) / TK;
-  float4 ra[AQ], rb[2];
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  auto gload = [&](int kt) {
-    const bool kin = kt * TK + lk4 < p.K;           // K % 4 == 0: a float4 is inside or outside as a whole
-#pragma unroll
-    for (int q = 0; q < AQ; ++q) ra[q] = (a_ok[q] && kin) ? *reinterpret_cast<const float4*>(ap[q] + kt * TK) : z4;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) rb[q] = (b_ok[q] && kin) ? *reinterpret_cast<const float4*>(bp[q] + kt * TK) : z4;
-  };
-  auto park = [&](int buf) {
-#pragma unroll
-    for (int q = 0; q < AQ; ++q) *reinterpret_cast<float4*>(&As[buf][lrow + 32 * q][lk4]) = ra[q];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) *reinterpret_cast<float4*>(&Bs[buf][lrow + 32 * q][lk4]) = rb[q];
-  };
-  gload(0);
-  park(0);
+  float4 ra0 = z4, ra1 = z4, rb0 = z4, rb1 = z4;
+  // every load is unconditional from a clamped (always valid) address and zeroed afterwards: a `cond ? *p : 0` form made the compiler
+  // select between the pointer and a zero it parked in scratch memory, and load through the flat path
+#define LEMAS_F32_LD(dst, ptr, ok, koff)                                   \
+  do {                                                                      \
+    const float4 t_ = *reinterpret_cast<const float4*>((ptr) + (koff));     \
+    dst = make_float4((ok) ? t_.x : 0.f, (ok) ? t_.y : 0.f, (ok) ? t_.z : 0.f, (ok) ? t_.w : 0.f); \
+  } while (0)
+#define LEMAS_F32_GLOAD(kt)                                                                         \
+  do {                                                                                              \
+    const bool kin = (kt) * TK + lk4 < p.K; /* K % 4 == 0: a float4 is inside or outside as a whole */ \
+    const int koff = kin ? (kt) * TK : -lk4; /* outside: the row's first float4 (valid), zeroed below */ \
+    LEMAS_F32_LD(ra0, ap0, a_ok0 && kin, koff);                                                     \
+    if (AQ == 2) LEMAS_F32_LD(ra1, ap1, a_ok1 && kin, koff);                                        \
+    LEMAS_F32_LD(rb0, bp0, b_ok0 && kin, koff);                                                     \
+    LEMAS_F32_LD(rb1, bp1, b_ok1 && kin, koff);                                                     \
+  } while (0)
+#define LEMAS_F32_PARK(buf)                                                                         \
+  do {                                                                                              \
+    *reinterpret_cast<float4*>(&As[buf][lrow][lk4]) = ra0;                                          \
+    if (AQ == 2) *reinterpret_cast<float4*>(&As[buf][(lrow + 32) % TM][lk4]) = ra1;                 \
+    *reinterpret_cast<float4*>(&Bs[buf][lrow][lk4]) = rb0;                                          \
+    *reinterpret_cast<float4*>(&Bs[buf][lrow + 32][lk4]) = rb1;                                     \
+  } while (0)
+#define LEMAS_F32_MFMA4(av, bv0, bv1, c0, c1)                                  \
+  c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(bv0, av, c0, 0, 0, 0); /* C^T: see the epilogue */ \
+  c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(bv1, av, c1, 0, 0, 0);
+  LEMAS_F32_GLOAD(0);
+  LEMAS_F32_PARK(0);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) gload(kt + 1);
+    if (kt + 1 < nk) LEMAS_F32_GLOAD(kt + 1);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {                    // two 16-k halves of the tile
-      float4 a[TI], b[2];
-#pragma unroll
-      for (int t = 0; t < TI; ++t) a[t] = *reinterpret_cast<const float4*>(&As[cur][wm * (TM / 2) + t * 16 + l15][h * 16 + lk * 4]);
-#pragma unroll
-      for (int t = 0; t < 2; ++t) b[t] = *reinterpret_cast<const float4*>(&Bs[cur][wn * 32 + t * 16 + l15][h * 16 + lk * 4]);
-#pragma unroll
-      for (int j4 = 0; j4 < 4; ++j4) {
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const float av = j4 == 0 ? a[i].x : j4 == 1 ? a[i].y : j4 == 2 ? a[i].z : a[i].w;
-            const float bv = j4 == 0 ? b[j].x : j4 == 1 ? b[j].y : j4 == 2 ? b[j].z : b[j].w;
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av, acc[i][j], 0, 0, 0);   // C^T: see the epilogue
-          }
-      }
+      const float4 a0 = *reinterpret_cast<const float4*>(&As[cur][wm * (TM / 2) + l15][h * 16 + lk * 4]);
+      const float4 a1 = TI == 2 ? *reinterpret_cast<const float4*>(&As[cur][(wm * (TM / 2) + 16 + l15) % TM][h * 16 + lk * 4]) : z4;
+      const float4 b0 = *reinterpret_cast<const float4*>(&Bs[cur][wn * 32 + l15][h * 16 + lk * 4]);
+      const float4 b1 = *reinterpret_cast<const float4*>(&Bs[cur][wn * 32 + 16 + l15][h * 16 + lk * 4]);
+      LEMAS_F32_MFMA4(a0.x, b0.x, b1.x, acc00, acc01)
+      if (TI == 2) { LEMAS_F32_MFMA4(a1.x, b0.x, b1.x, acc10, acc11) }
+      LEMAS_F32_MFMA4(a0.y, b0.y, b1.y, acc00, acc01)
+      if (TI == 2) { LEMAS_F32_MFMA4(a1.y, b0.y, b1.y, acc10, acc11) }
+      LEMAS_F32_MFMA4(a0.z, b0.z, b1.z, acc00, acc01)
+      if (TI == 2) { LEMAS_F32_MFMA4(a1.z, b0.z, b1.z, acc10, acc11) }
+      LEMAS_F32_MFMA4(a0.w, b0.w, b1.w, acc00, acc01)
+      if (TI == 2) { LEMAS_F32_MFMA4(a1.w, b0.w, b1.w, acc10, acc11) }
     }
-    if (kt + 1 < nk) park(cur ^ 1);                  // that buffer was last read in iteration kt - 1: every wave is past the barrier that ended it
+    if (kt + 1 < nk) LEMAS_F32_PARK(cur ^ 1);        // that buffer was last read in iteration kt - 1: every wave is past the barrier that ended it
     __syncthreads();
   }
+#undef LEMAS_F32_GLOAD
+#undef LEMAS_F32_LD
+#undef LEMAS_F32_PARK
+#undef LEMAS_F32_MFMA4
+  const f32x4 acc[2][2] = {{acc00, acc01}, {acc10, acc11}};
 
   // The MFMA runs with its operands swapped (C^T = W . A^T; same products, same k order, same sums), so a lane owns ONE output row and
   // FOUR CONSECUTIVE columns: row = lane & 15, columns (lane >> 4) * 4 + reg.  Bias / residual / add operands and the result move as

@@ -182,6 +182,7 @@ def test_fp8_cost_of_quantising_activations_and_outlier_stress(golden_dir, name,
     from lemas_tts_amd.model.cfm import CFM
     fx, arch, sd = T._load(golden_dir, name)
     m = CFM(arch, int(fx["vocab"]), sd, device=DEV)
+    m.engine.set_option("fp8_outlier_guard", 0)       # the raw cost of the two quantisations (the guard's effect: test_fp8_outlier_guard below)
     args, kw = _golden_args(fx)
     got = {}
     for mode in (0, 1, 2):
@@ -191,6 +192,49 @@ def test_fp8_cost_of_quantising_activations_and_outlier_stress(golden_dir, name,
     print(f"\n[fp8 points {name}] mel-MSE vs reference: bf16 {got[0]:.3e}  MXFP8 weights+activations {got[1]:.3e}  fp8 weights only {got[2]:.3e}")
     assert got[0] <= bounds[0] and got[1] <= bounds[1] and got[2] <= bounds[2], got
     assert got[0] < got[2] < got[1], got          # each step of quantisation costs accuracy: bf16 < weights-only < weights + activations
+
+
+def test_fp8_outlier_guard(golden_dir):
+    """Activation outliers at a PRODUCTION step count (tests/golden/configs0_outlier_nfe32.npz: the reference's own output at full depth,
+    NFE 32, on weights whose residual-writing projections scale 1 % of the channels x30 -- oracle/gen_golden.py --full-size).  Unguarded,
+    the fp8 path misses the 1e-4 target there (2.9e-4; the few outlier products are not averaged over K).  With the guard (default) the
+    engine sees the outlier channels in the per-channel weight scales, keeps the two LayerNorm-fed GEMMs of every block on bf16 operands
+    and meets the target; on weights without such channels the guard changes nothing."""
+    import test_gpu_00_sample as T
+    from lemas_tts_amd import synth
+    from lemas_tts_amd.model.cfm import CFM
+    fx, arch, sd = T._load(golden_dir, "configs0_outlier_nfe32")
+    fx = synth.expand_reference_fixture(fx)
+    m = CFM(arch, int(fx["vocab"]), sd, device=DEV)
+    args, kw = _golden_args(fx)
+    got = {}
+    for guard in (0, 1):
+        m.engine.set_option("fp8_outlier_guard", guard)
+        m.engine.set_option("fp8", 1)
+        out, _ = m.sample(*args, use_acc_grl=False, **kw)
+        got[guard] = T._gen_mse(out.cpu().numpy(), fx["out"], fx)
+        assert m.engine.stat("fp8_gemms_kept_bf16") == (2 if guard else 0)
+    n_out = m.engine.stat("fp8_outlier_channels")
+    m.engine.set_option("fp8", 0)
+    out, _ = m.sample(*args, use_acc_grl=False, **kw)
+    bf16 = T._gen_mse(out.cpu().numpy(), fx["out"], fx)
+    print(f"\n[fp8 outlier guard, NFE 32, {n_out} outlier channels] mel-MSE vs reference: bf16 {bf16:.3e}  fp8 unguarded {got[0]:.3e}  fp8 guarded {got[1]:.3e}")
+    assert 5 <= n_out <= 20                   # 1 % of 1024 channels
+    assert bf16 <= 1e-4 and got[1] <= 1e-4, (bf16, got)
+    assert got[1] < got[0]
+    del m
+    # no outlier channels: the guard does not trip and the fp8 path is bit-for-bit what it was
+    fx2, arch2, sd2 = T._load(golden_dir, "mini_plain")
+    m2 = _fp8_model(arch2, int(fx2["vocab"]), sd2)
+    a2, k2 = _golden_args(fx2)
+    outs = []
+    for guard in (0, 1):
+        m2.engine.set_option("fp8_outlier_guard", guard)
+        o, _ = m2.sample(*a2, use_acc_grl=False, **k2)
+        outs.append(o.cpu().numpy())
+        assert m2.engine.stat("fp8_gemms_kept_bf16") == 0 and m2.engine.stat("fp8_outlier_channels") == 0
+    np.testing.assert_array_equal(outs[0], outs[1])
+    m2.engine.set_option("fp8_outlier_guard", 1)
 
 
 # The full-depth, NFE-32 tolerance of the fp8 path is checked at FULL SIZE against the reference's own output in

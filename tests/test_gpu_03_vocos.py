@@ -60,3 +60,34 @@ def test_randomised_lengths_vocoder_mel_resample_prosody(seed):
     fb = torch.from_numpy(synth.synth_fbank(60 + seed, T))[None]
     emb = ProsodyEncoder(state_dict=psd, arch=arch, device="cuda:0")(fb).cpu()
     assert float((emb - P.OracleECAPA(psd, arch).forward(fb)).abs().max()) < 2e-5
+
+
+def test_vocos_frames_first_view_graph_replay_and_cache():
+    """round 4: (1) a permute(0, 2, 1) VIEW of frames-first rows -- how every caller of the reference builds the argument
+    (utils_infer.py:546-549) -- is decoded in place (lemas_vocos_decode_rows) and gives the bits of the contiguous [B, C, L] form;
+    (2) the hipGraph the backbone + head is replayed from (captured the second time a shape is seen) gives the eager bits;
+    (3) the shape cache is bounded and survives eviction."""
+    from lemas_tts_amd.engine import VocosEngine
+    sd = synth.synth_vocos_state_dict(9)
+    eng = VocosEngine(sd, device="cuda:0")
+    g = torch.Generator().manual_seed(3)
+    out = (torch.randn(2, 400, 100, generator=g) * 2 - 3).cuda()            # sampler output layout [B, N, mel]
+    view = out[:, 120:, :].permute(0, 2, 1)                                  # frames 120.. of both samples, not contiguous
+    assert not view.is_contiguous()
+    eng.set_option("graph", 0)
+    eager = eng.decode(view.contiguous()).cpu().numpy()
+    np.testing.assert_array_equal(eng.decode(view).cpu().numpy(), eager)     # strided rows == contiguous mel
+    one = eng.decode(out[1:2, 120:, :].permute(0, 2, 1)).cpu().numpy()
+    np.testing.assert_array_equal(one[0], eager[1])                          # a batch-mate does not change a sample
+    eng.set_option("graph", 1)
+    for _ in range(3):                                                       # first sight eager, then captured, then replayed
+        np.testing.assert_array_equal(eng.decode(view).cpu().numpy(), eager)
+    eng.set_option("graph_cache", 2)
+    for L in (50, 60, 70, 50, 60, 70):                                       # three shapes, twice each, through a cache of two
+        w = eng.decode(out[:1, :L, :].permute(0, 2, 1)).cpu().numpy()
+        eng.set_option("graph", 0)
+        np.testing.assert_array_equal(w, eng.decode(out[:1, :L, :].permute(0, 2, 1)).cpu().numpy())
+        eng.set_option("graph", 1)
+    np.testing.assert_array_equal(eng.decode(view).cpu().numpy(), eager)
+    with pytest.raises(Exception):
+        eng.set_option("no_such_option", 1)
