@@ -134,12 +134,13 @@ int lemas_dit_set_option(lemas_dit* m, const char* key, int64_t value);
  * frame count inside a cached bucket -- same batch, same 128-row pitch -- patches one of the bucket's instantiated graphs with
  * hipGraphExecUpdate instead of instantiating another; default 1), "fp8_outlier_guard" (default 1: with option "fp8" = 1, a checkpoint
  * whose residual-writing projections (attn.to_out, ff.2) show outlier output channels -- per-channel weight scale > 8x the median --
- * keeps the two GEMMs that consume LayerNorm outputs (QKV, FF1) on bf16 operands; the out-projection and FF2 stay fp8.  Such channels
- * dominate every LayerNorm output, and e4m3's 2^-4 step on those few products is not averaged away: measured 2.9e-4 mel-MSE at full
- * depth / NFE 32 without the guard, against the 1e-4 target).
+ * runs every block GEMM on its bf16 operands after all: such channels make the solve five to seven times more sensitive to e4m3 noise at
+ * EVERY GEMM site (2.9e-4 mel-MSE at full depth / NFE 32 against the 1e-4 target; no single site stays under it with margin), so fp8 does
+ * not ship for such weights.  0 = run fp8 regardless), "fp8_sites" (mask of the GEMM sites of a block that take fp8 operands when
+ * "fp8" = 1: 1 QKV, 2 out-projection, 4 FF1, 8 FF2; default 15).
  * counters since creation, for tools and tests: "graph_captures", "graph_instantiates", "graph_updates", "graph_update_failures",
  * "graph_evictions", "graph_buckets", "fp8_outlier_channels" (residual channels flagged by the guard; -1 before the first fp8 prepare),
- * "fp8_gemms_kept_bf16" (GEMMs per DiT block the guard keeps on bf16: 0 or 2) */
+ * "fp8_gemms_kept_bf16" (GEMMs per DiT block that run on bf16 operands while "fp8" = 1: 0, or 4 when the guard tripped) */
 int lemas_dit_get_stat(lemas_dit* m, const char* key, int64_t* value);
 /* synchronises the device and returns 0, or LEMAS_E_STATE when a device-side wait of this engine gave up (fused LayerNorm tail):
  * every result since then is invalid and prepare() / solve() refuse to run */

@@ -53,18 +53,25 @@ struct lemas_dit {
   // are e4m3 with one fp32 scale per output channel, the activations stay bf16.  Run as the bf16 kernels on the dequantised weights: the
   // same numbers a weights-only fp8 kernel would produce, next to the MXFP8 path that also quantises the activations
   bool fp8_wonly = false, fp8_wonly_ready = false;
-  // fp8 OUTLIER GUARD (option "fp8_outlier_guard", default on).  e4m3 has a 2^-4 relative step; a GEMM output stays accurate because
-  // ~1000 products of similar size average that noise.  When a few residual-stream channels are tens of times larger than the rest
-  // (trained DiT checkpoints have them; synth.synth_cfm_state_dict(outlier=...) reproduces the mechanism: rows of attn.to_out / ff.2
-  // scaled up), the LayerNorm outputs that feed the QKV and FF1 GEMMs are dominated by those few channels and the products with them
-  // are NOT averaged: measured against the reference at full depth and NFE 32, 1 % of the channels x30 takes the fp8 path from 5.9e-5 to
-  // 2.9e-4 mel-MSE (weights-only fp8: 2.2e-4) -- over the 1e-4 target (profiles/r04_fp8_outlier_points.txt).  The residual-writing
-  // projections' per-output-channel weight scales, which quantize_fp8() computes anyway, show such channels; when any channel's scale is
-  // more than 8x the median, the two GEMMs behind the LayerNorms keep bf16 operands (their LayerNorm launches write bf16) and only the
-  // out-projection and FF2 -- whose inputs, attention output and GELU(FF1), carry no such channels -- run on fp8.
+  // fp8 OUTLIER GUARD (option "fp8_outlier_guard", default on).  Trained DiT checkpoints carry a few residual-stream channels tens of times
+  // larger than the rest; synth.synth_cfm_state_dict(outlier=...) reproduces the mechanism (rows of attn.to_out / ff.2, weight and bias,
+  // scaled up).  Measured against the reference's own output at full depth and NFE 32 (tests/golden/configs0_outlier_nfe32.npz, 1 % of the
+  // channels x30; profiles/r04_fp8_outlier_points.txt): bf16 3.9e-6, the fp8 path 2.9e-4 (weights-only fp8 2.2e-4) against the 1e-4
+  // target -- and no part of it is safe to keep: ONE GEMM site on fp8 with the other three on bf16 gives 6.4e-5 (QKV), 8.4e-5
+  // (out-projection), 1.15e-4 (FF1), 1.05e-4 (FF2), five to seven times what the same site costs on weights without outliers.  So fp8 does
+  // not ship for such checkpoints: quantize_fp8() already computes the per-output-channel scales of the residual-writing projections,
+  // which show the outlier channels (scale > 8x the median over channels), and when there are any the engine keeps every block GEMM on its
+  // bf16 operands although "fp8" is on (the result is then the bf16 path's, bit for bit).  `fp8_outlier_channels` / `fp8_gemms_kept_bf16`
+  // (lemas_dit_get_stat) tell the caller.  What the guard watches is this one mechanism; outliers made elsewhere (a modulation scale, the
+  // text embedding) are not seen -- a first-contact item for real checkpoints.
   bool fp8_guard = true, fp8_guard_tripped = false;
   int fp8_outlier_channels = 0;
-  bool f8_ln_fed() const { return fp8 && !(fp8_guard && fp8_guard_tripped); }     // QKV and FF1 on fp8 operands?
+  // which of a block's four GEMM sites take fp8 operands (bit 0 QKV, 1 out-projection, 2 FF1, 3 FF2): option "fp8_sites" (default all),
+  // narrowed by the guard.  Each site's input comes from its own producer (LayerNorm 1, attention, LayerNorm 2, FF1's epilogue), so the
+  // four choices are independent.
+  int fp8_sites_opt = 15;
+  int fp8_sites() const { return !fp8 ? 0 : (fp8_guard && fp8_guard_tripped) ? 0 : fp8_sites_opt; }
+  bool f8_ln_fed() const { return (fp8_sites() & 0b0101) == 0b0101; }     // QKV and FF1 both on fp8 operands
   // measurement options (per engine; changing one drops the cached graphs): explicit tile ids for the block GEMMs with N == 1024 /
   // N == 2048, for the fused QK+V launch, and the XCD block grid of the tile order; 0 = the production choice
   int opt_tile_n1024 = 0, opt_tile_n2048 = 0, opt_tile_qkv = 0, opt_xcd_gx = 0;
@@ -809,7 +816,8 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     uint8_t* ff8 = fp8 ? d_ff8.as<uint8_t>() + r0 * ffd : nullptr;
     uint8_t* ffmx = fp8 ? d_ffmx.as<uint8_t>() + r0 * (ffd / 32) : nullptr;
     // which of the block's GEMMs take fp8 operands: all of them, or (outlier guard tripped) only the two whose inputs are not LayerNorm outputs
-    const bool f8_ln = f8_ln_fed(), f8_res = fp8;
+    const int sites = fp8_sites();
+    const bool f8_qkv = sites & 1, f8_out = sites & 2, f8_ff1 = sites & 4, f8_ff2 = sites & 8;
     g.concurrency = lanes;
     g.xcd_gx = opt_xcd_gx;
     auto tile_for = [&](int n) { return fp8 ? 0 : n == 1024 ? opt_tile_n1024 : n == 2048 ? opt_tile_n2048 : 0; };
@@ -835,7 +843,7 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
       g.ln_part = lnpart; g.ln_np = d / 32;
     } else if (!(fuse_ln && l > 0)) {      // fused: block l's attn_norm rows were written by block l-1's FF2 launch
       RC_TRY(pbegin(PC_LN, q));
-      if (f8_ln) HIP_TRY(launch_ln_mod_f8(xres, h8, hmx, rows, d, tab, tab_stride, base + d, base, step, q));
+      if (f8_qkv) HIP_TRY(launch_ln_mod_f8(xres, h8, hmx, rows, d, tab, tab_stride, base + d, base, step, q));
       else HIP_TRY(launch_ln_mod(xres, hbf, rows, d, tab, tab_stride, base + d, base, step, q));
       RC_TRY(pend(q));
     }
@@ -846,11 +854,11 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     if (fuse_qkv) {
       GemmParams gq = g, gv = g;
       RC_TRY(pkernel(PC_GEMM_QKV, &gq.ev_start, &gq.ev_stop));
-      operands(f8_ln, hbf, h8, hmx, w.wqkv, w.wqkv8, w.sqkv, w.wqkvq, 0, d);
+      operands(f8_qkv, hbf, h8, hmx, w.wqkv, w.wqkv8, w.sqkv, w.wqkvq, 0, d);
       gq.A = g.A; gq.a_mx = g.a_mx; gq.W = g.W; gq.w_scale = g.w_scale; gq.f8 = g.f8;
       gq.bias = w.bqkv.as<float>(); gq.N = 2 * in; gq.K = d; gq.n_valid = 2 * in; gq.kv_len = nullptr;
       gq.lnc1_off = fo; gq.lnc2_off = fo + 3 * in; gv.lnc1_off = fo + 2 * in; gv.lnc2_off = fo + 5 * in;
-      operands(f8_ln, hbf, h8, hmx, w.wqkv, w.wqkv8, w.sqkv, w.wqkvq, (size_t)2 * in, d);
+      operands(f8_qkv, hbf, h8, hmx, w.wqkv, w.wqkv8, w.sqkv, w.wqkvq, (size_t)2 * in, d);
       gv.A = g.A; gv.a_mx = g.a_mx; gv.W = g.W; gv.w_scale = g.w_scale; gv.f8 = g.f8;
       gv.bias = w.bqkv.as<float>() + 2 * in; gv.N = in; gv.K = d; gv.n_valid = in; gv.kv_len = nullptr;
       gq.tile = gv.tile = opt_tile_qkv;
@@ -864,26 +872,26 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
       g.K = d;
     } else {
       RC_TRY(pkernel(PC_GEMM_QK, &g.ev_start, &g.ev_stop));
-      operands(f8_ln, hbf, h8, hmx, w.wqkv, w.wqkv8, w.sqkv, w.wqkvq, 0, d);
+      operands(f8_qkv, hbf, h8, hmx, w.wqkv, w.wqkv8, w.sqkv, w.wqkvq, 0, d);
       g.bias = w.bqkv.as<float>(); g.N = 2 * in; g.K = d; g.n_valid = 2 * in;
       g.kv_len = nullptr; g.tile = tile_for(g.N); g.lnc1_off = fo; g.lnc2_off = fo + 3 * in;
       TL_SLOT(g);
       HIP_TRY(launch_gemm_bf16(EPI_QK_ROPE, g, q));
       RC_TRY(pkernel(PC_GEMM_V, &g.ev_start, &g.ev_stop));
-      operands(f8_ln, hbf, h8, hmx, w.wqkv, w.wqkv8, w.sqkv, w.wqkvq, (size_t)2 * in, d);
+      operands(f8_qkv, hbf, h8, hmx, w.wqkv, w.wqkv8, w.sqkv, w.wqkvq, (size_t)2 * in, d);
       g.bias = w.bqkv.as<float>() + 2 * in; g.N = in; g.n_valid = in; g.tile = tile_for(g.N); g.lnc1_off = fo + 2 * in; g.lnc2_off = fo + 5 * in;
       TL_SLOT(g);
       HIP_TRY(launch_gemm_bf16(EPI_V_T, g, q));
     }
     g.ln_part = nullptr;
     RC_TRY(pkernel(PC_ATTN, &at.ev_start, &at.ev_stop));
-    at.out8 = f8_res ? a8 : nullptr; at.out_mx = f8_res ? amx : nullptr;
+    at.out8 = f8_out ? a8 : nullptr; at.out_mx = f8_out ? amx : nullptr;
     TL_SLOT(at);
     RC_TRY(skew_pre(ln, q));
     HIP_TRY(launch_attention(at, q));
     RC_TRY(skew_post(ln, q));
     RC_TRY(pkernel(PC_GEMM_OUT, &g.ev_start, &g.ev_stop));
-    operands(f8_res, abf, a8, amx, w.wo, w.wo8, w.so, w.woq, 0, in);
+    operands(f8_out, abf, a8, amx, w.wo, w.wo8, w.so, w.woq, 0, in);
     g.bias = w.bo; g.N = d; g.K = in; g.n_valid = d;
     g.out_f32 = xres; g.ldc = d; g.gate_off = base + 2 * d; g.kv_len = has_len ? d_len.as<int>() : nullptr; g.tile = tile_for(g.N);
     if (fuse_ln) {   // ff_norm (modules.py:637) as the tail of the out-projection launch
@@ -897,22 +905,22 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     g.ln_out = nullptr; g.xs_out = nullptr;
     if (!fuse_ln && !fold) {
       RC_TRY(pbegin(PC_LN, q));
-      if (f8_ln) HIP_TRY(launch_ln_mod_f8(xres, h8, hmx, rows, d, tab, tab_stride, base + 4 * d, base + 3 * d, step, q));
+      if (f8_ff1) HIP_TRY(launch_ln_mod_f8(xres, h8, hmx, rows, d, tab, tab_stride, base + 4 * d, base + 3 * d, step, q));
       else HIP_TRY(launch_ln_mod(xres, hbf, rows, d, tab, tab_stride, base + 4 * d, base + 3 * d, step, q));
       RC_TRY(pend(q));
     }
     RC_TRY(pkernel(PC_GEMM_FF1, &g.ev_start, &g.ev_stop));
-    operands(f8_ln, hbf, h8, hmx, w.w1, w.w18, w.s1, w.w1q, 0, d);
+    operands(f8_ff1, hbf, h8, hmx, w.w1, w.w18, w.s1, w.w1q, 0, d);
     g.bias = w.b1; g.N = ffd; g.K = d; g.n_valid = ffd;
     g.out_bf16 = ffb; g.out_f8 = ff8; g.out_mx = ffmx; g.ldc = ffd; g.kv_len = nullptr; g.tile = tile_for(g.N);
     if (fold) { g.ln_part = lnpart; g.lnc1_off = fo + 6 * in; g.lnc2_off = fo + 6 * in + ffd; }
     TL_SLOT(g);
     RC_TRY(skew_pre(ln, q));
-    HIP_TRY(launch_gemm_bf16(f8_res ? EPI_BIAS_GELU_F8 : EPI_BIAS_GELU_BF16, g, q));       // FF2 consumes MXFP8 whenever the path is fp8
+    HIP_TRY(launch_gemm_bf16(f8_ff2 ? EPI_BIAS_GELU_F8 : EPI_BIAS_GELU_BF16, g, q));       // FF1 writes what FF2 reads
     RC_TRY(skew_post(ln, q));
     g.ln_part = nullptr;
     RC_TRY(pkernel(PC_GEMM_FF2, &g.ev_start, &g.ev_stop));
-    operands(f8_res, ffb, ff8, ffmx, w.w2, w.w28, w.s2, w.w2q, 0, ffd);
+    operands(f8_ff2, ffb, ff8, ffmx, w.w2, w.w28, w.s2, w.w2q, 0, ffd);
     g.bias = w.b2; g.N = d; g.K = ffd; g.n_valid = d;
     g.out_f32 = xres; g.ldc = d; g.gate_off = base + 5 * d; g.tile = tile_for(g.N);
     if (fuse_ln) {   // the next block's attn_norm (modules.py:314: shift, scale first), or the final norm (:335: scale, shift) after the last
@@ -995,7 +1003,7 @@ int lemas_dit::step_graph(hipStream_t s, hipGraphExec_t* exec, hipEvent_t* done)
     graph_generation = moved;
   }
   char key[112];
-  snprintf(key, sizeof key, "B%d_P%d_cfg%d_len%d_dual%d_f8%d_ln%d_av%d", B, pitch, (int)use_cfg, (int)has_len, (int)dual, fp8 ? (f8_ln_fed() ? 1 : 3) : fp8_wonly ? 2 : 0,
+  snprintf(key, sizeof key, "B%d_P%d_cfg%d_len%d_dual%d_f8%d_ln%d_av%d", B, pitch, (int)use_cfg, (int)has_len, (int)dual, fp8 ? 16 + fp8_sites() : fp8_wonly ? 2 : 0,
            (int)ln_fused + 2 * (int)fold_on(), attn_variant);
   auto it = graphs.find(key);
   if (it == graphs.end()) {
@@ -1176,6 +1184,12 @@ int lemas_dit_set_option(lemas_dit* m, const char* key, int64_t value) {
   }
   if (!strcmp(key, "graph_update")) { m->graph_update = value != 0; return 0; }
   if (!strcmp(key, "fp8_outlier_guard")) { m->fp8_guard = value != 0; m->drop_graphs(); return 0; }
+  if (!strcmp(key, "fp8_sites")) {
+    if (value < 0 || value > 15) { set_error("lemas_dit_set_option: fp8_sites is a mask of GEMM sites (1 QKV, 2 out-projection, 4 FF1, 8 FF2), 0 .. 15"); return LEMAS_E_ARG; }
+    m->fp8_sites_opt = (int)value;
+    m->drop_graphs();
+    return 0;
+  }
   if (!strcmp(key, "profile")) {
     m->profile = value != 0;
     for (auto& r : m->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -1195,7 +1209,7 @@ int lemas_dit_get_stat(lemas_dit* m, const char* key, int64_t* value) {
   if (!strcmp(key, "graph_evictions")) { *value = m->n_evict; return 0; }
   if (!strcmp(key, "graph_buckets")) { *value = (int64_t)m->graphs.size(); return 0; }
   if (!strcmp(key, "fp8_outlier_channels")) { *value = m->fp8_ready ? m->fp8_outlier_channels : -1; return 0; }      // -1: weights not quantised yet
-  if (!strcmp(key, "fp8_gemms_kept_bf16")) { *value = (m->fp8 && !m->f8_ln_fed()) ? 2 : 0; return 0; }                 // per DiT block
+  if (!strcmp(key, "fp8_gemms_kept_bf16")) { *value = m->fp8 ? 4 - __builtin_popcount(m->fp8_sites()) : 0; return 0; }       // per DiT block
   set_error("lemas_dit_get_stat: unknown counter '%s'", key);
   return LEMAS_E_ARG;
 }

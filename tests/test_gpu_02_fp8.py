@@ -197,9 +197,9 @@ def test_fp8_cost_of_quantising_activations_and_outlier_stress(golden_dir, name,
 def test_fp8_outlier_guard(golden_dir):
     """Activation outliers at a PRODUCTION step count (tests/golden/configs0_outlier_nfe32.npz: the reference's own output at full depth,
     NFE 32, on weights whose residual-writing projections scale 1 % of the channels x30 -- oracle/gen_golden.py --full-size).  Unguarded,
-    the fp8 path misses the 1e-4 target there (2.9e-4; the few outlier products are not averaged over K).  With the guard (default) the
-    engine sees the outlier channels in the per-channel weight scales, keeps the two LayerNorm-fed GEMMs of every block on bf16 operands
-    and meets the target; on weights without such channels the guard changes nothing."""
+    the fp8 path misses the 1e-4 target there (2.9e-4), and so does every partial form worth having (profiles/r04_fp8_outlier_points.txt).
+    With the guard (default) the engine sees the outlier channels in the per-channel weight scales and keeps the block GEMMs on bf16
+    operands: "fp8" = 1 then gives the bf16 path's bits and meets the target; on weights without such channels the guard changes nothing."""
     import test_gpu_00_sample as T
     from lemas_tts_amd import synth
     from lemas_tts_amd.model.cfm import CFM
@@ -207,21 +207,23 @@ def test_fp8_outlier_guard(golden_dir):
     fx = synth.expand_reference_fixture(fx)
     m = CFM(arch, int(fx["vocab"]), sd, device=DEV)
     args, kw = _golden_args(fx)
-    got = {}
+    got, outs = {}, {}
     for guard in (0, 1):
         m.engine.set_option("fp8_outlier_guard", guard)
         m.engine.set_option("fp8", 1)
         out, _ = m.sample(*args, use_acc_grl=False, **kw)
-        got[guard] = T._gen_mse(out.cpu().numpy(), fx["out"], fx)
-        assert m.engine.stat("fp8_gemms_kept_bf16") == (2 if guard else 0)
+        outs[guard] = out.cpu().numpy()
+        got[guard] = T._gen_mse(outs[guard], fx["out"], fx)
+        assert m.engine.stat("fp8_gemms_kept_bf16") == (4 if guard else 0)
     n_out = m.engine.stat("fp8_outlier_channels")
     m.engine.set_option("fp8", 0)
     out, _ = m.sample(*args, use_acc_grl=False, **kw)
     bf16 = T._gen_mse(out.cpu().numpy(), fx["out"], fx)
     print(f"\n[fp8 outlier guard, NFE 32, {n_out} outlier channels] mel-MSE vs reference: bf16 {bf16:.3e}  fp8 unguarded {got[0]:.3e}  fp8 guarded {got[1]:.3e}")
     assert 5 <= n_out <= 20                   # 1 % of 1024 channels
-    assert bf16 <= 1e-4 and got[1] <= 1e-4, (bf16, got)
-    assert got[1] < got[0]
+    assert bf16 <= 1e-4 and got[1] <= 1e-4, (bf16, got)      # THE tolerance (BASELINE.json), not a multiple of what was measured
+    assert got[0] > 1e-4                      # what the guard is there for (if this ever passes unguarded, the guard can go)
+    np.testing.assert_array_equal(outs[1], out.cpu().numpy())
     del m
     # no outlier channels: the guard does not trip and the fp8 path is bit-for-bit what it was
     fx2, arch2, sd2 = T._load(golden_dir, "mini_plain")
