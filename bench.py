@@ -310,7 +310,14 @@ def run_job(a, w, model, vocoder, rank, world, dist, comm_device, device, bcast)
                 torch.from_numpy(synth.synth_noise(5000 + i, N)))
     job = [make(i) for i in range(U)] if rank == 0 else None
 
+    from lemas_tts_amd.parallel import gather_to_rank0, scatter_from_rank0
     MB = w["B"]           # utterances per CFM.sample batch: configs[3]'s per-GPU batch of 8; a rank with a longer shard runs it in turns
+
+    def pack(idx):        # a shard as two flat tensors: [cond | y0] fp32, token ids int64
+        return [torch.cat([torch.stack([job[i][0] for i in idx]).reshape(-1), torch.stack([job[i][2] for i in idx]).reshape(-1)]),
+                torch.stack([job[i][1] for i in idx]).reshape(-1)]
+    packed = [pack(shards[r]) for r in range(world)] if rank == 0 else None        # rank 0 owns the job, already laid out per shard
+    like = [torch.empty(per * (F_ + N) * 100, dtype=torch.float32), torch.empty(per * nt, dtype=torch.int64)]
 
     def once():
         t = {}
@@ -318,24 +325,8 @@ def run_job(a, w, model, vocoder, rank, world, dist, comm_device, device, bcast)
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        # ---- scatter: rank 0 sends each rank its shard (cond | y0 as one fp32 buffer, tokens as int64), point to point
-        nf = per * (F_ + N) * 100
-
-        def pack(idx):
-            return (torch.cat([torch.stack([job[i][0] for i in idx]).reshape(-1), torch.stack([job[i][2] for i in idx]).reshape(-1)]),
-                    torch.stack([job[i][1] for i in idx]).reshape(-1))
-        if rank == 0:
-            for r in range(1, world):
-                fb, tb = pack(shards[r])
-                dist.send(fb.to(comm_device), dst=r)
-                dist.send(tb.to(comm_device), dst=r)
-            fbuf, tbuf = pack(shards[0])
-            fbuf, tbuf = fbuf.to(comm_device), tbuf.to(comm_device)
-        else:
-            fbuf = torch.empty(nf, dtype=torch.float32, device=comm_device)
-            tbuf = torch.empty(per * nt, dtype=torch.int64, device=comm_device)
-            dist.recv(fbuf, src=0)
-            dist.recv(tbuf, src=0)
+        # ---- scatter: rank 0 sends each rank its shard
+        fbuf, tbuf = scatter_from_rank0(packed, like, dist if world > 1 else None, comm_device)
         cond = fbuf[: per * F_ * 100].reshape(per, F_, 100).to(device)
         y0 = fbuf[per * F_ * 100:].reshape(per, N, 100).to(device)
         text = tbuf.reshape(per, nt).cpu()
@@ -354,17 +345,12 @@ def run_job(a, w, model, vocoder, rank, world, dist, comm_device, device, bcast)
         t["compute_ms"] = 1e3 * (time.perf_counter() - t1)
         # ---- gather: waveforms back to rank 0's host
         t2 = time.perf_counter()
-        wbuf = wav.to(comm_device).contiguous()
+        got = gather_to_rank0(wav, dist if world > 1 else None, comm_device)
         host = None
         if rank == 0:
             host = torch.empty((U, HOP * (L - 1)), dtype=torch.float32)
-            host[torch.tensor(shards[0])] = wbuf.cpu()
-            for r in range(1, world):
-                got = torch.empty_like(wbuf)
-                dist.recv(got, src=r)
-                host[torch.tensor(shards[r])] = got.cpu()
-        else:
-            dist.send(wbuf, dst=0)
+            for r in range(world):
+                host[torch.tensor(shards[r])] = got[r]
         torch.cuda.synchronize()
         t["gather_ms"] = 1e3 * (time.perf_counter() - t2)
         t["job_ms"] = 1e3 * (time.perf_counter() - t0)
@@ -396,7 +382,7 @@ def run_job(a, w, model, vocoder, rank, world, dist, comm_device, device, bcast)
             "n_gpus": world, "steps": max(a.steps, 1), "warmup": max(a.warmup, 1), "ms_per_step": job_ms, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "fp8" if a.fp8 else "bf16", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[3] as a job: {U} utterances of 4 s ref + 8 s target (F={F_}, N={N}) owned by rank 0, dealt to "
-                                   f"{world} rank(s) ({U // world} per rank as one batch), NFE={nfe}, CFG={CFG}, waveforms gathered on rank 0's host",
+                                   f"{world} rank(s) ({U // world} per rank, run as batches of {MB}), NFE={nfe}, CFG={CFG}, waveforms gathered on rank 0's host",
                        "workload_key": "configs3_full", "utterances_total": U, "utterances_per_rank": U // world, "utterances_per_batch": MB,
                        "batches_per_rank": (U // world + MB - 1) // MB,
                        "parallelism": f"dp{world}: scatter inputs -> per-rank CFM.sample batch + Vocos decode -> gather waveforms; no step-loop collective",

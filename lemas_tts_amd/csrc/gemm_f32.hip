@@ -8,7 +8,7 @@
 //     step (modules.py:311,332,727-731) -- the t-grid is known up front;
 //   * once per ODE step: the K=100 "x" part of the input projection (keeps the ODE state path in fp32);
 //   * the Vocos vocoder (all of it: embed conv as im2col GEMM, pointwise convs, head, inverse DFT).
-// Tile TM x 64 x 32 (TM = 64, or 32 when a 64-row grid would leave most CUs idle), 4 waves as 2x2, each wave (TM/2) x 32 outputs.
+// Tile TM x 64 x 32 (TM = 64; 32 for problems of at most 32 rows), 4 waves as 2x2, each wave (TM/2) x 32 outputs.
 // LDS tiles are row-major [row][32 k + 4 pad]: a thread parks the float4 it loaded with ONE ds_write_b128 and a lane fetches the four k
 // values of its (row, k-group) with ONE ds_read_b128 (the 16 lanes of a read group hit 16 different 4-bank groups: row pitch 36 words), i.e.
 // MFMA j of a 16-k half takes k = 4 lk + j instead of 4 j + lk -- A and W use the same assignment, so every product meets its partner and only
@@ -169,9 +169,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Params p) {
 template <int EPI>
 hipError_t launch(const GemmF32Params& p, hipStream_t s) {
   const int gn = (p.N + TN - 1) / TN, nb = p.nbatch > 0 ? p.nbatch : 1;
-  // 64-row tiles unless they leave the chip mostly idle (the vocoder's N = 512 convolutions at L ~ 900: 120 workgroups): then 32-row tiles
-  if ((long)gn * ((p.M + 63) / 64) * nb < 200 && p.M > 32) {
-    hipLaunchKernelGGL((gemm_f32_kernel<EPI, 32>), dim3(gn, (p.M + 31) / 32, nb), dim3(256), 0, s, p);
+  // 64-row tiles; the 32-row form only for problems of at most 32 rows (the per-utterance GEMVs: prosody projections, the time MLP).  Measured:
+  // for the vocoder's N = 512 convolutions at L ~ 900 (120 workgroups of 64 rows against 240 of 32) the taller tile is the faster one,
+  // 59 vs 66 us (profiles/r04a_kernel_stats_configs1.txt) -- more workgroups do not help a loop whose K-tiles are a dependent chain
+  if (p.M <= 32) {
+    hipLaunchKernelGGL((gemm_f32_kernel<EPI, 32>), dim3(gn, 1, nb), dim3(256), 0, s, p);
   } else {
     hipLaunchKernelGGL((gemm_f32_kernel<EPI, 64>), dim3(gn, (p.M + 63) / 64, nb), dim3(256), 0, s, p);
   }

@@ -90,6 +90,39 @@ def run_sharded(utterances: Sequence, lengths: Sequence[int], fn, dist) -> Optio
     return out
 
 
+def scatter_from_rank0(per_rank: Optional[Sequence[Sequence[torch.Tensor]]], like: Sequence[torch.Tensor], dist, device) -> List[torch.Tensor]:
+    """Rank 0 holds ``per_rank[r]`` = the tensors of rank r's shard (e.g. [cond | y0 floats, token ids]); every rank returns its own, on
+    ``device``.  ``like`` gives the shapes / dtypes a non-zero rank receives into.  Point to point (send / recv): the shards differ per
+    rank and nothing else needs them -- the job's only traffic besides the weight broadcast and the gather below (the
+    reference's precedent hands each GPU worker its own file list, uvr5/multiprocess_cuda_infer.py:404-420)."""
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None else (0, 1)
+    dev = torch.device(device)
+    if rank == 0:
+        for r in range(1, world):
+            for t in per_rank[r]:
+                dist.send(t.to(dev).contiguous(), dst=r)
+        return [t.to(dev) for t in per_rank[0]]
+    out = [torch.empty(tuple(t.shape), dtype=t.dtype, device=dev) for t in like]
+    for t in out:
+        dist.recv(t, src=0)
+    return out
+
+
+def gather_to_rank0(t: torch.Tensor, dist, device) -> Optional[List[torch.Tensor]]:
+    """Every rank's equally shaped result tensor (its shard's waveforms) -> a list on rank 0 (host tensors), None elsewhere."""
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None else (0, 1)
+    buf = t.to(torch.device(device)).contiguous()
+    if rank != 0:
+        dist.send(buf, dst=0)
+        return None
+    out = [buf.cpu()]
+    for r in range(1, world):
+        got = torch.empty_like(buf)
+        dist.recv(got, src=r)
+        out.append(got.cpu())
+    return out
+
+
 def gpu_numa_cpus(device_index: int):
     """(numa_node, cpu list) of the host NUMA node GPU ``device_index`` hangs off, from sysfs
     (``/sys/bus/pci/devices/<bdf>/{numa_node,local_cpulist}``); (None, None) when the platform does not say."""

@@ -79,3 +79,49 @@ def test_two_rank_sharded_run_matches_single_rank():
     assert all(g[0] for g in got), "weight broadcast changed the tensors"
     r0 = [g for g in got if g[1] is not None][0]
     assert r0[1] and r0[2] == 5, "sharded results differ from the single-rank run"
+
+
+def _job_worker(rank, world, port, q):
+    """the sharded JOB's data movement (bench.py --job configs3_full): rank 0 owns every utterance, shards go out point to point,
+    per-utterance results come back to rank 0 in input order"""
+    from lemas_tts_amd.parallel import gather_to_rank0, scatter_from_rank0
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    U, F_, nt = 12, 7, 5
+    shards = shard_utterances([100] * U, world)
+    per = len(shards[rank])
+    packed = None
+    if rank == 0:
+        job = [(torch.full((F_, 3), float(i)), torch.full((nt,), i, dtype=torch.int64)) for i in range(U)]
+        packed = [[torch.stack([job[i][0] for i in sh]).reshape(-1), torch.stack([job[i][1] for i in sh]).reshape(-1)] for sh in shards]
+    like = [torch.empty(per * F_ * 3), torch.empty(per * nt, dtype=torch.int64)]
+    fbuf, tbuf = scatter_from_rank0(packed, like, dist, "cpu")
+    mine = fbuf.reshape(per, F_, 3)
+    ok_in = all(float(mine[b, 0, 0]) == float(i) and int(tbuf.reshape(per, nt)[b, 0]) == i for b, i in enumerate(shards[rank]))
+    res = mine.sum(dim=(1, 2))[:, None] * 2.0                  # "waveform" of each utterance: a function of its own input only
+    got = gather_to_rank0(res, dist, "cpu")
+    if rank == 0:
+        host = torch.empty(U, 1)
+        for r in range(world):
+            host[torch.tensor(shards[r])] = got[r]
+        q.put((ok_in, bool(torch.equal(host[:, 0], torch.arange(U).float() * F_ * 3 * 2.0))))
+    else:
+        q.put((ok_in, got is None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3])
+def test_job_scatter_and_gather_over_gloo(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_job_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(a and b for a, b in got), got
