@@ -408,6 +408,11 @@ def main():
     ap.add_argument("--job", choices=["configs3_full"], default=None, help="run the SHARDED JOB instead of the weak-scaling step: rank 0 owns "
                     "BASELINE configs[3]'s 64 utterances, deals them to the ranks, gathers the waveforms on its host (see run_job)")
     ap.add_argument("--attn-variant", type=int, default=-1, help="engine option attn_variant (-1 = engine default)")
+    ap.add_argument("--no-phases", action="store_true", help="skip the serial hoists / step loop / vocoder / D2H timing after the timed region "
+                    "(profiler passes: rocprofv3 --pmc aborts in that section on the batched workloads, DESIGN.md section 8)")
+    ap.add_argument("--xcd-runs", type=int, default=-1, help="engine measurement option xcd_runs (1 = round 3's GEMM tile order)")
+    ap.add_argument("--graph", type=int, default=-1, help="engine option graph (-1 = engine default: one hipGraph launch per ODE step)")
+    ap.add_argument("--vocoder-graph", type=int, default=-1, help="vocoder option graph (-1 = default: backbone + head replayed as one hipGraph)")
     ap.add_argument("--dual", type=int, default=1, help="1 = CFG branches as two concurrent lanes (default), 0 = one stream")
     ap.add_argument("--overlap", type=int, default=1, help="1 = Vocos decode + D2H of utterance i on a side stream under the step loop of "
                     "utterance i+1 (default), 0 = strictly serial")
@@ -486,6 +491,10 @@ def main():
     model = CFM(arch, VOCAB, sd, device=device, use_prosody_encoder=w["prosody"])
     if a.attn_variant >= 0:
         model.engine.set_option("attn_variant", a.attn_variant)
+    if a.graph >= 0:
+        model.engine.set_option("graph", a.graph)
+    if a.xcd_runs >= 0:
+        model.engine.set_option("xcd_runs", a.xcd_runs)
     model.engine.set_option("dual", a.dual)
     model.engine.set_option("fp8", a.fp8)
     if a.ln_fused >= 0:
@@ -494,6 +503,8 @@ def main():
         model.engine.set_option("ln_fold", a.ln_fold)
     model.engine.set_option("table_cache", 0)      # hoists are redone for every utterance: nothing cached across steps
     vocoder = VocosEngine(vsd, device=device)
+    if a.vocoder_graph >= 0:
+        vocoder.set_option("graph", a.vocoder_graph)
     del sd, vsd                                     # the engines own their copies; the broadcast buffer can go
     if a.job:
         result = run_job(a, w, model, vocoder, rank, world, dist, comm_device, device, bcast)
@@ -687,6 +698,15 @@ def main():
         result["kernel_tflops"] = {k: round(class_flops(k, rows, nsq) / (1e3 * v[0] / v[1] * 1e-6) / 1e12, 1) for k, v in mm.items()}
         result["kernel_time_share"] = {k: round(v[0] / total_ms, 4) for k, v in prof.items() if v[1] > 0}
         result["kernel_avg_us"] = {k: round(1e3 * v[0] / v[1], 2) for k, v in prof.items() if v[1] > 0}
+
+        if a.no_phases:
+            if dist:
+                dist.barrier()
+                dist.destroy_process_group()
+            sys.stdout.flush()
+            os.write(json_fd, (json.dumps(result) + "\n").encode())
+            os.close(json_fd)
+            return
 
         # ---- the other phases of one utterance, serially, with stream events: hoists / step loop / vocoder / D2H
         def timed_ms(fn, reps=3):

@@ -76,6 +76,38 @@ __device__ __forceinline__ unsigned int pack_fp8x4(float a, float b, float c, fl
   return (unsigned int)v;
 }
 
+// ---- XCD-aware tile order of the GEMM launches (gemm_bf16.hip, gemm_f32.hip) -------------------------------------------------------
+// Workgroups are dispatched round-robin over the 8 XCDs (private, non-coherent L2s): workgroup `bid` runs on XCD bid & 7.  The tile grid is cut
+// into gx x gy blocks (gx * gy = 8), one per XCD, so that an XCD fetches 1 / gx of the A panels and 1 / gy of the W panels instead of all of
+// both; workgroup `bid` takes tile (bid >> 3) of block (bid & 7), the launch holds 8 x (largest block) workgroups and the few beyond a
+// smaller block's end return at once.
+__host__ __device__ __forceinline__ int xcd_grid(int tiles_m, int tiles_n, int gx) {
+  const int gy = 8 / gx;
+  const int bm = (tiles_m + gx - 1) / gx, bn = (tiles_n + gy - 1) / gy;
+  return 8 * bm * bn;
+}
+__device__ __forceinline__ bool xcd_tile_coords(int bid, int tiles_m, int tiles_n, int gx, int& tm, int& tn) {
+  const int gy = 8 / gx;
+  const int bm = (tiles_m + gx - 1) / gx, bn = (tiles_n + gy - 1) / gy;
+  const int blk = bid & 7, idx = bid >> 3;
+  const int bi = blk / gy, bj = blk - bi * gy;
+  const int rows = min(bm, tiles_m - bi * bm), cols = min(bn, tiles_n - bj * bn);
+  if (rows <= 0 || cols <= 0 || idx >= rows * cols) return false;
+  tm = bi * bm + idx / cols;
+  tn = bj * bn + idx % cols;
+  return true;
+}
+// XCD block grid: fabric-side fetch ~ gy * |A| + gx * |W| -> minimise gy * M + gx * N
+static inline int pick_xcd_gx(int M, int N) {
+  int best = 8;
+  long cost = -1;
+  for (int gx : {8, 4, 2, 1}) {
+    const long c = (long)(8 / gx) * M + (long)gx * N;
+    if (cost < 0 || c < cost) { cost = c; best = gx; }
+  }
+  return best;
+}
+
 // ---- epilogue selectors of the bf16 MFMA GEMM -------------------------------------------------
 enum GemmEpi : int {
   EPI_BIAS_BF16 = 0,       // out_bf16[m][n] = acc + bias
@@ -131,6 +163,9 @@ struct GemmParams {
   // XCD block grid of the tile order: the tile grid is cut into xcd_gx x (8 / xcd_gx) blocks, one per XCD (gemm_bf16.hip
   // tile_coords).  0 = let the launcher choose (minimises the fabric-side fetch gy * |A| + gx * |W|); 8 = the row-major order.
   int xcd_gx;
+  // measurement switch: != 0 = round 3's tile order (every XCD takes an equal-length RUN of the blocked tile sequence, which straddles blocks of
+  // a ragged grid) instead of one block per XCD; for A/B runs of the two orders in one process (engine option "xcd_runs")
+  int xcd_runs;
   // explicit tile shape (ids as for launch_gemm_bf16_tile; 0 = the production choice).  Set per launch by whoever builds the
   // parameters -- unit tests, kbench, the engine's per-engine measurement options -- never by process-global state.
   int tile;

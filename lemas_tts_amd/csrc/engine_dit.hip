@@ -74,7 +74,7 @@ struct lemas_dit {
   bool f8_ln_fed() const { return (fp8_sites() & 0b0101) == 0b0101; }     // QKV and FF1 both on fp8 operands
   // measurement options (per engine; changing one drops the cached graphs): explicit tile ids for the block GEMMs with N == 1024 /
   // N == 2048, for the fused QK+V launch, and the XCD block grid of the tile order; 0 = the production choice
-  int opt_tile_n1024 = 0, opt_tile_n2048 = 0, opt_tile_qkv = 0, opt_xcd_gx = 0;
+  int opt_tile_n1024 = 0, opt_tile_n2048 = 0, opt_tile_qkv = 0, opt_xcd_gx = 0, opt_xcd_runs = 0;
   // attention schedule variant (attention.hip VAR).  19 = no running max (P = exp2(S) on q prescaled by the QK epilogue, one range check
   // per workgroup with a classical second pass if it trips) + static priority for the younger half-workgroup: 25.9 -> 22.5 us per lane
   // launch at configs[1], +4.6 % end to end (profiles/r03_attention_variants.txt); 0 = the classical online softmax
@@ -820,6 +820,7 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     const bool f8_qkv = sites & 1, f8_out = sites & 2, f8_ff1 = sites & 4, f8_ff2 = sites & 8;
     g.concurrency = lanes;
     g.xcd_gx = opt_xcd_gx;
+    g.xcd_runs = opt_xcd_runs;
     auto tile_for = [&](int n) { return fp8 ? 0 : n == 1024 ? opt_tile_n1024 : n == 2048 ? opt_tile_n2048 : 0; };
     // A / W / their scales for one GEMM: bf16 operands, or (f8) MXFP8 activations x per-channel-scaled e4m3 weights
     auto operands = [&](bool f8, const bf16_t* abf16, const uint8_t* af8, const uint8_t* afmx, const DevBuf& wb, const DevBuf& w8, const DevBuf& wsc,
@@ -1145,7 +1146,7 @@ int lemas_dit_set_option(lemas_dit* m, const char* key, int64_t value) {
   }
   {
     int* slot = !strcmp(key, "tile_n1024") ? &m->opt_tile_n1024 : !strcmp(key, "tile_n2048") ? &m->opt_tile_n2048
-              : !strcmp(key, "tile_qkv") ? &m->opt_tile_qkv : !strcmp(key, "xcd_gx") ? &m->opt_xcd_gx
+              : !strcmp(key, "tile_qkv") ? &m->opt_tile_qkv : !strcmp(key, "xcd_gx") ? &m->opt_xcd_gx : !strcmp(key, "xcd_runs") ? &m->opt_xcd_runs
               : !strcmp(key, "attn_variant") ? &m->attn_variant : !strcmp(key, "lane_skew") ? &m->lane_skew : nullptr;
     if (slot) {
       if (slot == &m->attn_variant && !attention_variant_ok((int)value)) {

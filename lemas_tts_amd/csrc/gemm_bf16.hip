@@ -63,22 +63,19 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // ended in the next and fetched both blocks' panels (out-projection / FF2 at configs[1]: 41.9 MB of fabric reads per launch against 31.3 MB
 // for aligned blocks).  Here workgroup `bid` belongs to XCD bid & 7 = block bid & 7 and takes tile (bid >> 3) of that block; the launch holds
 // 8 x (largest block) workgroups and the few beyond a smaller block's end return at once (xcd_grid / xcd_tile_coords).
-__host__ __device__ __forceinline__ int xcd_grid(int tiles_m, int tiles_n, int gx) {
-  const int gy = 8 / gx;
-  const int bm = (tiles_m + gx - 1) / gx, bn = (tiles_n + gy - 1) / gy;
-  return 8 * bm * bn;
+// (xcd_grid / xcd_tile_coords live in common.h: the fp32 GEMM uses the same mapping)
+// tile of workgroup `bid`: one block per XCD (default) or, for A/B measurements, round 3's equal runs (GemmParams::xcd_runs); false = surplus workgroup
+__device__ __forceinline__ void tile_coords(int seq, int tiles_m, int tiles_n, int gx, int& tm, int& tn);
+__device__ __forceinline__ bool tile_of(int bid, int tiles_m, int tiles_n, int gx, int runs, int& tm, int& tn) {
+  if (runs) {
+    const int nwg = tiles_m * tiles_n;
+    if (bid >= nwg) return false;
+    tile_coords(xcd_remap(bid, nwg), tiles_m, tiles_n, gx, tm, tn);
+    return true;
+  }
+  return xcd_tile_coords(bid, tiles_m, tiles_n, gx, tm, tn);
 }
-__device__ __forceinline__ bool xcd_tile_coords(int bid, int tiles_m, int tiles_n, int gx, int& tm, int& tn) {
-  const int gy = 8 / gx;
-  const int bm = (tiles_m + gx - 1) / gx, bn = (tiles_n + gy - 1) / gy;
-  const int blk = bid & 7, idx = bid >> 3;
-  const int bi = blk / gy, bj = blk - bi * gy;
-  const int rows = min(bm, tiles_m - bi * bm), cols = min(bn, tiles_n - bj * bn);
-  if (rows <= 0 || cols <= 0 || idx >= rows * cols) return false;
-  tm = bi * bm + idx / cols;
-  tn = bj * bn + idx % cols;
-  return true;
-}
+static inline int grid_of(int tiles_m, int tiles_n, int gx, int runs) { return runs ? tiles_m * tiles_n : xcd_grid(tiles_m, tiles_n, gx); }
 __device__ __forceinline__ void tile_coords(int seq, int tiles_m, int tiles_n, int gx, int& tm, int& tn) {
   const int gy = 8 / gx;
   const int bm = (tiles_m + gx - 1) / gx, bn = (tiles_n + gy - 1) / gy;
@@ -1418,7 +1415,7 @@ template <int EPI>
 __global__ __launch_bounds__(512) void gemm_pp2_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int tm, tn;
-  if (!xcd_tile_coords(blockIdx.x, (p.M + 255) / 256, p.N / 128, p.xcd_gx, tm, tn)) return;
+  if (!tile_of(blockIdx.x, (p.M + 255) / 256, p.N / 128, p.xcd_gx, p.xcd_runs, tm, tn)) return;
   gemm_body_pp2<EPI, EPI != EPI_V_T>(p, smem, tm * 256, tn * 128, reinterpret_cast<float*>(smem + 3 * (256 + 128) * 128));
 }
 
@@ -1430,7 +1427,7 @@ struct LaunchPP2 {
   }
   static hipError_t run(const GemmParams& p, hipStream_t s) {
     if (p.N % 128 != 0 || p.K % 64 != 0) return hipErrorInvalidValue;
-    const dim3 grid(xcd_grid((p.M + 255) / 256, p.N / 128, p.xcd_gx)), block(512);
+    const dim3 grid(grid_of((p.M + 255) / 256, p.N / 128, p.xcd_gx, p.xcd_runs)), block(512);
     // the (r, -r mu) table behind the ring is only there for a ln-fold consumer: every other launch keeps the ring's own footprint
     const int lds_now = p.ln_part ? lds : lds - 256 * 8;
     if (p.ev_start) hipExtLaunchKernelGGL((gemm_pp2_kernel<EPI>), grid, block, lds_now, s, p.ev_start, p.ev_stop, 0, p);
@@ -1443,7 +1440,7 @@ template <int EPI>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int tm, tn;
-  if (!xcd_tile_coords(blockIdx.x, (p.M + 255) / 256, p.N / 256, p.xcd_gx, tm, tn)) return;
+  if (!tile_of(blockIdx.x, (p.M + 255) / 256, p.N / 256, p.xcd_gx, p.xcd_runs, tm, tn)) return;
   gemm_body_pp<EPI, EPI != EPI_V_T>(p, smem, tm * 256, tn * 256, reinterpret_cast<float*>(smem + 8 * 16384));
 }
 
@@ -1456,7 +1453,7 @@ struct LaunchPP {
   }
   static hipError_t run(const GemmParams& p, hipStream_t s) {
     if (p.N % 256 != 0 || p.K % 64 != 0) return hipErrorInvalidValue;
-    const dim3 grid(xcd_grid((p.M + 255) / 256, p.N / 256, p.xcd_gx)), block(512);
+    const dim3 grid(grid_of((p.M + 255) / 256, p.N / 256, p.xcd_gx, p.xcd_runs)), block(512);
     const int lds_now = p.ln_part ? lds : lds - 256 * 8;
     if (p.ev_start) hipExtLaunchKernelGGL((gemm_pp_kernel<EPI>), grid, block, lds_now, s, p.ev_start, p.ev_stop, 0, p);
     else hipLaunchKernelGGL((gemm_pp_kernel<EPI>), grid, block, lds_now, s, p);
@@ -1476,7 +1473,7 @@ template <int EPI, int TBM, int TBN, int NSTAGE, int NWM, int NWN, bool F8>
 __global__ __launch_bounds__(64 * NWM * NWN) void gemm_bf16_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int tm, tn;
-  if (!xcd_tile_coords(blockIdx.x, (p.M + TBM - 1) / TBM, p.N / TBN, p.xcd_gx, tm, tn)) return;
+  if (!tile_of(blockIdx.x, (p.M + TBM - 1) / TBM, p.N / TBN, p.xcd_gx, p.xcd_runs, tm, tn)) return;
   gemm_body<EPI, TBM, TBN, NSTAGE, NWM, NWN, EPI != EPI_V_T, F8>(p, smem, tm * TBM, tn * TBN,
       reinterpret_cast<float*>(smem + body_lds_base<EPI, TBM, TBN, NSTAGE, NWM, NWN, F8>()));
 }
@@ -1521,7 +1518,7 @@ struct Launch {
   static hipError_t run(const GemmParams& p, hipStream_t s) {
     if (p.N % C::BN != 0) return hipErrorInvalidValue;
     const int tiles_m = (p.M + C::BM - 1) / C::BM, tiles_n = p.N / C::BN;
-    const dim3 grid(xcd_grid(tiles_m, tiles_n, p.xcd_gx)), block(64 * C::WM * C::WN);
+    const dim3 grid(grid_of(tiles_m, tiles_n, p.xcd_gx, p.xcd_runs)), block(64 * C::WM * C::WN);
     // without the ln-fold table the launch keeps the ring's own footprint (128 x 128: exactly 96 KB, which with the attention kernel's
     // exact 64 KB is a CU's 160 KB -- measured: sharing or not sharing a CU that way changes nothing, profiles/r03_structural_attempts.txt)
     const int lds_now = p.ln_part ? lds : lds - C::BM * 8;
@@ -1622,11 +1619,11 @@ __global__ __launch_bounds__(64 * TileCfg<TILE>::WM * TileCfg<TILE>::WN) void ge
   float* rs = reinterpret_cast<float*>(smem + QkvLds<F8, TILE>::base);
   int tm, tn;
   if (bid < tiles_q) {       // tiles_q / tiles_v: the PADDED workgroup counts of the two parts (multiples of 8: both parts keep the XCD phase)
-    if (!xcd_tile_coords(bid, (pq.M + C::BM - 1) / C::BM, pq.N / C::BN, pq.xcd_gx, tm, tn)) return;
+    if (!tile_of(bid, (pq.M + C::BM - 1) / C::BM, pq.N / C::BN, pq.xcd_gx, pq.xcd_runs, tm, tn)) return;
     if constexpr (!F8 && TILE == T256x128) gemm_body_pp2<EPI_QK_ROPE, true>(pq, smem, tm * 256, tn * 128, rs);
     else gemm_body<EPI_QK_ROPE, C::BM, C::BN, C::ST, C::WM, C::WN, true, F8>(pq, smem, tm * C::BM, tn * C::BN, rs);
   } else {
-    if (!xcd_tile_coords(bid - tiles_q, (pv.M + C::BM - 1) / C::BM, pv.N / C::BN, pv.xcd_gx, tm, tn)) return;
+    if (!tile_of(bid - tiles_q, (pv.M + C::BM - 1) / C::BM, pv.N / C::BN, pv.xcd_gx, pv.xcd_runs, tm, tn)) return;
     if constexpr (!F8 && TILE == T256x128) gemm_body_pp2<EPI_V_T, false>(pv, smem, tm * 256, tn * 128, rs);
     else gemm_body<EPI_V_T, C::BM, C::BN, C::ST, C::WM, C::WN, false, F8>(pv, smem, tm * C::BM, tn * C::BN, rs);
   }
@@ -1642,7 +1639,7 @@ struct LaunchQkv {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_qkv_fused_kernel<F8, TILE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   }
   static hipError_t run(const GemmParams& pq, const GemmParams& pv, hipStream_t s) {
-    const int tiles_q = xcd_grid((pq.M + C::BM - 1) / C::BM, pq.N / C::BN, pq.xcd_gx), tiles_v = xcd_grid((pv.M + C::BM - 1) / C::BM, pv.N / C::BN, pv.xcd_gx);
+    const int tiles_q = grid_of((pq.M + C::BM - 1) / C::BM, pq.N / C::BN, pq.xcd_gx, pq.xcd_runs), tiles_v = grid_of((pv.M + C::BM - 1) / C::BM, pv.N / C::BN, pv.xcd_gx, pv.xcd_runs);
     const dim3 grid(tiles_q + tiles_v), block(64 * NW);
     const int lds_now = (pq.ln_part || pv.ln_part) ? lds : lds - C::BM * 8;
     if (pq.ev_start)
@@ -1697,17 +1694,6 @@ hipError_t gemm_bf16_init() {
   if ((e = LaunchQkv<true, T256x128>::init()) != hipSuccess) return e;
   if ((e = LaunchQkv<true, T128x128>::init()) != hipSuccess) return e;
   return LaunchQkv<true, T128x64>::init();
-}
-
-// XCD block grid (gx x 8/gx, see tile_coords): fabric-side fetch ~ gy * |A| + gx * |W| -> minimise gy * M + gx * N
-static int pick_xcd_gx(int M, int N) {
-  int best = 8;
-  long cost = -1;
-  for (int gx : {8, 4, 2, 1}) {
-    const long c = (long)(8 / gx) * M + (long)gx * N;
-    if (cost < 0 || c < cost) { cost = c; best = gx; }
-  }
-  return best;
 }
 
 // ln fold: what a launch that consumes (ln_part) or produces (xs_out) the folded LayerNorm must look like

@@ -31,6 +31,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Params p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int l15 = lane & 15, lk = lane >> 4;
+  // Row-major tile order, NOT the XCD-blocked one of the bf16 GEMMs (common.h xcd_tile_coords): measured on the vocoder (16 of these launches,
+  // 938 rows): the blocked order cuts the fabric-side bytes of a decode from 810 to 529 MB (every XCD no longer fetches every panel) and makes
+  // the decode 13 % SLOWER (0.95 -> 1.07 ms), the K = 100 input projection of the step loop 6 % slower (profiles/r04_f32_gemm_xcd_order.txt).
+  // These launches are latency-bound chains of K-tiles, the panels come from the die-level cache either way, and eight XCDs asking for the
+  // same lines at the same time is the cheaper pattern.
   const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
 
   const int lrow = tid >> 3, lk4 = (tid & 7) * 4;   // loader: rows lrow (+ 32), k offset lk4 inside the tile

@@ -54,6 +54,7 @@ def main():
         m.engine.set_option("tile_n2048", int(opts.get("n2048", 0)))
         m.engine.set_option("tile_qkv", int(opts.get("qkv", 0)))
         m.engine.set_option("xcd_gx", int(opts.get("gx", 0)))
+        m.engine.set_option("xcd_runs", int(opts.get("runs", 0)))       # 1 = round 3's tile order (equal runs per XCD instead of one block per XCD)
         m.engine.set_option("ln_fused", int(opts.get("ln_fused", 0)))
         m.engine.set_option("ln_fold", int(opts.get("ln_fold", 0)))
         m.engine.set_option("lane_skew", int(opts.get("skew", 0)))

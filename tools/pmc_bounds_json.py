@@ -84,12 +84,19 @@ def main(args):
                 if waves and sym in WAVES_PER_WG:
                     simds = min(1024.0, waves / WAVES_PER_WG[sym] * 4)          # one workgroup per CU on every big launch
                     r["mfma_busy"] = round(mf / (simds * cyc), 4)
+            if not wc:          # the wave-cycle group was not collected: the three wave states are disjoint and sum to it (MI355X_MICROARCH.md, PMC slots)
+                parts = [get(e, c) for c in ("SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY")]
+                if all(v is not None for v in parts):
+                    wc = sum(parts)
+                    r["wave_cycles_from"] = "sum of the three wave states (SQ_WAVE_CYCLES pass failed)"
             if wc:
                 for key, ctr in (("wave_issuing", "SQ_ACTIVE_INST_ANY"), ("wave_parked", "SQ_WAIT_ANY"), ("wave_stalled", "SQ_WAIT_INST_ANY"),
                                  ("valu_active", "SQ_ACTIVE_INST_VALU")):
                     v = get(e, ctr)
                     if v is not None:
                         r[key] = round(v / wc, 4)
+            if len(r) <= 1:
+                continue        # nothing but a duration: no bound to state
             hit, miss = get(e, "TCC_HIT_sum"), get(e, "TCC_MISS_sum")
             if hit is not None and miss is not None and hit + miss > 0:
                 r["l2_hit"] = round(hit / (hit + miss), 4)

@@ -8,7 +8,7 @@ pass() {   # pass <workload> <out file> <counters...>
   w=$1; out=$2; shift 2
   d=/tmp/pmcp_${w}_$(echo "$*" | tr ' ' '_' | cut -c1-40)
   rm -rf $d
-  (cd $R && timeout 300 rocprofv3 --kernel-trace --pmc "$@" -d $d -- python bench.py --workload $w --no-cpu-baseline --no-clock-power --steps 1 --warmup 1 > /tmp/pmcp.out 2>/tmp/pmcp.log) || { echo "# pass failed ($w: $*)" >> $out; tail -3 /tmp/pmcp.log >> $out; }
+  (cd $R && timeout 300 rocprofv3 --kernel-trace --pmc "$@" -d $d -- python bench.py --workload $w --no-cpu-baseline --no-clock-power --no-phases --steps 1 --warmup 1 > /tmp/pmcp.out 2>/tmp/pmcp.log) || { echo "# pass failed ($w: $*)" >> $out; tail -3 /tmp/pmcp.log >> $out; }
   echo "## $*" >> $out
   db=$(find $d -name "*_results.db" | head -1)
   [ -n "$db" ] && (cd $R && python tools/rocpd_pmc.py $db gemm_bf16 gemm_pp attn_fwd ln_mod gemm_qkv >> $out 2>&1)
