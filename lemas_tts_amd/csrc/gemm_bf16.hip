@@ -26,6 +26,7 @@
 // 128-row tile never straddles two samples and v^T stores are 8-B aligned; rows >= seq_valid are padding
 // (computed, never stored where it matters).
 #include <mutex>
+#include <type_traits>
 
 #include "common.h"
 #include "ln_core.h"
@@ -142,6 +143,53 @@ __device__ __forceinline__ bf16x4 pack4(float a, float b, float c, float d) {
   return o;
 }
 
+// ---------------------------------------------------------------- row windows (epilogue addressing)
+// A wave tile is at most 128 rows, aligned to its own height, and seq_pitch is a multiple of 128 (or the launch is one sample, seq_pitch >= M):
+// all its rows belong to ONE sample, so the sample index, the position of its first row and the number of LIVE rows counted from that
+// row are wave-uniform.  The epilogues used to derive (sample, position) per lane and per stored row -- an integer division by a run-time
+// pitch, a second one for the kv_len index, a 64-bit address multiply and an exec-mask branch around every store: ~25 VALU slots per
+// row, and the epilogues are VALU-issue bound (two waves per SIMD: 2400-3800 wave instructions per 128 x 64 wave tile measured as
+// 9-16 us per 256 x 256 tile).  Here the two divisions happen once per wave, on uniform values, and every row access goes through a
+// raw buffer descriptor whose base is the block's first row and whose size is the block's live rows: the hardware range check drops
+// the dead rows (loads return 0), the byte offset is 32 bits, and no store sits behind a branch.
+struct RowWin {
+  int b2, pos0;      // sample (of the doubled batch) and position of the wave tile's first row
+  int kvl;           // kv_len of that sample (INT_MAX: none); folded into `rl` by row_window_kv()
+  int rl, rows_m;    // rows of the wave tile, counted from its first one, that are stored (pos < seq_valid, m < M) / that exist (m < M)
+};
+__device__ __forceinline__ RowWin row_window(const GemmParams& p, int mw_uniform, bool kv) {
+  const int mw = __builtin_amdgcn_readfirstlane(mw_uniform);
+  RowWin w;
+  w.b2 = mw / p.seq_pitch;
+  w.pos0 = mw - w.b2 * p.seq_pitch;
+  w.kvl = 0x7fffffff;
+  if (kv && p.kv_len) w.kvl = p.kv_len[w.b2 % p.batch];
+  const int left = p.M - mw;
+  w.rows_m = left < 0 ? 0 : left > 128 ? 128 : left;
+  const int rl = p.seq_valid - w.pos0;
+  w.rl = rl < 0 ? 0 : rl > w.rows_m ? w.rows_m : rl;
+  return w;
+}
+// (separate from row_window: the kv_len load is requested one K-tile before the loop ends and first looked at after it)
+__device__ __forceinline__ void row_window_kv(RowWin& w) {
+  const int rl = w.kvl - w.pos0;
+  w.rl = rl < 0 ? 0 : rl < w.rl ? rl : w.rl;
+}
+constexpr int BUF_WORD3 = 0x00020000;      // gfx950 raw buffer descriptor, dword 3: 32-bit data format, no swizzle, no stride
+constexpr int BUF_OOB = 0x40000000;        // a byte offset past every window (windows are < 4 MB): the access is dropped
+constexpr int BUF_SC1 = 16;                // aux: write-through, the policy of store_wt_b128 (common.h)
+// `rows` rows of `row_bytes` each, starting `first_row` rows into the array at `base` (all uniform)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rows(const void* base, long long first_row, int rows, int row_bytes) {
+  char* b = const_cast<char*>(static_cast<const char*>(base)) + first_row * row_bytes;
+  // (the explicit readfirstlane: a clamp the compiler evaluates on the vector ALU would otherwise put the whole descriptor in VGPRs and
+  // wrap every access in a waterfall loop)
+  const int bytes = __builtin_amdgcn_readfirstlane(rows > 0 ? rows * row_bytes : 0);
+  return __builtin_amdgcn_make_buffer_rsrc(b, 0, bytes, BUF_WORD3);
+}
+__device__ __forceinline__ float4 buf_load_f4(__amdgpu_buffer_rsrc_t r, int voff) {
+  return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+}
+
 // ---------------------------------------------------------------- epilogues (staged through LDS)
 // After the K loop the ring's LDS is free.  Every wave parks its finished sub-tile in a private LDS slab and reads it
 // back row-wise, so that each global store instruction writes whole 128/256-B contiguous segments (8 or 16 lanes x
@@ -164,175 +212,50 @@ struct SlabF8 {     // [WTM rows][WTN e4m3] + 16 B pad per row
   static constexpr int PITCH = WTN + 16, BYTES = WTM * PITCH, CPR = WTN / 16, RPI = 64 / CPR, ITERS = WTM / RPI;
 };
 
+// MXFP8 output (EPI_BIAS_GELU_F8; the other row epilogues are epilogue_row_blocks below): one 32-row block.
 template <int EPI, int TI, int TJ>
 __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x16 (&acc)[TI][TJ], char* slab, int mw, int nw,
                                               int lane) {
+  static_assert(EPI == EPI_BIAS_GELU_F8, "the MXFP8 epilogue only");
   constexpr int WTM = 32 * TI, WTN = 32 * TJ;
   const int l31 = lane & 31, hi = lane >> 5;
-  if (EPI == EPI_GATE_RES) {
-    using S = SlabF32<WTM, WTN>;
-    const float* gate = p.tab + (size_t)p.step_idx[0] * p.tab_stride + p.gate_off;
-    // x_res rows this lane will update: issue the global reads first, they fly while the slab is written
-    const int rr = lane / S::CPR, ch = lane % S::CPR;
-    float4 xin[S::ITERS];
-    bool ok[S::ITERS];
+  // a 32-column block of one row lives in two lanes (l, l ^ 32) x 16 registers
+  using S = SlabF8<WTM, WTN>;
+  const int mxld = p.ldc >> 5;
+  const RowWin win = row_window(p, mw, false);
+  const int mwu = __builtin_amdgcn_readfirstlane(mw);
 #pragma unroll
-    for (int it = 0; it < S::ITERS; ++it) {
-      const int m = mw + it * S::RPI + rr;
-      const int b2 = m / p.seq_pitch, pos = m - b2 * p.seq_pitch;
-      bool live = m < p.M && pos < p.seq_valid && (nw + ch * 4) < p.n_valid;
-      if (p.kv_len) live = live && pos < p.kv_len[b2 % p.batch];
-      ok[it] = live;
-      xin[it] = live ? *reinterpret_cast<const float4*>(p.out_f32 + (size_t)m * p.ldc + nw + ch * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+  for (int i = 0; i < TI; ++i) {
+    const int m = mw + i * 32 + l31;
+    const bool live = i * 32 + l31 < win.rl;
 #pragma unroll
-    for (int j = 0; j < TJ; ++j)
+    for (int j = 0; j < TJ; ++j) {
+      float v[16];
+      float amax = 0.f;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int nl = j * 32 + 8 * g + 4 * hi;
-        const float4 bias = *reinterpret_cast<const float4*>(p.bias + nw + nl);
-        const float4 gt = *reinterpret_cast<const float4*>(gate + nw + nl);
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-          *reinterpret_cast<float4*>(slab + (i * 32 + l31) * S::PITCH + nl * 4) =
-              make_float4(gt.x * (acc[i][j][4 * g + 0] + bias.x), gt.y * (acc[i][j][4 * g + 1] + bias.y),
-                          gt.z * (acc[i][j][4 * g + 2] + bias.z), gt.w * (acc[i][j][4 * g + 3] + bias.w));
+        const float4 bias = *reinterpret_cast<const float4*>(p.bias + nw + j * 32 + 8 * g + 4 * hi);
+        v[4 * g + 0] = gelu_tanh_f(acc[i][j][4 * g + 0] + bias.x); v[4 * g + 1] = gelu_tanh_f(acc[i][j][4 * g + 1] + bias.y);
+        v[4 * g + 2] = gelu_tanh_f(acc[i][j][4 * g + 2] + bias.z); v[4 * g + 3] = gelu_tanh_f(acc[i][j][4 * g + 3] + bias.w);
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[4 * g + 0]), fabsf(v[4 * g + 1]))), fmaxf(fabsf(v[4 * g + 2]), fabsf(v[4 * g + 3])));
       }
+      amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+      const int e = mx_exponent(amax);
+      const float inv = mx_inv_scale(e);
 #pragma unroll
-    for (int it = 0; it < S::ITERS; ++it) {
-      const float4 d = *reinterpret_cast<const float4*>(slab + (it * S::RPI + rr) * S::PITCH + ch * 16);
-      if (ok[it]) {
-        const int m = mw + it * S::RPI + rr;
-        float4 x = xin[it];
-        x.x += d.x; x.y += d.y; x.z += d.z; x.w += d.w;
-        store_wt_b128(p.out_f32 + (size_t)m * p.ldc + nw + ch * 4, __builtin_bit_cast(u32x4, x));
-      }
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<unsigned int*>(slab + (i * 32 + l31) * S::PITCH + j * 32 + 8 * g + 4 * hi) =
+            pack_fp8x4(v[4 * g + 0] * inv, v[4 * g + 1] * inv, v[4 * g + 2] * inv, v[4 * g + 3] * inv);
+      if (hi == 0 && live) p.out_mx[(size_t)m * mxld + ((nw + j * 32) >> 5)] = (uint8_t)(e + 127);
     }
-  } else if (EPI == EPI_BIAS_F32) {
-    using S = SlabF32<WTM, WTN>;
+  }
+  const int rr = lane / S::CPR, ch = lane % S::CPR;
+  const __amdgpu_buffer_rsrc_t wst = buf_rows(p.out_f8, mwu, win.rl, p.ldc);
+  const int vo = rr * p.ldc + nw + ch * 16, rstep = S::RPI * p.ldc;
 #pragma unroll
-    for (int j = 0; j < TJ; ++j)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int nl = j * 32 + 8 * g + 4 * hi;
-        const float4 bias = *reinterpret_cast<const float4*>(p.bias + nw + nl);
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-          *reinterpret_cast<float4*>(slab + (i * 32 + l31) * S::PITCH + nl * 4) =
-              make_float4(acc[i][j][4 * g + 0] + bias.x, acc[i][j][4 * g + 1] + bias.y, acc[i][j][4 * g + 2] + bias.z,
-                          acc[i][j][4 * g + 3] + bias.w);
-      }
-    const int rr = lane / S::CPR, ch = lane % S::CPR;
-#pragma unroll
-    for (int it = 0; it < S::ITERS; ++it) {
-      const int m = mw + it * S::RPI + rr;
-      const int b2 = m / p.seq_pitch, pos = m - b2 * p.seq_pitch;
-      const float4 d = *reinterpret_cast<const float4*>(slab + (it * S::RPI + rr) * S::PITCH + ch * 16);
-      if (m < p.M && pos < p.seq_valid && (nw + ch * 4) < p.n_valid) *reinterpret_cast<float4*>(p.out_f32 + (size_t)m * p.ldc + nw + ch * 4) = d;
-    }
-  } else if (EPI == EPI_QK_ROPE) {
-    // fp32 slab; RoPE is applied on the row-wise read-back, where a lane owns 8 consecutive head dims of one position
-    // (two float4 table loads per 16-B output chunk instead of 4x as many float2 loads in the fragment layout)
-    using S = SlabF32<WTM, WTN>;
-#pragma unroll
-    for (int j = 0; j < TJ; ++j)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int nl = j * 32 + 8 * g + 4 * hi;
-        const float4 bias = *reinterpret_cast<const float4*>(p.bias + nw + nl);
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-          *reinterpret_cast<float4*>(slab + (i * 32 + l31) * S::PITCH + nl * 4) =
-              make_float4(acc[i][j][4 * g + 0] + bias.x, acc[i][j][4 * g + 1] + bias.y, acc[i][j][4 * g + 2] + bias.z,
-                          acc[i][j][4 * g + 3] + bias.w);
-      }
-    constexpr int CPR = WTN / 8, RPI = 64 / CPR, ITERS = WTM / RPI;   // 8 head dims (16 B of bf16) per lane
-    const int rr = lane / CPR, ch = lane % CPR;
-    const int inner = p.heads * 64, n = nw + ch * 8;
-    const int which = n / inner, head = (n % inner) >> 6, d = n & 63;
-    bf16_t* base = (which == 0 ? p.q : p.k) + (size_t)head * p.seq_pitch * 64 + d;
-    const float qs = (which == 0 && p.q_scale != 0.f) ? p.q_scale : 1.0f;
-#pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
-      const int m = mw + it * RPI + rr;
-      const int b2 = m / p.seq_pitch, pos = m - b2 * p.seq_pitch;
-      const bool live = m < p.M && pos < p.seq_valid;
-      const int ps = live ? pos : 0;
-      const float4 c = *reinterpret_cast<const float4*>(p.rope_cos + ps * 32 + (d >> 1));
-      const float4 sn = *reinterpret_cast<const float4*>(p.rope_sin + ps * 32 + (d >> 1));
-      const float4 a = *reinterpret_cast<const float4*>(slab + (it * RPI + rr) * S::PITCH + ch * 32);
-      const float4 b = *reinterpret_cast<const float4*>(slab + (it * RPI + rr) * S::PITCH + ch * 32 + 16);
-      bf16x8 o;
-      o[0] = (bf16_t)((a.x * c.x - a.y * sn.x) * qs); o[1] = (bf16_t)((a.y * c.x + a.x * sn.x) * qs);
-      o[2] = (bf16_t)((a.z * c.y - a.w * sn.y) * qs); o[3] = (bf16_t)((a.w * c.y + a.z * sn.y) * qs);
-      o[4] = (bf16_t)((b.x * c.z - b.y * sn.z) * qs); o[5] = (bf16_t)((b.y * c.z + b.x * sn.z) * qs);
-      o[6] = (bf16_t)((b.z * c.w - b.w * sn.w) * qs); o[7] = (bf16_t)((b.w * c.w + b.z * sn.w) * qs);
-      if (live) store_wt_b128(base + ((size_t)b2 * p.heads * p.seq_pitch + pos) * 64, __builtin_bit_cast(u32x4, o));
-    }
-  } else if (EPI == EPI_BIAS_GELU_F8) {
-    // MXFP8 output: a 32-column block of one row lives in two lanes (l, l ^ 32) x 16 registers
-    using S = SlabF8<WTM, WTN>;
-    const int mxld = p.ldc >> 5;
-#pragma unroll
-    for (int i = 0; i < TI; ++i) {
-      const int m = mw + i * 32 + l31;
-      const int b2 = m / p.seq_pitch, pos = m - b2 * p.seq_pitch;
-      const bool live = m < p.M && pos < p.seq_valid;
-#pragma unroll
-      for (int j = 0; j < TJ; ++j) {
-        float v[16];
-        float amax = 0.f;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const float4 bias = *reinterpret_cast<const float4*>(p.bias + nw + j * 32 + 8 * g + 4 * hi);
-          v[4 * g + 0] = gelu_tanh_f(acc[i][j][4 * g + 0] + bias.x); v[4 * g + 1] = gelu_tanh_f(acc[i][j][4 * g + 1] + bias.y);
-          v[4 * g + 2] = gelu_tanh_f(acc[i][j][4 * g + 2] + bias.z); v[4 * g + 3] = gelu_tanh_f(acc[i][j][4 * g + 3] + bias.w);
-          amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[4 * g + 0]), fabsf(v[4 * g + 1]))), fmaxf(fabsf(v[4 * g + 2]), fabsf(v[4 * g + 3])));
-        }
-        amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
-        const int e = mx_exponent(amax);
-        const float inv = mx_inv_scale(e);
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          *reinterpret_cast<unsigned int*>(slab + (i * 32 + l31) * S::PITCH + j * 32 + 8 * g + 4 * hi) =
-              pack_fp8x4(v[4 * g + 0] * inv, v[4 * g + 1] * inv, v[4 * g + 2] * inv, v[4 * g + 3] * inv);
-        if (hi == 0 && live) p.out_mx[(size_t)m * mxld + ((nw + j * 32) >> 5)] = (uint8_t)(e + 127);
-      }
-    }
-    const int rr = lane / S::CPR, ch = lane % S::CPR;
-#pragma unroll
-    for (int it = 0; it < S::ITERS; ++it) {
-      const int m = mw + it * S::RPI + rr;
-      const int b2 = m / p.seq_pitch, pos = m - b2 * p.seq_pitch;
-      const u32x4 d = *reinterpret_cast<const u32x4*>(slab + (it * S::RPI + rr) * S::PITCH + ch * 16);
-      if (m < p.M && pos < p.seq_valid) store_wt_b128(p.out_f8 + (size_t)m * p.ldc + nw + ch * 16, d);
-    }
-  } else {   // bf16 outputs: plain, GELU-tanh
-    using S = SlabBf16<WTM, WTN>;
-#pragma unroll
-    for (int i = 0; i < TI; ++i) {
-#pragma unroll
-      for (int j = 0; j < TJ; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int nl = j * 32 + 8 * g + 4 * hi;
-          const float4 bias = *reinterpret_cast<const float4*>(p.bias + nw + nl);
-          float v0 = acc[i][j][4 * g + 0] + bias.x, v1 = acc[i][j][4 * g + 1] + bias.y;
-          float v2 = acc[i][j][4 * g + 2] + bias.z, v3 = acc[i][j][4 * g + 3] + bias.w;
-          bf16x4 o;
-          if (EPI == EPI_BIAS_GELU_BF16) o = pack4(gelu_tanh_f(v0), gelu_tanh_f(v1), gelu_tanh_f(v2), gelu_tanh_f(v3));
-          else o = pack4(v0, v1, v2, v3);
-          *reinterpret_cast<bf16x4*>(slab + (i * 32 + l31) * S::PITCH + nl * 2) = o;
-        }
-    }
-    const int rr = lane / S::CPR, ch = lane % S::CPR;
-#pragma unroll
-    for (int it = 0; it < S::ITERS; ++it) {
-      const int m = mw + it * S::RPI + rr;
-      const int b2 = m / p.seq_pitch, pos = m - b2 * p.seq_pitch;
-      const u32x4 d = *reinterpret_cast<const u32x4*>(slab + (it * S::RPI + rr) * S::PITCH + ch * 16);
-      if (m < p.M && pos < p.seq_valid && (nw + ch * 8) < p.n_valid) store_wt_b128(p.out_bf16 + (size_t)m * p.ldc + nw + ch * 8, d);
-    }
+  for (int it = 0; it < S::ITERS; ++it) {
+    const u32x4 d = *reinterpret_cast<const u32x4*>(slab + (it * S::RPI + rr) * S::PITCH + ch * 16);
+    __builtin_amdgcn_raw_buffer_store_b128(d, wst, vo + it * rstep, 0, BUF_SC1);
   }
 }
 
@@ -362,31 +285,34 @@ struct EpiPre {
   const float* c1src;                           // LNA == 2: where to re-read them (nullptr: not a consumer)
   float4 r0[NR], r1[EPI == EPI_QK_ROPE ? NR : 1];     // block 0: residual rows | cos rows, sin rows
   const float* gate;
+  RowWin win;                                         // the wave tile's rows (uniform)
 
   // rows of 32-row block i of the wave tile at (mw, nw): residual / RoPE operands into (x, y)
   __device__ __forceinline__ void load_rows(const GemmParams& p, int mw, int nw, int lane, int i, float4 (&x)[NR], float4 (&y)[EPI == EPI_QK_ROPE ? NR : 1]) {
+    const int mwu = __builtin_amdgcn_readfirstlane(mw);
     if constexpr (EPI == EPI_GATE_RES) {
       using S = SlabF32<32, WTN>;
       const int rr = lane / S::CPR, ch = lane % S::CPR;
       int col = nw + ch * 4;
       col = col < p.ldc - 3 ? col : 0;
+      // every row that exists (m < M), live or not: the ln-fold producer re-publishes the rows it does not update
+      const __amdgpu_buffer_rsrc_t w = buf_rows(p.out_f32, (long long)mwu + 32 * i, win.rows_m - 32 * i, p.ldc * 4);
+      const int vo = (rr * p.ldc + col) * 4, rstep = S::RPI * p.ldc * 4;
 #pragma unroll
-      for (int it = 0; it < NR; ++it) {
-        int m = mw + 32 * i + it * S::RPI + rr;
-        m = m < p.M ? m : p.M - 1;
-        x[it] = *reinterpret_cast<const float4*>(p.out_f32 + (size_t)m * p.ldc + col);
-      }
+      for (int it = 0; it < NR; ++it) x[it] = buf_load_f4(w, vo + it * rstep);
     } else if constexpr (EPI == EPI_QK_ROPE) {
       constexpr int CPR = WTN / 8, RPI = 64 / CPR;
       const int rr = lane / CPR, ch = lane % CPR;
       const int d = (nw + ch * 8) & 63;
+      // table rows pos0 + 32 i ... of the live rows (the table has seq_valid of them); dead rows are rotated by 0 and never stored
+      const int rows = win.rl - 32 * i;
+      const __amdgpu_buffer_rsrc_t wc = buf_rows(p.rope_cos, (long long)win.pos0 + 32 * i, rows, 128);
+      const __amdgpu_buffer_rsrc_t ws = buf_rows(p.rope_sin, (long long)win.pos0 + 32 * i, rows, 128);
+      const int vo = (rr * 32 + (d >> 1)) * 4;
 #pragma unroll
       for (int it = 0; it < NR; ++it) {
-        const int m = mw + 32 * i + it * RPI + rr;
-        const int b2 = m / p.seq_pitch, pos = m - b2 * p.seq_pitch;
-        const int ps = (m < p.M && pos < p.seq_valid) ? pos : 0;
-        x[it] = *reinterpret_cast<const float4*>(p.rope_cos + ps * 32 + (d >> 1));
-        y[it] = *reinterpret_cast<const float4*>(p.rope_sin + ps * 32 + (d >> 1));
+        x[it] = buf_load_f4(wc, vo + it * RPI * 128);
+        y[it] = buf_load_f4(ws, vo + it * RPI * 128);
       }
     }
   }
@@ -415,6 +341,7 @@ struct EpiPre {
             c1_c[j * 4 + g] = c1src ? *reinterpret_cast<const float4*>(c1src + nw + nl) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
+    win = row_window(p, mw, EPI == EPI_GATE_RES);
     load_rows(p, mw, nw, lane, 0, r0, r1);
   }
 };
@@ -456,97 +383,109 @@ __device__ __forceinline__ void epilogue_row_blocks(const GemmParams& p, f32x16 
     return *reinterpret_cast<const float4*>(gate + nw + j * 32 + 8 * g + 4 * hi);
   };
 
+  const int mwu = __builtin_amdgcn_readfirstlane(mw);
   if constexpr (EPI == EPI_GATE_RES) {
     using S = SlabF32<32, WTN>;
     const int rr = lane / S::CPR, ch = lane % S::CPR;
     float4 xnext[Pre::NR], unused[1];
-    const bool prod = p.xs_out != nullptr;      // ln-fold producer: scaled bf16 image + row partial sums of the new rows
-    float4 sc1p = make_float4(1.f, 1.f, 1.f, 1.f);
-    if (prod) {
-      const float4 t = *reinterpret_cast<const float4*>(gate - p.gate_off + p.xs_scale_off + nw + ch * 4);
-      sc1p = make_float4(1.0f + t.x, 1.0f + t.y, 1.0f + t.z, 1.0f + t.w);
-    }
-#pragma unroll
-    for (int i = 0; i < TI; ++i) {
-      float4 xin[Pre::NR];
-      if (AHEAD || i == 0) {
-#pragma unroll
-        for (int it = 0; it < Pre::NR; ++it) xin[it] = i == 0 ? pre.r0[it] : xnext[it];
-        if (AHEAD && i + 1 < TI) pre.load_rows(p, mw, nw, lane, i + 1, xnext, unused);
-      } else {
-        pre.load_rows(p, mw, nw, lane, i, xin, unused);
+    row_window_kv(pre.win);
+    const int rl = pre.win.rl;
+    int vo = (rr * p.ldc + nw + ch * 4) * 4;
+    if (nw + ch * 4 >= p.n_valid) vo = BUF_OOB;
+    const int rstep = S::RPI * p.ldc * 4;
+    // one block of 32 rows: gate (acc + bias) through the slab, added to the residual rows, stored through the block's window of
+    // live rows.  PROD = the ln-fold producer (xs_out): scaled bf16 image + row partial sums of the new rows, every row that exists
+    auto blocks = [&](auto prod_c) {
+      constexpr bool PROD = decltype(prod_c)::value;
+      float4 sc1p = make_float4(1.f, 1.f, 1.f, 1.f);
+      if constexpr (PROD) {
+        const float4 t = *reinterpret_cast<const float4*>(gate - p.gate_off + p.xs_scale_off + nw + ch * 4);
+        sc1p = make_float4(1.0f + t.x, 1.0f + t.y, 1.0f + t.z, 1.0f + t.w);
       }
 #pragma unroll
-      for (int j = 0; j < TJ; ++j)
+      for (int i = 0; i < TI; ++i) {
+        float4 xin[Pre::NR];
+        if (AHEAD || i == 0) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int nl = j * 32 + 8 * g + 4 * hi;
-          const float4 bias = bias_of(j, g), gt = gate_of(j, g);
-          *reinterpret_cast<float4*>(slab + l31 * S::PITCH + nl * 4) =
-              make_float4(gt.x * (acc[i][j][4 * g + 0] + bias.x), gt.y * (acc[i][j][4 * g + 1] + bias.y),
-                          gt.z * (acc[i][j][4 * g + 2] + bias.z), gt.w * (acc[i][j][4 * g + 3] + bias.w));
+          for (int it = 0; it < Pre::NR; ++it) xin[it] = i == 0 ? pre.r0[it] : xnext[it];
+          if (AHEAD && i + 1 < TI) pre.load_rows(p, mw, nw, lane, i + 1, xnext, unused);
+        } else {
+          pre.load_rows(p, mw, nw, lane, i, xin, unused);
         }
-      // all slab rows of the block first: the stores below are asm with a memory clobber, which would otherwise put every LDS read
-      // behind the previous iteration's stores
-      float4 dv[S::ITERS];
 #pragma unroll
-      for (int it = 0; it < S::ITERS; ++it) dv[it] = *reinterpret_cast<const float4*>(slab + (it * S::RPI + rr) * S::PITCH + ch * 16);
-      float k1 = 0.f, k2 = 0.f;      // ln fold: the (sum, sum of squares) pair this lane will publish for the block
+        for (int j = 0; j < TJ; ++j)
 #pragma unroll
-      for (int it = 0; it < S::ITERS; ++it) {
-        const float4 d = dv[it];
-        const int m = mw + 32 * i + it * S::RPI + rr;
-        const int b2 = m / p.seq_pitch, pos = m - b2 * p.seq_pitch;
-        bool live = m < p.M && pos < p.seq_valid && (nw + ch * 4) < p.n_valid;
-        if (p.kv_len) live = live && pos < p.kv_len[b2 % p.batch];
-        float4 x = xin[it];
-        if (live) {
-          x.x += d.x; x.y += d.y; x.z += d.z; x.w += d.w;
-          store_wt_b128(p.out_f32 + (size_t)m * p.ldc + nw + ch * 4, __builtin_bit_cast(u32x4, x));
-        }
-        if (prod) {     // every row of the activation space (updated or not): the consumer GEMM reads all of them
-          if (m < p.M) {
-            const bf16x4 o = pack4(x.x * sc1p.x, x.y * sc1p.y, x.z * sc1p.z, x.w * sc1p.w);
-            store_wt_b64(p.xs_out + (size_t)m * p.ldc + nw + ch * 4, __builtin_bit_cast(unsigned int __attribute__((ext_vector_type(2))), o));
+          for (int g = 0; g < 4; ++g) {
+            const int nl = j * 32 + 8 * g + 4 * hi;
+            const float4 bias = bias_of(j, g), gt = gate_of(j, g);
+            *reinterpret_cast<float4*>(slab + l31 * S::PITCH + nl * 4) =
+                make_float4(gt.x * (acc[i][j][4 * g + 0] + bias.x), gt.y * (acc[i][j][4 * g + 1] + bias.y),
+                            gt.z * (acc[i][j][4 * g + 2] + bias.z), gt.w * (acc[i][j][4 * g + 3] + bias.w));
           }
-          float s1 = (x.x + x.y) + (x.z + x.w);
-          float s2 = __builtin_fmaf(x.x, x.x, __builtin_fmaf(x.y, x.y, __builtin_fmaf(x.z, x.z, x.w * x.w)));
-          // butterfly over the 8 lanes (32 columns = one statistics slot) of the row on DPP: v_add_f32 with a lane-permuting source
-          // modifier (the __shfl_xor form is a ds_bpermute round trip per step: 2 us of a 16 us launch).  xor 1, xor 2 (quad
-          // permutes), then the other quad of the 8 (row_half_mirror), whose lanes all hold their quad's sum by then
-          s1 += dpp_f<0xB1>(s1); s2 += dpp_f<0xB1>(s2);
-          s1 += dpp_f<0x4E>(s1); s2 += dpp_f<0x4E>(s2);
-          s1 += dpp_f<0x141>(s1); s2 += dpp_f<0x141>(s2);
-          // lane (rr, ch) keeps the pair of iteration it = ch % 8: after the loop ITERS * RPI * (CPR / 8) = 32 * WTN / 32 lanes hold one
-          // (row, slot) pair each and ONE store instruction publishes the block's statistics
-          if ((ch & 7) == it) { k1 = s1; k2 = s2; }
+        const __amdgpu_buffer_rsrc_t wst = buf_rows(p.out_f32, (long long)mwu + 32 * i, rl - 32 * i, p.ldc * 4);
+        float k1 = 0.f, k2 = 0.f;      // ln fold: the (sum, sum of squares) pair this lane will publish for the block
+#pragma unroll
+        for (int it = 0; it < S::ITERS; ++it) {
+          const float4 d = *reinterpret_cast<const float4*>(slab + (it * S::RPI + rr) * S::PITCH + ch * 16);
+          float4 x = xin[it];
+          if constexpr (!PROD) {
+            x.x += d.x; x.y += d.y; x.z += d.z; x.w += d.w;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), wst, vo + it * rstep, 0, BUF_SC1);
+          } else {
+            const int row = 32 * i + it * S::RPI + rr, m = mw + row;
+            if (row < rl && vo != BUF_OOB) { x.x += d.x; x.y += d.y; x.z += d.z; x.w += d.w; }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), wst, vo + it * rstep, 0, BUF_SC1);
+            if (m < p.M) {     // every row of the activation space (updated or not): the consumer GEMM reads all of them
+              const bf16x4 o = pack4(x.x * sc1p.x, x.y * sc1p.y, x.z * sc1p.z, x.w * sc1p.w);
+              store_wt_b64(p.xs_out + (size_t)m * p.ldc + nw + ch * 4, __builtin_bit_cast(unsigned int __attribute__((ext_vector_type(2))), o));
+            }
+            float s1 = (x.x + x.y) + (x.z + x.w);
+            float s2 = __builtin_fmaf(x.x, x.x, __builtin_fmaf(x.y, x.y, __builtin_fmaf(x.z, x.z, x.w * x.w)));
+            // butterfly over the 8 lanes (32 columns = one statistics slot) of the row on DPP: v_add_f32 with a lane-permuting source
+            // modifier (the __shfl_xor form is a ds_bpermute round trip per step: 2 us of a 16 us launch).  xor 1, xor 2 (quad
+            // permutes), then the other quad of the 8 (row_half_mirror), whose lanes all hold their quad's sum by then
+            s1 += dpp_f<0xB1>(s1); s2 += dpp_f<0xB1>(s2);
+            s1 += dpp_f<0x4E>(s1); s2 += dpp_f<0x4E>(s2);
+            s1 += dpp_f<0x141>(s1); s2 += dpp_f<0x141>(s2);
+            // lane (rr, ch) keeps the pair of iteration it = ch % 8: after the loop ITERS * RPI * (CPR / 8) = 32 * WTN / 32 lanes hold one
+            // (row, slot) pair each and ONE store instruction publishes the block's statistics
+            if ((ch & 7) == it) { k1 = s1; k2 = s2; }
+          }
+        }
+        if constexpr (PROD) {
+          static_assert(S::ITERS <= 8 && (S::CPR == 8 || S::CPR == 16), "one kept pair per lane");
+          const int m = mw + 32 * i + (ch & 7) * S::RPI + rr;
+          if ((ch & 7) < S::ITERS && m < p.M)
+            *reinterpret_cast<float2*>(p.ln_part_out + ((size_t)m * LN_NP + ((nw + ch * 4) >> 5)) * 2) = make_float2(k1, k2);
         }
       }
-      if (prod) {
-        static_assert(S::ITERS <= 8 && (S::CPR == 8 || S::CPR == 16), "one kept pair per lane");
-        const int m = mw + 32 * i + (ch & 7) * S::RPI + rr;
-        if ((ch & 7) < S::ITERS && m < p.M)
-          *reinterpret_cast<float2*>(p.ln_part_out + ((size_t)m * LN_NP + ((nw + ch * 4) >> 5)) * 2) = make_float2(k1, k2);
-      }
-    }
+    };
+    if (p.xs_out != nullptr) blocks(std::true_type{}); else blocks(std::false_type{});
   } else if constexpr (EPI == EPI_QK_ROPE) {
     using S = SlabF32<32, WTN>;
     constexpr int CPR = WTN / 8, RPI = 64 / CPR, ITERS = 32 / RPI;   // 8 head dims (16 B of bf16) per lane
     static_assert(ITERS == Pre::NR, "row operand count");
+    static_assert(WTN <= 64, "a wave tile lies inside one head");
     const int rr = lane / CPR, ch = lane % CPR;
-    const int inner = p.heads * 64, n = nw + ch * 8;
-    const int which = n / inner, head = (n % inner) >> 6, d = n & 63;
-    bf16_t* base = (which == 0 ? p.q : p.k) + (size_t)head * p.seq_pitch * 64 + d;
+    const int nwu = __builtin_amdgcn_readfirstlane(nw);
+    const int inner = p.heads * 64;
+    const int which = nwu / inner, head = (nwu % inner) >> 6, d = (nw + ch * 8) & 63;     // uniform: q or k, the head
+    const bf16_t* qk = which == 0 ? p.q : p.k;
+    const long long row0 = ((long long)pre.win.b2 * p.heads + head) * p.seq_pitch + pre.win.pos0;    // [b2][head][pos][64]
+    const int rl = pre.win.rl, vo = (rr * 64 + d) * 2;
     const float qs = (which == 0 && p.q_scale != 0.f) ? p.q_scale : 1.0f;
     float4 cnext[ITERS], snext[ITERS];
+    auto blocks = [&](auto lna_c) {      // two copies of the unrolled blocks: with and without the folded LayerNorm (a run-time property of the launch)
+    constexpr bool L = LNA != 0 && decltype(lna_c)::value;
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
+      const __amdgpu_buffer_rsrc_t wst = buf_rows(qk, row0 + 32 * i, rl - 32 * i, 128);
       float4 cs[ITERS], sn[ITERS];
 #pragma unroll
       for (int it = 0; it < ITERS; ++it) { cs[it] = i == 0 ? pre.r0[it] : cnext[it]; sn[it] = i == 0 ? pre.r1[it] : snext[it]; }
       if (i + 1 < TI) pre.load_rows(p, mw, nw, lane, i + 1, cnext, snext);
-      float r, nrm;
-      row_rn(i, r, nrm);
+      float r = 1.0f, nrm = 0.f;
+      if constexpr (L) row_rn(i, r, nrm);
 #pragma unroll
       for (int j = 0; j < TJ; ++j)
 #pragma unroll
@@ -554,7 +493,7 @@ __device__ __forceinline__ void epilogue_row_blocks(const GemmParams& p, f32x16 
           const int nl = j * 32 + 8 * g + 4 * hi;
           const float4 bias = bias_of(j, g);
           float4 v;
-          if constexpr (LNA != 0) {
+          if constexpr (L) {
             const float4 c1 = c1_of(j, g);
             v = make_float4(__builtin_fmaf(r, acc[i][j][4 * g + 0], __builtin_fmaf(nrm, c1.x, bias.x)),
                             __builtin_fmaf(r, acc[i][j][4 * g + 1], __builtin_fmaf(nrm, c1.y, bias.y)),
@@ -568,9 +507,6 @@ __device__ __forceinline__ void epilogue_row_blocks(const GemmParams& p, f32x16 
         }
 #pragma unroll
       for (int it = 0; it < ITERS; ++it) {
-        const int m = mw + 32 * i + it * RPI + rr;
-        const int b2 = m / p.seq_pitch, pos = m - b2 * p.seq_pitch;
-        const bool live = m < p.M && pos < p.seq_valid;
         const float4 c = cs[it], sv = sn[it];
         const float4 a = *reinterpret_cast<const float4*>(slab + (it * RPI + rr) * S::PITCH + ch * 32);
         const float4 b = *reinterpret_cast<const float4*>(slab + (it * RPI + rr) * S::PITCH + ch * 32 + 16);
@@ -579,12 +515,17 @@ __device__ __forceinline__ void epilogue_row_blocks(const GemmParams& p, f32x16 
         o[2] = (bf16_t)((a.z * c.y - a.w * sv.y) * qs); o[3] = (bf16_t)((a.w * c.y + a.z * sv.y) * qs);
         o[4] = (bf16_t)((b.x * c.z - b.y * sv.z) * qs); o[5] = (bf16_t)((b.y * c.z + b.x * sv.z) * qs);
         o[6] = (bf16_t)((b.z * c.w - b.w * sv.w) * qs); o[7] = (bf16_t)((b.w * c.w + b.z * sv.w) * qs);
-        if (live) store_wt_b128(base + ((size_t)b2 * p.heads * p.seq_pitch + pos) * 64, __builtin_bit_cast(u32x4, o));
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), wst, vo + it * RPI * 128, 0, BUF_SC1);
       }
     }
+    };
+    if constexpr (LNA != 0) { if (lna) blocks(std::true_type{}); else blocks(std::false_type{}); } else blocks(std::false_type{});
   } else if constexpr (EPI == EPI_BIAS_F32) {
     using S = SlabF32<32, WTN>;
     const int rr = lane / S::CPR, ch = lane % S::CPR;
+    int vo = (rr * p.ldc + nw + ch * 4) * 4;
+    if (nw + ch * 4 >= p.n_valid) vo = BUF_OOB;
+    const int rstep = S::RPI * p.ldc * 4;
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
 #pragma unroll
@@ -597,21 +538,25 @@ __device__ __forceinline__ void epilogue_row_blocks(const GemmParams& p, f32x16 
               make_float4(acc[i][j][4 * g + 0] + bias.x, acc[i][j][4 * g + 1] + bias.y, acc[i][j][4 * g + 2] + bias.z,
                           acc[i][j][4 * g + 3] + bias.w);
         }
+      const __amdgpu_buffer_rsrc_t wst = buf_rows(p.out_f32, (long long)mwu + 32 * i, pre.win.rl - 32 * i, p.ldc * 4);
 #pragma unroll
       for (int it = 0; it < S::ITERS; ++it) {
-        const int m = mw + 32 * i + it * S::RPI + rr;
-        const int b2 = m / p.seq_pitch, pos = m - b2 * p.seq_pitch;
         const float4 d = *reinterpret_cast<const float4*>(slab + (it * S::RPI + rr) * S::PITCH + ch * 16);
-        if (m < p.M && pos < p.seq_valid && (nw + ch * 4) < p.n_valid) *reinterpret_cast<float4*>(p.out_f32 + (size_t)m * p.ldc + nw + ch * 4) = d;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, d), wst, vo + it * rstep, 0, 0);
       }
     }
   } else {   // bf16 outputs: plain, GELU-tanh
     using S = SlabBf16<32, WTN>;
     const int rr = lane / S::CPR, ch = lane % S::CPR;
+    int vo = (rr * p.ldc + nw + ch * 8) * 2;
+    if (nw + ch * 8 >= p.n_valid) vo = BUF_OOB;
+    const int rstep = S::RPI * p.ldc * 2;
+    auto blocks = [&](auto lna_c) {
+    constexpr bool L = LNA != 0 && decltype(lna_c)::value;
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
-      float r, nrm;
-      row_rn(i, r, nrm);
+      float r = 1.0f, nrm = 0.f;
+      if constexpr (L) row_rn(i, r, nrm);
 #pragma unroll
       for (int j = 0; j < TJ; ++j)
 #pragma unroll
@@ -619,7 +564,7 @@ __device__ __forceinline__ void epilogue_row_blocks(const GemmParams& p, f32x16 
           const int nl = j * 32 + 8 * g + 4 * hi;
           const float4 bias = bias_of(j, g);
           float v0, v1, v2, v3;
-          if constexpr (LNA != 0) {
+          if constexpr (L) {
             const float4 c1 = c1_of(j, g);
             v0 = __builtin_fmaf(r, acc[i][j][4 * g + 0], __builtin_fmaf(nrm, c1.x, bias.x));
             v1 = __builtin_fmaf(r, acc[i][j][4 * g + 1], __builtin_fmaf(nrm, c1.y, bias.y));
@@ -634,14 +579,15 @@ __device__ __forceinline__ void epilogue_row_blocks(const GemmParams& p, f32x16 
           else o = pack4(v0, v1, v2, v3);
           *reinterpret_cast<bf16x4*>(slab + l31 * S::PITCH + nl * 2) = o;
         }
+      const __amdgpu_buffer_rsrc_t wst = buf_rows(p.out_bf16, (long long)mwu + 32 * i, pre.win.rl - 32 * i, p.ldc * 2);
 #pragma unroll
       for (int it = 0; it < S::ITERS; ++it) {
-        const int m = mw + 32 * i + it * S::RPI + rr;
-        const int b2 = m / p.seq_pitch, pos = m - b2 * p.seq_pitch;
         const u32x4 d = *reinterpret_cast<const u32x4*>(slab + (it * S::RPI + rr) * S::PITCH + ch * 16);
-        if (m < p.M && pos < p.seq_valid && (nw + ch * 8) < p.n_valid) store_wt_b128(p.out_bf16 + (size_t)m * p.ldc + nw + ch * 8, d);
+        __builtin_amdgcn_raw_buffer_store_b128(d, wst, vo + it * rstep, 0, BUF_SC1);
       }
     }
+    };
+    if constexpr (LNA != 0) { if (lna) blocks(std::true_type{}); else blocks(std::false_type{}); } else blocks(std::false_type{});
   }
 }
 
@@ -663,39 +609,48 @@ __device__ __forceinline__ void epilogue_vt(const GemmParams& p, f32x16 (&acc)[T
     bsrc = row + p.lnc2_off;
     c1src = row + p.lnc1_off;
   }
+  auto park = [&](auto lna_c) {      // with / without the folded LayerNorm: a run-time property of the launch, two copies of the unrolled code
+    constexpr bool L = decltype(lna_c)::value;
 #pragma unroll
-  for (int j = 0; j < TJ; ++j) {
-    const float bias = bsrc[nw + j * 32 + l31];
-    const float c1 = lna ? c1src[nw + j * 32 + l31] : 0.f;
+    for (int j = 0; j < TJ; ++j) {
+      const float bias = bsrc[nw + j * 32 + l31];
+      const float c1 = L ? c1src[nw + j * 32 + l31] : 0.f;
 #pragma unroll
-    for (int i = 0; i < TI; ++i)
+      for (int i = 0; i < TI; ++i)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float4 ra = make_float4(1.f, 0.f, 1.f, 0.f), rb = ra;      // (r, -r mu) of rows +0, +1 | +2, +3
-        if (lna) {
-          ra = *reinterpret_cast<const float4*>(rs + 2 * (i * 32 + 8 * g + 4 * hi));
-          rb = *reinterpret_cast<const float4*>(rs + 2 * (i * 32 + 8 * g + 4 * hi) + 4);
+        for (int g = 0; g < 4; ++g) {
+          bf16x4 o;
+          if constexpr (L) {
+            // (r, -r mu) of rows +0, +1 | +2, +3
+            const float4 ra = *reinterpret_cast<const float4*>(rs + 2 * (i * 32 + 8 * g + 4 * hi));
+            const float4 rb = *reinterpret_cast<const float4*>(rs + 2 * (i * 32 + 8 * g + 4 * hi) + 4);
+            o = pack4(__builtin_fmaf(ra.x, acc[i][j][4 * g + 0], __builtin_fmaf(ra.y, c1, bias)),
+                      __builtin_fmaf(ra.z, acc[i][j][4 * g + 1], __builtin_fmaf(ra.w, c1, bias)),
+                      __builtin_fmaf(rb.x, acc[i][j][4 * g + 2], __builtin_fmaf(rb.y, c1, bias)),
+                      __builtin_fmaf(rb.z, acc[i][j][4 * g + 3], __builtin_fmaf(rb.w, c1, bias)));
+          } else {
+            o = pack4(acc[i][j][4 * g + 0] + bias, acc[i][j][4 * g + 1] + bias, acc[i][j][4 * g + 2] + bias, acc[i][j][4 * g + 3] + bias);
+          }
+          *reinterpret_cast<bf16x4*>(slab + (j * 32 + l31) * S::PITCH + (i * 32 + 8 * g + 4 * hi) * 2) = o;
         }
-        *reinterpret_cast<bf16x4*>(slab + (j * 32 + l31) * S::PITCH + (i * 32 + 8 * g + 4 * hi) * 2) =
-            pack4(__builtin_fmaf(ra.x, acc[i][j][4 * g + 0], __builtin_fmaf(ra.y, c1, bias)),
-                  __builtin_fmaf(ra.z, acc[i][j][4 * g + 1], __builtin_fmaf(ra.w, c1, bias)),
-                  __builtin_fmaf(rb.x, acc[i][j][4 * g + 2], __builtin_fmaf(rb.y, c1, bias)),
-                  __builtin_fmaf(rb.z, acc[i][j][4 * g + 3], __builtin_fmaf(rb.w, c1, bias)));
-      }
-  }
+    }
+  };
+  if (lna) park(std::true_type{}); else park(std::false_type{});
+  static_assert(WTN <= 64, "a wave tile lies inside one head");
   const int rr = lane / S::CPR, ch = lane % S::CPR;
-  const int b2 = mw / p.seq_pitch, pos0 = mw - b2 * p.seq_pitch;   // a wave tile never straddles samples (pitch % 128 == 0)
-  const int inner = p.heads * 64;
+  const int mwu = __builtin_amdgcn_readfirstlane(mw), nwu = __builtin_amdgcn_readfirstlane(nw);
+  const int b2 = mwu / p.seq_pitch, pos0 = mwu - b2 * p.seq_pitch;   // a wave tile never straddles samples (pitch % 128 == 0)
+  const int head = (nwu % (p.heads * 64)) >> 6;
+  // v^T is [b2][head][64 d][npad]: the window is this wave tile's WTN d-rows (none when the tile lies past M), a lane stores 8 positions of
+  // one of them.  Positions past seq_valid inside the pitch are padding columns of v^T (masked keys): storing them is harmless
+  const __amdgpu_buffer_rsrc_t wst = buf_rows(p.vt, ((long long)b2 * p.heads + head) * 64 + (nwu & 63), mwu < p.M ? WTN : 0, p.npad * 2);
+  int vo = (rr * p.npad + pos0 + ch * 8) * 2;
+  if (pos0 + ch * 8 >= p.npad) vo = BUF_OOB;
+  const int rstep = S::RPI * p.npad * 2;
 #pragma unroll
   for (int it = 0; it < S::ITERS; ++it) {
-    const int dl = it * S::RPI + rr;
-    const int n = nw + dl;
-    const u32x4 d = *reinterpret_cast<const u32x4*>(slab + dl * S::PITCH + ch * 16);
-    // positions past seq_valid inside the pitch are padding columns of v^T (masked keys): storing them is harmless
-    if (mw < p.M && pos0 + ch * 8 < p.npad) {
-      bf16_t* dst = p.vt + ((size_t)(b2 * p.heads + ((n % inner) >> 6)) * 64 + (n & 63)) * p.npad + pos0 + ch * 8;
-      store_wt_b128(dst, d);
-    }
+    const u32x4 d = *reinterpret_cast<const u32x4*>(slab + (it * S::RPI + rr) * S::PITCH + ch * 16);
+    __builtin_amdgcn_raw_buffer_store_b128(d, wst, vo + it * rstep, 0, BUF_SC1);
   }
 }
 
@@ -1060,7 +1015,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, int m
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
       f32x16 (&blk)[1][TJ] = *reinterpret_cast<f32x16 (*)[1][TJ]>(&acc[i]);
-      if (SWAP) epilogue_rows<EPI, 1, TJ>(p, blk, slab, m0 + wm * WTM + 32 * i, n0 + wn * WTN, lane);
+      if constexpr (SWAP) epilogue_rows<EPI, 1, TJ>(p, blk, slab, m0 + wm * WTM + 32 * i, n0 + wn * WTN, lane);
       else epilogue_vt<1, TJ>(p, blk, slab, m0 + wm * WTM + 32 * i, n0 + wn * WTN, lane, rs_lds + 2 * (wm * WTM + 32 * i));
     }
   }

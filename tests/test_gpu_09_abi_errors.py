@@ -76,6 +76,13 @@ def test_dit_bad_sample_arguments():
                 dict(cond_mask=None), dict(y=None), dict(t_grid=None), dict(text_len=0)):
         assert call(**bad) != 0, bad
         assert _err(L), bad
+    # ABI 200: a client built against another layout of lemas_sample_args is refused by its struct_size, with a message that says what to do
+    assert call(struct_size=0) != 0 and "struct_size" in _err(L)
+    assert call(struct_size=C.sizeof(_lib.SampleArgs) - 8) != 0 and "struct_size" in _err(L)
+    # cond_rows: 0 = `frames` rows (the old meaning), fewer rows are zero-filled on the device, more than `frames` is a caller bug
+    assert call(cond_rows=20) == 0
+    assert call(cond_rows=41) != 0 and _err(L)
+    torch.cuda.synchronize()
     # a non-monotone time grid is what torchdiffeq would reject (SURVEY a-O)
     tg[:] = [0.0, 0.6, 0.5]
     assert call() != 0 and "monoton" in _err(L).lower()
