@@ -27,15 +27,33 @@ __device__ __forceinline__ void store_wt_b64(void* p, unsigned int __attribute__
   asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 
+// Wave-wide sum / max, every lane gets the result.  The wave must be fully active (all call sites branch wave-uniformly).
+// Four DPP steps fold the 16 lanes of a row (xor 1, xor 2 as quad permutes, then row_half_mirror and row_mirror: by then every lane of a
+// quad / half row holds the same partial), four v_readlane + three adds fold the rows.  The __shfl_xor butterfly this replaces is six
+// DEPENDENT ds_bpermute round trips per reduction: 24 of them in a row were 1.4 us of the 5 us LayerNorm launch.
+template <int CTRL>
+__device__ __forceinline__ float dpp_lanes_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_lanes_f<0xB1>(v);     // quad_perm [1,0,3,2]
+  v += dpp_lanes_f<0x4E>(v);     // quad_perm [2,3,0,1]
+  v += dpp_lanes_f<0x141>(v);    // row_half_mirror
+  v += dpp_lanes_f<0x140>(v);    // row_mirror
+  const int b = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+  return (r0 + r1) + (r2 + r3);
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, dpp_lanes_f<0xB1>(v));
+  v = fmaxf(v, dpp_lanes_f<0x4E>(v));
+  v = fmaxf(v, dpp_lanes_f<0x141>(v));
+  v = fmaxf(v, dpp_lanes_f<0x140>(v));
+  const int b = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 
 // Activations: v_exp_f32 / v_rcp_f32 directly (1 ulp class) -- a precise fp32 division costs ~10 VALU instructions and
@@ -43,10 +61,24 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ float fast_sigmoid(float z) {   // 1 / (1 + e^-z); z -> -inf gives rcp(inf) = 0
   return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z));
 }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// GELU, tanh form, two values at a time: 0.5 x (1 + tanh(u)) = x * sigmoid(2u) = x / (1 + 2^(-log2(e) 2u)),  u = sqrt(2/pi) (x + 0.044715 x^3),
+// with -log2(e) folded into the polynomial: 2^(x (c1 + c2 x^2)).  Written on 2-vectors so that the five non-transcendental steps are packed
+// fp32 instructions (v_pk_mul / v_pk_fma / v_pk_add: one issue slot per PAIR): the GEMM epilogues this sits in are bound by VALU issue, and
+// the two quarter-rate instructions per value (v_exp, v_rcp) are 8 of its slots either way.  x -> -inf: 2^(+inf) = inf, rcp = 0, x * 0 = -0.
+__device__ __forceinline__ f32x2 gelu_tanh_f2(f32x2 x) {
+  const f32x2 c1 = {-2.302208198144325f, -2.302208198144325f}, c2 = {-0.1029432395800235f, -0.1029432395800235f}, one = {1.0f, 1.0f};
+  const f32x2 z = x * (x * x * c2 + c1);
+  f32x2 d;
+  d.x = __builtin_amdgcn_exp2f(z.x); d.y = __builtin_amdgcn_exp2f(z.y);
+  d = d + one;
+  f32x2 r;
+  r.x = __builtin_amdgcn_rcpf(d.x); r.y = __builtin_amdgcn_rcpf(d.y);
+  return x * r;
+}
 __device__ __forceinline__ float gelu_tanh_f(float x) {
-  // 0.5 x (1 + tanh(u)) = x * sigmoid(2u),  u = sqrt(2/pi) (x + 0.044715 x^3)
-  const float u2 = x * (1.5957691216057308f + 0.07135481627260025f * x * x);
-  return x * fast_sigmoid(u2);
+  const f32x2 v = {x, x};
+  return gelu_tanh_f2(v).x;
 }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
 __device__ __forceinline__ float silu_f(float x) { return x * fast_sigmoid(x); }

@@ -235,8 +235,9 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x16 (&acc)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const float4 bias = *reinterpret_cast<const float4*>(p.bias + nw + j * 32 + 8 * g + 4 * hi);
-        v[4 * g + 0] = gelu_tanh_f(acc[i][j][4 * g + 0] + bias.x); v[4 * g + 1] = gelu_tanh_f(acc[i][j][4 * g + 1] + bias.y);
-        v[4 * g + 2] = gelu_tanh_f(acc[i][j][4 * g + 2] + bias.z); v[4 * g + 3] = gelu_tanh_f(acc[i][j][4 * g + 3] + bias.w);
+        const f32x2 g01 = gelu_tanh_f2(f32x2{acc[i][j][4 * g + 0] + bias.x, acc[i][j][4 * g + 1] + bias.y});
+        const f32x2 g23 = gelu_tanh_f2(f32x2{acc[i][j][4 * g + 2] + bias.z, acc[i][j][4 * g + 3] + bias.w});
+        v[4 * g + 0] = g01.x; v[4 * g + 1] = g01.y; v[4 * g + 2] = g23.x; v[4 * g + 3] = g23.y;
         amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[4 * g + 0]), fabsf(v[4 * g + 1]))), fmaxf(fabsf(v[4 * g + 2]), fabsf(v[4 * g + 3])));
       }
       amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
@@ -575,8 +576,12 @@ __device__ __forceinline__ void epilogue_row_blocks(const GemmParams& p, f32x16 
             v2 = acc[i][j][4 * g + 2] + bias.z; v3 = acc[i][j][4 * g + 3] + bias.w;
           }
           bf16x4 o;
-          if (EPI == EPI_BIAS_GELU_BF16) o = pack4(gelu_tanh_f(v0), gelu_tanh_f(v1), gelu_tanh_f(v2), gelu_tanh_f(v3));
-          else o = pack4(v0, v1, v2, v3);
+          if (EPI == EPI_BIAS_GELU_BF16) {
+            const f32x2 g01 = gelu_tanh_f2(f32x2{v0, v1}), g23 = gelu_tanh_f2(f32x2{v2, v3});
+            o = pack4(g01.x, g01.y, g23.x, g23.y);
+          } else {
+            o = pack4(v0, v1, v2, v3);
+          }
           *reinterpret_cast<bf16x4*>(slab + l31 * S::PITCH + nl * 2) = o;
         }
       const __amdgpu_buffer_rsrc_t wst = buf_rows(p.out_bf16, (long long)mwu + 32 * i, pre.win.rl - 32 * i, p.ldc * 2);
