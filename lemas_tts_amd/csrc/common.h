@@ -119,14 +119,17 @@ __host__ __device__ __forceinline__ int xcd_grid(int tiles_m, int tiles_n, int g
   return 8 * bm * bn;
 }
 __device__ __forceinline__ bool xcd_tile_coords(int bid, int tiles_m, int tiles_n, int gx, int& tm, int& tn) {
-  const int gy = 8 / gx;
-  const int bm = (tiles_m + gx - 1) / gx, bn = (tiles_n + gy - 1) / gy;
+  // gx is 1, 2, 4 or 8: shifts, not divisions (every workgroup runs this before it can request its first operand tile, and a division by a
+  // run-time value is ~30 dependent scalar instructions: five of them were ~0.2 us of every GEMM workgroup's start)
+  const int lg = 31 - __builtin_clz((unsigned)gx), lgy = 3 - lg, gy = 1 << lgy;
+  const int bm = (tiles_m + gx - 1) >> lg, bn = (tiles_n + gy - 1) >> lgy;
   const int blk = bid & 7, idx = bid >> 3;
-  const int bi = blk / gy, bj = blk - bi * gy;
+  const int bi = blk >> lgy, bj = blk & (gy - 1);
   const int rows = min(bm, tiles_m - bi * bm), cols = min(bn, tiles_n - bj * bn);
   if (rows <= 0 || cols <= 0 || idx >= rows * cols) return false;
-  tm = bi * bm + idx / cols;
-  tn = bj * bn + idx % cols;
+  const int r = idx / cols;
+  tm = bi * bm + r;
+  tn = bj * bn + (idx - r * cols);
   return true;
 }
 // XCD block grid: fabric-side fetch ~ gy * |A| + gx * |W| -> minimise gy * M + gx * N

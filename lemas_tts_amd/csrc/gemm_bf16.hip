@@ -66,6 +66,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // 8 x (largest block) workgroups and the few beyond a smaller block's end return at once (xcd_grid / xcd_tile_coords).
 // (xcd_grid / xcd_tile_coords live in common.h: the fp32 GEMM uses the same mapping)
 // tile of workgroup `bid`: one block per XCD (default) or, for A/B measurements, round 3's equal runs (GemmParams::xcd_runs); false = surplus workgroup
+// Request the operand pointers together with the first kernel arguments: left alone, the compiler loads them (s_load from the kernarg segment)
+// where they are first used, i.e. AFTER the tile coordinates are known, and a second scalar-memory round trip sits in front of the first
+// operand request of every workgroup.
+__device__ __forceinline__ void kernargs_early(const GemmParams& p) {
+  asm volatile("" ::"s"(p.A), "s"(p.W), "s"(p.K), "s"(p.M), "s"(p.N));
+}
 __device__ __forceinline__ void tile_coords(int seq, int tiles_m, int tiles_n, int gx, int& tm, int& tn);
 __device__ __forceinline__ bool tile_of(int bid, int tiles_m, int tiles_n, int gx, int runs, int& tm, int& tn) {
   if (runs) {
@@ -1375,6 +1381,7 @@ template <int EPI>
 __global__ __launch_bounds__(512) void gemm_pp2_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int tm, tn;
+  kernargs_early(p);
   if (!tile_of(blockIdx.x, (p.M + 255) / 256, p.N / 128, p.xcd_gx, p.xcd_runs, tm, tn)) return;
   gemm_body_pp2<EPI, EPI != EPI_V_T>(p, smem, tm * 256, tn * 128, reinterpret_cast<float*>(smem + 3 * (256 + 128) * 128));
 }
@@ -1400,6 +1407,7 @@ template <int EPI>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int tm, tn;
+  kernargs_early(p);
   if (!tile_of(blockIdx.x, (p.M + 255) / 256, p.N / 256, p.xcd_gx, p.xcd_runs, tm, tn)) return;
   gemm_body_pp<EPI, EPI != EPI_V_T>(p, smem, tm * 256, tn * 256, reinterpret_cast<float*>(smem + 8 * 16384));
 }
@@ -1433,6 +1441,7 @@ template <int EPI, int TBM, int TBN, int NSTAGE, int NWM, int NWN, bool F8>
 __global__ __launch_bounds__(64 * NWM * NWN) void gemm_bf16_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int tm, tn;
+  kernargs_early(p);
   if (!tile_of(blockIdx.x, (p.M + TBM - 1) / TBM, p.N / TBN, p.xcd_gx, p.xcd_runs, tm, tn)) return;
   gemm_body<EPI, TBM, TBN, NSTAGE, NWM, NWN, EPI != EPI_V_T, F8>(p, smem, tm * TBM, tn * TBN,
       reinterpret_cast<float*>(smem + body_lds_base<EPI, TBM, TBN, NSTAGE, NWM, NWN, F8>()));
@@ -1579,10 +1588,12 @@ __global__ __launch_bounds__(64 * TileCfg<TILE>::WM * TileCfg<TILE>::WN) void ge
   float* rs = reinterpret_cast<float*>(smem + QkvLds<F8, TILE>::base);
   int tm, tn;
   if (bid < tiles_q) {       // tiles_q / tiles_v: the PADDED workgroup counts of the two parts (multiples of 8: both parts keep the XCD phase)
+    kernargs_early(pq);
     if (!tile_of(bid, (pq.M + C::BM - 1) / C::BM, pq.N / C::BN, pq.xcd_gx, pq.xcd_runs, tm, tn)) return;
     if constexpr (!F8 && TILE == T256x128) gemm_body_pp2<EPI_QK_ROPE, true>(pq, smem, tm * 256, tn * 128, rs);
     else gemm_body<EPI_QK_ROPE, C::BM, C::BN, C::ST, C::WM, C::WN, true, F8>(pq, smem, tm * C::BM, tn * C::BN, rs);
   } else {
+    kernargs_early(pv);
     if (!tile_of(bid - tiles_q, (pv.M + C::BM - 1) / C::BM, pv.N / C::BN, pv.xcd_gx, pv.xcd_runs, tm, tn)) return;
     if constexpr (!F8 && TILE == T256x128) gemm_body_pp2<EPI_V_T, false>(pv, smem, tm * 256, tn * 128, rs);
     else gemm_body<EPI_V_T, C::BM, C::BN, C::ST, C::WM, C::WN, false, F8>(pv, smem, tm * C::BM, tn * C::BN, rs);
