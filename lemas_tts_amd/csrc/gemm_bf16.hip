@@ -361,7 +361,7 @@ struct EpiPre {
 // through the slab.
 // `lnx`: ln fold (GemmParams), consumer epilogues: the (r, -r mu) pairs of this wave tile's rows in LDS ([row][2], written by
 // ln_rowstat_store at the top of the kernel).  The producer side (EPI_GATE_RES with xs_out) needs nothing from the caller.
-template <int EPI, int TI, int TJ, bool COLS_ONCE, bool AHEAD = true, int LNA = (epi_lna<EPI>() ? 1 : 0)>
+template <int EPI, int TI, int TJ, bool COLS_ONCE, int AHEAD = 1, int LNA = (epi_lna<EPI>() ? 1 : 0)>
 __device__ __forceinline__ void epilogue_row_blocks(const GemmParams& p, f32x16 (&acc)[TI][TJ], char* slab, int mw, int nw, int lane,
                                                     EpiPre<EPI, TJ, COLS_ONCE, LNA>& pre, const float* lnx = nullptr) {
   static_assert(EPI != EPI_BIAS_GELU_F8 && EPI != EPI_V_T, "bf16-path row epilogues only");
@@ -412,10 +412,12 @@ __device__ __forceinline__ void epilogue_row_blocks(const GemmParams& p, f32x16 
 #pragma unroll
       for (int i = 0; i < TI; ++i) {
         float4 xin[Pre::NR];
-        if (AHEAD || i == 0) {
+        // residual rows of block i + 1: requested before this block goes through the slab (AHEAD 1), or right after its accumulators
+        // were parked there (AHEAD 2: the 256 x 256 tile, where the 32 registers of the next rows only exist once a block's are free)
+        if (AHEAD != 0 || i == 0) {
 #pragma unroll
           for (int it = 0; it < Pre::NR; ++it) xin[it] = i == 0 ? pre.r0[it] : xnext[it];
-          if (AHEAD && i + 1 < TI) pre.load_rows(p, mw, nw, lane, i + 1, xnext, unused);
+          if (AHEAD == 1 && i + 1 < TI) pre.load_rows(p, mw, nw, lane, i + 1, xnext, unused);
         } else {
           pre.load_rows(p, mw, nw, lane, i, xin, unused);
         }
@@ -429,6 +431,7 @@ __device__ __forceinline__ void epilogue_row_blocks(const GemmParams& p, f32x16 
                 make_float4(gt.x * (acc[i][j][4 * g + 0] + bias.x), gt.y * (acc[i][j][4 * g + 1] + bias.y),
                             gt.z * (acc[i][j][4 * g + 2] + bias.z), gt.w * (acc[i][j][4 * g + 3] + bias.w));
           }
+        if (AHEAD == 2 && i + 1 < TI) pre.load_rows(p, mw, nw, lane, i + 1, xnext, unused);
         const __amdgpu_buffer_rsrc_t wst = buf_rows(p.out_f32, (long long)mwu + 32 * i, rl - 32 * i, p.ldc * 4);
         float k1 = 0.f, k2 = 0.f;      // ln fold: the (sum, sum of squares) pair this lane will publish for the block
 #pragma unroll
@@ -490,7 +493,10 @@ __device__ __forceinline__ void epilogue_row_blocks(const GemmParams& p, f32x16 
       float4 cs[ITERS], sn[ITERS];
 #pragma unroll
       for (int it = 0; it < ITERS; ++it) { cs[it] = i == 0 ? pre.r0[it] : cnext[it]; sn[it] = i == 0 ? pre.r1[it] : snext[it]; }
-      if (i + 1 < TI) pre.load_rows(p, mw, nw, lane, i + 1, cnext, snext);
+      // the RoPE rows of block i + 1: requested here, or (wave tiles of four blocks: 128 accumulator registers) once this block's
+      // accumulators are parked in the slab and their registers are free
+      constexpr bool LATE = false;      // (tried for four-block wave tiles: the compiler spills MORE, 148 vs 124 B of scratch in the 256 x 256 QK kernel)
+      if (!LATE && i + 1 < TI) pre.load_rows(p, mw, nw, lane, i + 1, cnext, snext);
       float r = 1.0f, nrm = 0.f;
       if constexpr (L) row_rn(i, r, nrm);
 #pragma unroll
@@ -512,6 +518,7 @@ __device__ __forceinline__ void epilogue_row_blocks(const GemmParams& p, f32x16 
           }
           *reinterpret_cast<float4*>(slab + l31 * S::PITCH + nl * 4) = v;
         }
+      if (LATE && i + 1 < TI) pre.load_rows(p, mw, nw, lane, i + 1, cnext, snext);
 #pragma unroll
       for (int it = 0; it < ITERS; ++it) {
         const float4 c = cs[it], sv = sn[it];
@@ -1021,7 +1028,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, int m
   // the slab can be rewritten right after it was read): keeps the kernel's LDS footprint = the ring, not ring + big slabs
   char* slab = smem + wave * slab_bytes<EPI, 32, WTN>();
   if constexpr (SWAP && EPI != EPI_BIAS_GELU_F8) {
-    epilogue_row_blocks<EPI, TI, TJ, true, true, LNA>(p, acc, slab, m0 + wm * WTM, n0 + wn * WTN, lane, pre, rs_lds + 2 * (wm * WTM));
+    epilogue_row_blocks<EPI, TI, TJ, true, 1, LNA>(p, acc, slab, m0 + wm * WTM, n0 + wn * WTN, lane, pre, rs_lds + 2 * (wm * WTM));
   } else {
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
@@ -1196,14 +1203,16 @@ __device__ __forceinline__ void gemm_body_pp(const GemmParams& p, char* smem, in
   if constexpr (SWAP) {
     // 128 accumulator registers are still live here: the gate + residual epilogue has no room for its column vectors or a second
     // set of residual rows (and gained nothing from them: at full chip it is bound by the fp32 read-modify-write traffic), and
-    // the loop (224-256 VGPRs) none for an early request
+    // the loop (224-256 VGPRs) none for an early request.  (Round 4, AHEAD 2: the next block's rows requested once a block's
+    // accumulators are parked -- 56 B of scratch and SLOWER: 88.2 -> 91.2 us at M = 30720, K = 1024, 141.6 -> 152.5 at K = 2048,
+    // configs[3] -1.1 %; profiles/r04_gate_epilogue_prefetch_256x256.txt)
     constexpr int LNA = epi_lna<EPI>() ? 2 : 0;
     EpiPre<EPI, 2, EPI != EPI_GATE_RES, LNA> pre;
     pre.load(p, m0 + wm * 128, n0 + wn * 64, lane);
     if constexpr (EPI == EPI_GATE_RES) {
-      epilogue_row_blocks<EPI, 4, 2, false, false, LNA>(p, acc, slab, m0 + wm * 128, n0 + wn * 64, lane, pre);
+      epilogue_row_blocks<EPI, 4, 2, false, 0, LNA>(p, acc, slab, m0 + wm * 128, n0 + wn * 64, lane, pre);
     } else {
-      epilogue_row_blocks<EPI, 4, 2, true, true, LNA>(p, acc, slab, m0 + wm * 128, n0 + wn * 64, lane, pre, rs_lds + 2 * (wm * 128));
+      epilogue_row_blocks<EPI, 4, 2, true, 1, LNA>(p, acc, slab, m0 + wm * 128, n0 + wn * 64, lane, pre, rs_lds + 2 * (wm * 128));
     }
   } else {
 #pragma unroll
