@@ -54,59 +54,75 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Params p) {
 
   const int nk = (p.K + TK - 1) / TK;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 ra0 = z4, ra1 = z4, rb0 = z4, rb1 = z4;
-  // every load is unconditional from a clamped (always valid) address and zeroed afterwards: a `cond ? *p : 0` form made the compiler
-  // select between the pointer and a zero it parked in scratch memory, and load through the flat path
-#define LEMAS_F32_LD(dst, ptr, ok, koff)                                   \
-  do {                                                                      \
-    const float4 t_ = *reinterpret_cast<const float4*>((ptr) + (koff));     \
-    dst = make_float4((ok) ? t_.x : 0.f, (ok) ? t_.y : 0.f, (ok) ? t_.z : 0.f, (ok) ? t_.w : 0.f); \
-  } while (0)
-#define LEMAS_F32_GLOAD(kt)                                                                         \
+  // TWO register sets (x, y): the global loads of K-tiles t+2 and t+3 are in flight while tile t is multiplied and tile t+1 sits in the other
+  // LDS buffer.  With one set (round 4's first form, and the 16-k kernel before it) a workgroup had ONE K-tile of loads in flight and every
+  // iteration waited for an L2 / fabric round trip: 2.3 us per 32-k tile for the vocoder's pointwise convolutions against 0.43 us of MFMA work.
+  float4 ra0x = z4, ra1x = z4, rb0x = z4, rb1x = z4, ra0y = z4, ra1y = z4, rb0y = z4, rb1y = z4;
+  // every load is unconditional from a clamped (always valid) address; rows / k groups outside the problem are zeroed when the set is
+  // PARKED, not where it is loaded: a select right behind the load is a use, and the compiler put `s_waitcnt vmcnt(0)` there -- the loads
+  // never overlapped the MFMAs at all.  (A `cond ? *p : 0` form is worse still: a pointer select against a zero parked in scratch, flat loads.)
+#define LEMAS_F32_GLOAD(S, kt)                                                                      \
   do {                                                                                              \
     const bool kin = (kt) * TK + lk4 < p.K; /* K % 4 == 0: a float4 is inside or outside as a whole */ \
-    const int koff = kin ? (kt) * TK : -lk4; /* outside: the row's first float4 (valid), zeroed below */ \
-    LEMAS_F32_LD(ra0, ap0, a_ok0 && kin, koff);                                                     \
-    if (AQ == 2) LEMAS_F32_LD(ra1, ap1, a_ok1 && kin, koff);                                        \
-    LEMAS_F32_LD(rb0, bp0, b_ok0 && kin, koff);                                                     \
-    LEMAS_F32_LD(rb1, bp1, b_ok1 && kin, koff);                                                     \
+    const int koff = kin ? (kt) * TK : -lk4; /* outside: the row's first float4 (valid), zeroed at the park */ \
+    ra0##S = *reinterpret_cast<const float4*>(ap0 + koff);                                          \
+    if (AQ == 2) ra1##S = *reinterpret_cast<const float4*>(ap1 + koff);                             \
+    rb0##S = *reinterpret_cast<const float4*>(bp0 + koff);                                          \
+    rb1##S = *reinterpret_cast<const float4*>(bp1 + koff);                                          \
   } while (0)
-#define LEMAS_F32_PARK(buf)                                                                         \
+#define LEMAS_F32_SEL(v, ok) make_float4((ok) ? (v).x : 0.f, (ok) ? (v).y : 0.f, (ok) ? (v).z : 0.f, (ok) ? (v).w : 0.f)
+#define LEMAS_F32_PARK(S, buf, kt)                                                                  \
   do {                                                                                              \
-    *reinterpret_cast<float4*>(&As[buf][lrow][lk4]) = ra0;                                          \
-    if (AQ == 2) *reinterpret_cast<float4*>(&As[buf][(lrow + 32) % TM][lk4]) = ra1;                 \
-    *reinterpret_cast<float4*>(&Bs[buf][lrow][lk4]) = rb0;                                          \
-    *reinterpret_cast<float4*>(&Bs[buf][lrow + 32][lk4]) = rb1;                                     \
+    const bool kin = (kt) * TK + lk4 < p.K;                                                         \
+    *reinterpret_cast<float4*>(&As[buf][lrow][lk4]) = LEMAS_F32_SEL(ra0##S, a_ok0 && kin);          \
+    if (AQ == 2) *reinterpret_cast<float4*>(&As[buf][(lrow + 32) % TM][lk4]) = LEMAS_F32_SEL(ra1##S, a_ok1 && kin); \
+    *reinterpret_cast<float4*>(&Bs[buf][lrow][lk4]) = LEMAS_F32_SEL(rb0##S, b_ok0 && kin);          \
+    *reinterpret_cast<float4*>(&Bs[buf][lrow + 32][lk4]) = LEMAS_F32_SEL(rb1##S, b_ok1 && kin);     \
   } while (0)
 #define LEMAS_F32_MFMA4(av, bv0, bv1, c0, c1)                                  \
   c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(bv0, av, c0, 0, 0, 0); /* C^T: see the epilogue */ \
   c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(bv1, av, c1, 0, 0, 0);
-  LEMAS_F32_GLOAD(0);
-  LEMAS_F32_PARK(0);
+#define LEMAS_F32_TILE(cur)                                                                                                          \
+  _Pragma("unroll") for (int h = 0; h < 2; ++h) { /* two 16-k halves of the tile */                                                  \
+    const float4 a0 = *reinterpret_cast<const float4*>(&As[cur][wm * (TM / 2) + l15][h * 16 + lk * 4]);                             \
+    const float4 a1 = TI == 2 ? *reinterpret_cast<const float4*>(&As[cur][(wm * (TM / 2) + 16 + l15) % TM][h * 16 + lk * 4]) : z4;  \
+    const float4 b0 = *reinterpret_cast<const float4*>(&Bs[cur][wn * 32 + l15][h * 16 + lk * 4]);                                   \
+    const float4 b1 = *reinterpret_cast<const float4*>(&Bs[cur][wn * 32 + 16 + l15][h * 16 + lk * 4]);                              \
+    LEMAS_F32_MFMA4(a0.x, b0.x, b1.x, acc00, acc01)                                                                                  \
+    if (TI == 2) { LEMAS_F32_MFMA4(a1.x, b0.x, b1.x, acc10, acc11) }                                                                 \
+    LEMAS_F32_MFMA4(a0.y, b0.y, b1.y, acc00, acc01)                                                                                  \
+    if (TI == 2) { LEMAS_F32_MFMA4(a1.y, b0.y, b1.y, acc10, acc11) }                                                                 \
+    LEMAS_F32_MFMA4(a0.z, b0.z, b1.z, acc00, acc01)                                                                                  \
+    if (TI == 2) { LEMAS_F32_MFMA4(a1.z, b0.z, b1.z, acc10, acc11) }                                                                 \
+    LEMAS_F32_MFMA4(a0.w, b0.w, b1.w, acc00, acc01)                                                                                  \
+    if (TI == 2) { LEMAS_F32_MFMA4(a1.w, b0.w, b1.w, acc10, acc11) }                                                                 \
+  }
+  LEMAS_F32_GLOAD(x, 0);
+  LEMAS_F32_PARK(x, 0, 0);
+  const int last = nk - 1;
+  LEMAS_F32_GLOAD(x, min(1, last));
+  LEMAS_F32_GLOAD(y, min(2, last));
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) LEMAS_F32_GLOAD(kt + 1);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {                    // two 16-k halves of the tile
-      const float4 a0 = *reinterpret_cast<const float4*>(&As[cur][wm * (TM / 2) + l15][h * 16 + lk * 4]);
-      const float4 a1 = TI == 2 ? *reinterpret_cast<const float4*>(&As[cur][(wm * (TM / 2) + 16 + l15) % TM][h * 16 + lk * 4]) : z4;
-      const float4 b0 = *reinterpret_cast<const float4*>(&Bs[cur][wn * 32 + l15][h * 16 + lk * 4]);
-      const float4 b1 = *reinterpret_cast<const float4*>(&Bs[cur][wn * 32 + 16 + l15][h * 16 + lk * 4]);
-      LEMAS_F32_MFMA4(a0.x, b0.x, b1.x, acc00, acc01)
-      if (TI == 2) { LEMAS_F32_MFMA4(a1.x, b0.x, b1.x, acc10, acc11) }
-      LEMAS_F32_MFMA4(a0.y, b0.y, b1.y, acc00, acc01)
-      if (TI == 2) { LEMAS_F32_MFMA4(a1.y, b0.y, b1.y, acc10, acc11) }
-      LEMAS_F32_MFMA4(a0.z, b0.z, b1.z, acc00, acc01)
-      if (TI == 2) { LEMAS_F32_MFMA4(a1.z, b0.z, b1.z, acc10, acc11) }
-      LEMAS_F32_MFMA4(a0.w, b0.w, b1.w, acc00, acc01)
-      if (TI == 2) { LEMAS_F32_MFMA4(a1.w, b0.w, b1.w, acc10, acc11) }
-    }
-    if (kt + 1 < nk) LEMAS_F32_PARK(cur ^ 1);        // that buffer was last read in iteration kt - 1: every wave is past the barrier that ended it
+  // Two K-tiles per trip: tile kt from buffer 0 while set x (tile kt+1) is parked in buffer 1 and refilled with tile kt+3, then tile kt+1
+  // from buffer 1 while set y (tile kt+2) goes to buffer 0 and is refilled with tile kt+4.  A buffer is rewritten one barrier after its last
+  // read; a set is parked two half-trips after it was requested.  The body is branch-free on purpose -- requests past the last tile re-read
+  // the last one, parks past it write zeros nobody reads: with conditionals inside, the compiler's wait-count bookkeeping gives up at the
+  // loop edge and waits for EVERY load in flight (vmcnt 0) at each park, which halves the look-ahead again.
+  int kt = 0;
+  for (; kt + 1 < nk; kt += 2) {
+    LEMAS_F32_PARK(x, 1, kt + 1);
+    LEMAS_F32_GLOAD(x, min(kt + 3, last));
+    LEMAS_F32_TILE(0)
+    __syncthreads();
+    LEMAS_F32_PARK(y, 0, kt + 2);
+    LEMAS_F32_GLOAD(y, min(kt + 4, last));
+    LEMAS_F32_TILE(1)
     __syncthreads();
   }
+  if (nk & 1) { LEMAS_F32_TILE(0) }        // an odd tile count: the last tile was parked in buffer 0 by the final trip (or is tile 0)
+#undef LEMAS_F32_TILE
 #undef LEMAS_F32_GLOAD
-#undef LEMAS_F32_LD
+#undef LEMAS_F32_SEL
 #undef LEMAS_F32_PARK
 #undef LEMAS_F32_MFMA4
   const f32x4 acc[2][2] = {{acc00, acc01}, {acc10, acc11}};
