@@ -57,27 +57,35 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Params p) {
   // TWO register sets (x, y): the global loads of K-tiles t+2 and t+3 are in flight while tile t is multiplied and tile t+1 sits in the other
   // LDS buffer.  With one set (round 4's first form, and the 16-k kernel before it) a workgroup had ONE K-tile of loads in flight and every
   // iteration waited for an L2 / fabric round trip: 2.3 us per 32-k tile for the vocoder's pointwise convolutions against 0.43 us of MFMA work.
-  float4 ra0x = z4, ra1x = z4, rb0x = z4, rb1x = z4, ra0y = z4, ra1y = z4, rb0y = z4, rb1y = z4;
+  const f32x4 zv = {0.f, 0.f, 0.f, 0.f};
+  f32x4 ra0x = zv, ra1x = zv, rb0x = zv, rb1x = zv, ra0y = zv, ra1y = zv, rb0y = zv, rb1y = zv;
   // every load is unconditional from a clamped (always valid) address; rows / k groups outside the problem are zeroed when the set is
   // PARKED, not where it is loaded: a select right behind the load is a use, and the compiler put `s_waitcnt vmcnt(0)` there -- the loads
   // never overlapped the MFMAs at all.  (A `cond ? *p : 0` form is worse still: a pointer select against a zero parked in scratch, flat loads.)
+  // The loads are asm (invisible to the compiler's wait-count bookkeeping, like the fragment reads of the bf16 GEMM) and every park waits
+  // with an exact count: only for ITS set, the other set's NLD loads -- requested after it -- stay in flight.  Left to the compiler the park
+  // at the head of a trip waits for everything (vmcnt 0 at the loop edge) and the younger set loses half of its look-ahead.
+#define LEMAS_F32_ASMLD(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst) : "v"(ptr) : "memory")
 #define LEMAS_F32_GLOAD(S, kt)                                                                      \
   do {                                                                                              \
     const bool kin = (kt) * TK + lk4 < p.K; /* K % 4 == 0: a float4 is inside or outside as a whole */ \
     const int koff = kin ? (kt) * TK : -lk4; /* outside: the row's first float4 (valid), zeroed at the park */ \
-    ra0##S = *reinterpret_cast<const float4*>(ap0 + koff);                                          \
-    if (AQ == 2) ra1##S = *reinterpret_cast<const float4*>(ap1 + koff);                             \
-    rb0##S = *reinterpret_cast<const float4*>(bp0 + koff);                                          \
-    rb1##S = *reinterpret_cast<const float4*>(bp1 + koff);                                          \
+    LEMAS_F32_ASMLD(ra0##S, ap0 + koff);                                                            \
+    if (AQ == 2) LEMAS_F32_ASMLD(ra1##S, ap1 + koff);                                               \
+    LEMAS_F32_ASMLD(rb0##S, bp0 + koff);                                                            \
+    LEMAS_F32_ASMLD(rb1##S, bp1 + koff);                                                            \
   } while (0)
-#define LEMAS_F32_SEL(v, ok) make_float4((ok) ? (v).x : 0.f, (ok) ? (v).y : 0.f, (ok) ? (v).z : 0.f, (ok) ? (v).w : 0.f)
-#define LEMAS_F32_PARK(S, buf, kt)                                                                  \
+#define LEMAS_F32_SEL(v, ok) ((ok) ? (v) : zv)
+  // (the wait names the set's registers as read-write operands: without that data dependence the compiler hoists the selects below ABOVE
+  // the wait -- seen in the ISA -- and parks registers the loads have not reached yet)
+#define LEMAS_F32_PARK(S, buf, kt, INFLIGHT)                                                        \
   do {                                                                                              \
     const bool kin = (kt) * TK + lk4 < p.K;                                                         \
-    *reinterpret_cast<float4*>(&As[buf][lrow][lk4]) = LEMAS_F32_SEL(ra0##S, a_ok0 && kin);          \
-    if (AQ == 2) *reinterpret_cast<float4*>(&As[buf][(lrow + 32) % TM][lk4]) = LEMAS_F32_SEL(ra1##S, a_ok1 && kin); \
-    *reinterpret_cast<float4*>(&Bs[buf][lrow][lk4]) = LEMAS_F32_SEL(rb0##S, b_ok0 && kin);          \
-    *reinterpret_cast<float4*>(&Bs[buf][lrow + 32][lk4]) = LEMAS_F32_SEL(rb1##S, b_ok1 && kin);     \
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(ra0##S), "+v"(ra1##S), "+v"(rb0##S), "+v"(rb1##S) : "n"(INFLIGHT) : "memory"); \
+    *reinterpret_cast<f32x4*>(&As[buf][lrow][lk4]) = LEMAS_F32_SEL(ra0##S, a_ok0 && kin);           \
+    if (AQ == 2) *reinterpret_cast<f32x4*>(&As[buf][(lrow + 32) % TM][lk4]) = LEMAS_F32_SEL(ra1##S, a_ok1 && kin); \
+    *reinterpret_cast<f32x4*>(&Bs[buf][lrow][lk4]) = LEMAS_F32_SEL(rb0##S, b_ok0 && kin);           \
+    *reinterpret_cast<f32x4*>(&Bs[buf][lrow + 32][lk4]) = LEMAS_F32_SEL(rb1##S, b_ok1 && kin);      \
   } while (0)
 #define LEMAS_F32_MFMA4(av, bv0, bv1, c0, c1)                                  \
   c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(bv0, av, c0, 0, 0, 0); /* C^T: see the epilogue */ \
@@ -97,8 +105,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Params p) {
     LEMAS_F32_MFMA4(a0.w, b0.w, b1.w, acc00, acc01)                                                                                  \
     if (TI == 2) { LEMAS_F32_MFMA4(a1.w, b0.w, b1.w, acc10, acc11) }                                                                 \
   }
+  constexpr int NLD = AQ == 2 ? 4 : 3;      // loads per set
   LEMAS_F32_GLOAD(x, 0);
-  LEMAS_F32_PARK(x, 0, 0);
+  LEMAS_F32_PARK(x, 0, 0, 0);
   const int last = nk - 1;
   LEMAS_F32_GLOAD(x, min(1, last));
   LEMAS_F32_GLOAD(y, min(2, last));
@@ -110,19 +119,23 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Params p) {
   // loop edge and waits for EVERY load in flight (vmcnt 0) at each park, which halves the look-ahead again.
   int kt = 0;
   for (; kt + 1 < nk; kt += 2) {
-    LEMAS_F32_PARK(x, 1, kt + 1);
+    LEMAS_F32_PARK(x, 1, kt + 1, NLD);
     LEMAS_F32_GLOAD(x, min(kt + 3, last));
     LEMAS_F32_TILE(0)
     __syncthreads();
-    LEMAS_F32_PARK(y, 0, kt + 2);
+    LEMAS_F32_PARK(y, 0, kt + 2, NLD);
     LEMAS_F32_GLOAD(y, min(kt + 4, last));
     LEMAS_F32_TILE(1)
     __syncthreads();
   }
+  // The tail's redundant requests must land before their registers mean anything else: the compiler sees both sets dead past the loop and
+  // would hand the registers out while the loads are still in flight (the operands keep them alive up to the wait).
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra0x), "+v"(ra1x), "+v"(rb0x), "+v"(rb1x), "+v"(ra0y), "+v"(ra1y), "+v"(rb0y), "+v"(rb1y)::"memory");
   if (nk & 1) { LEMAS_F32_TILE(0) }        // an odd tile count: the last tile was parked in buffer 0 by the final trip (or is tile 0)
 #undef LEMAS_F32_TILE
 #undef LEMAS_F32_GLOAD
 #undef LEMAS_F32_SEL
+#undef LEMAS_F32_ASMLD
 #undef LEMAS_F32_PARK
 #undef LEMAS_F32_MFMA4
   const f32x4 acc[2][2] = {{acc00, acc01}, {acc10, acc11}};
