@@ -8,13 +8,15 @@
 //     step (modules.py:311,332,727-731) -- the t-grid is known up front;
 //   * once per ODE step: the K=100 "x" part of the input projection (keeps the ODE state path in fp32);
 //   * the Vocos vocoder (all of it: embed conv as im2col GEMM, pointwise convs, head, inverse DFT).
-// Tile TM x 64 x 32 (TM = 64; 32 for problems of at most 32 rows), 4 waves as 2x2, each wave (TM/2) x 32 outputs.
+// Tile TM x 64 x 32 (TM = 64, or 32 for small grids: launch()), 4 waves as 2x2, each wave (TM/2) x 32 outputs.
 // LDS tiles are row-major [row][32 k + 4 pad]: a thread parks the float4 it loaded with ONE ds_write_b128 and a lane fetches the four k
 // values of its (row, k-group) with ONE ds_read_b128 (the 16 lanes of a read group hit 16 different 4-bank groups: row pitch 36 words), i.e.
 // MFMA j of a 16-k half takes k = 4 lk + j instead of 4 j + lk -- A and W use the same assignment, so every product meets its partner and only
-// the order of the fp32 additions inside a 16-k group differs from the textbook one.  Two LDS buffers: the global loads of tile t+1 are in
-// registers while tile t is multiplied, one __syncthreads per K-tile.  (Round 4: the previous form -- 16-k tiles, scalar LDS traffic, two
-// barriers per tile -- ran the vocoder's pointwise convolutions at 16-24 % of the fp32 matrix peak.)
+// the order of the fp32 additions inside a 16-k group differs from the textbook one.  Two LDS buffers and TWO register sets: while tile t is
+// multiplied, tile t+1 sits in the other buffer and the global loads of tiles t+2 and t+3 are in flight (asm loads, exact wait counts), one
+// __syncthreads per K-tile.  Round-4 history of the vocoder decode at L = 938 (profiles/r04_vocoder_f32_gemm.txt): 0.94 ms with every
+// load waited for where it was issued (a select behind the load), 0.79 with the loads overlapping the MFMAs, 0.77 with exact wait counts,
+// 0.59 with 32-row tiles on the under-filled grids.
 #include "common.h"
 
 namespace {
@@ -203,11 +205,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Params p) {
 template <int EPI>
 hipError_t launch(const GemmF32Params& p, hipStream_t s) {
   const int gn = (p.N + TN - 1) / TN, nb = p.nbatch > 0 ? p.nbatch : 1;
-  // 64-row tiles; the 32-row form only for problems of at most 32 rows (the per-utterance GEMVs: prosody projections, the time MLP).  Measured:
-  // for the vocoder's N = 512 convolutions at L ~ 900 (120 workgroups of 64 rows against 240 of 32) the taller tile is the faster one,
-  // 59 vs 66 us (profiles/r04a_kernel_stats_configs1.txt) -- more workgroups do not help a loop whose K-tiles are a dependent chain
-  if (p.M <= 32) {
-    hipLaunchKernelGGL((gemm_f32_kernel<EPI, 32>), dim3(gn, 1, nb), dim3(256), 0, s, p);
+  // 64-row tiles for big grids; the 32-row form for problems of at most 32 rows (the per-utterance GEMVs: prosody projections, the time MLP)
+  // and for grids of fewer than 400 64-row workgroups, i.e. under ~1.5 per CU (the vocoder at L ~ 900: N = 512 convolutions 120 -> 240
+  // workgroups, 43.9 -> 27.9 us; N = 1536 360 -> 720, 28.9 -> 23.9 us).  Measured both ways: while a workgroup's loads did not overlap its
+  // MFMAs the taller tile won (59 vs 66 us); with the loads in flight across two K-tiles the bound is what a CU can pull out of L2
+  // (~11 B per cycle) and how evenly the workgroups cover the CUs, and the smaller tile wins on both counts at these sizes.
+  const long g64 = (long)gn * ((p.M + 63) / 64) * nb;
+  if (p.M <= 32 || g64 < 400) {
+    hipLaunchKernelGGL((gemm_f32_kernel<EPI, 32>), dim3(gn, (p.M + 31) / 32, nb), dim3(256), 0, s, p);
   } else {
     hipLaunchKernelGGL((gemm_f32_kernel<EPI, 64>), dim3(gn, (p.M + 63) / 64, nb), dim3(256), 0, s, p);
   }
