@@ -36,25 +36,41 @@ __global__ __launch_bounds__(256, 2) void convpos_kernel(const ConvPosParams p) 
   const int f0 = blockIdx.x * FB;
   const int N = p.n, C = p.channels, taps = p.taps, half = taps / 2;
 
-  // ---- stage the input slab (frames f0-half .. f0+FB+half-1), zero outside [0, N)
-  for (int t = tid; t < SLAB_ROWS * 8; t += 256) {
-    const int r = t >> 3, ch = t & 7;
-    const int f = f0 - half + r;
-    u32x4 v = u32x4{0u, 0u, 0u, 0u};
-    if (f >= 0 && f < N && r < FB + taps - 1) {
-      const size_t off = ((size_t)b * p.pitch + f) * C + g * CG + ch * 8;
-      if (FIRST) {
-        const float4 a = *reinterpret_cast<const float4*>(p.in_f32 + off);
-        const float4 c = *reinterpret_cast<const float4*>(p.in_f32 + off + 4);
-        bf16x8 w;
-        w[0] = (bf16_t)a.x; w[1] = (bf16_t)a.y; w[2] = (bf16_t)a.z; w[3] = (bf16_t)a.w;
-        w[4] = (bf16_t)c.x; w[5] = (bf16_t)c.y; w[6] = (bf16_t)c.z; w[7] = (bf16_t)c.w;
-        v = __builtin_bit_cast(u32x4, w);
-      } else {
-        v = *reinterpret_cast<const u32x4*>(p.in_bf16 + off);
-      }
+  // ---- stage the input slab (frames f0-half .. f0+FB+half-1), zero outside [0, N).  All of a thread's chunks are requested before the
+  // first one is converted: every load is unconditional from a clamped frame and zeroed by a select at the LDS write (with the load inside
+  // the `if`, each of the five trips waited for its own round trip to L2 / the fabric: ~5 us of a 20 us launch).
+  constexpr int NCH = (SLAB_ROWS * 8 + 255) / 256;
+  u32x4 sv[NCH][FIRST ? 2 : 1];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int t = tid + 256 * i, r = t >> 3, ch = t & 7;
+    int f = f0 - half + r;
+    f = f < 0 ? 0 : f >= N ? N - 1 : f;
+    const size_t off = ((size_t)b * p.pitch + f) * C + g * CG + ch * 8;
+    if (FIRST) {
+      sv[i][0] = *reinterpret_cast<const u32x4*>(p.in_f32 + off);
+      sv[i][FIRST ? 1 : 0] = *reinterpret_cast<const u32x4*>(p.in_f32 + off + 4);
+    } else {
+      sv[i][0] = *reinterpret_cast<const u32x4*>(p.in_bf16 + off);
     }
-    *reinterpret_cast<u32x4*>(sIn + lds_off(r, ch)) = v;
+  }
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int t = tid + 256 * i, r = t >> 3, ch = t & 7;
+    const int f = f0 - half + r;
+    const bool ok = f >= 0 && f < N && r < FB + taps - 1;
+    u32x4 v;
+    if (FIRST) {
+      const float4 a = __builtin_bit_cast(float4, sv[i][0]), c = __builtin_bit_cast(float4, sv[i][FIRST ? 1 : 0]);
+      bf16x8 w;
+      w[0] = (bf16_t)a.x; w[1] = (bf16_t)a.y; w[2] = (bf16_t)a.z; w[3] = (bf16_t)a.w;
+      w[4] = (bf16_t)c.x; w[5] = (bf16_t)c.y; w[6] = (bf16_t)c.z; w[7] = (bf16_t)c.w;
+      v = __builtin_bit_cast(u32x4, w);
+    } else {
+      v = sv[i][0];
+    }
+    v = ok ? v : u32x4{0u, 0u, 0u, 0u};
+    if (t < SLAB_ROWS * 8) *reinterpret_cast<u32x4*>(sIn + lds_off(r, ch)) = v;
   }
 
   const bf16_t* wg = p.w + (size_t)g * taps * CG * CG;
@@ -66,8 +82,9 @@ __global__ __launch_bounds__(256, 2) void convpos_kernel(const ConvPosParams p) 
       const int id = tid + 256 * i;        // 0 .. 2047
       const int tp = id >> 9;              // tap within stage
       const int tap = stage * TPS + tp;
-      rw[i] = tap < taps ? *reinterpret_cast<const u32x4*>(wg + (size_t)tap * CG * CG + (id & 511) * 8)
-                         : u32x4{0u, 0u, 0u, 0u};
+      // (taps past the last one of the final stage re-read it: they are never multiplied -- the tap loop below skips them)
+      const int tc = tap < taps ? tap : taps - 1;
+      rw[i] = *reinterpret_cast<const u32x4*>(wg + (size_t)tc * CG * CG + (id & 511) * 8);
     }
   };
   auto wwrite = [&]() {
