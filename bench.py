@@ -53,6 +53,12 @@ The JSON line also carries
   cpu_baseline -- the fp32 oracle (oracle/lemas_oracle.py, a port of the reference's path) timed on this box's host
                   cores on a bounded sample: the FIRST Euler step (which also builds both branches' text embedding, cached afterwards)
                   and a SECOND, warm one are timed apart; estimate = first + 31 x warm + the full vocoder.
+
+Measurement switches (none changes what the timed region computes): ``--no-phases`` skips the serial hoists / step loop / vocoder / D2H
+timing after the timed region (profiler passes with counters on the batched workloads: DESIGN.md section 8, profiler note),
+``--no-clock-power`` the rocm-smi sampling pass, ``--no-cpu-baseline`` the oracle leg; ``--graph 0`` / ``--vocoder-graph 0`` launch eagerly,
+``--xcd-runs 1`` is round 3's GEMM tile order, ``--attn-variant`` / ``--ln-fused`` / ``--ln-fold`` / ``--dual 0`` select the engine's
+non-default kernels and schedules (the A/Bs of DESIGN.md section 8).
 """
 from __future__ import annotations
 
