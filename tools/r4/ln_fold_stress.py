@@ -2,7 +2,7 @@
 import sys, os
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import torch
-import test_gpu_01_kernels as T
+import test_gpu_13_option_kernels as T
 
 cases = [(17, 4, 18, 2048), (17, 4, 17, 2048), (17, 1, 18, 2048), (17, 5, 18, 1024), (17, 4, 16, 2048), (17, 4, 22, 2048)]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
