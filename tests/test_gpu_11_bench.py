@@ -25,7 +25,7 @@ def test_bench_spawns_its_own_ranks():
     one = _bench(["--steps", "1", "--warmup", "1", "--depth", "2", "--no-cpu-baseline", "--workload", "short"])
     assert one["n_gpus"] == 1 and one["value"] > 0 and "roofline" in one and one["roofline"]["frac"] > 0
     assert one["config"]["workload_key"] == "short" and one["config"]["parallelism"].startswith("dp1")
-    assert one["roofline_vocoder"]["bound"] == "hbm" and 0 < one["roofline_vocoder"]["frac"] < 1 and one["hoist_ms"] > 0
+    assert one["roofline_vocoder"]["bound"] == "mfma_f32" and 0 < one["roofline_vocoder"]["hbm_view"]["frac"] < 1 and 0 < one["roofline_vocoder"]["frac"] < 1 and one["hoist_ms"] > 0
     assert set(one["phase_ms"]) >= {"hoists", "step_loop", "vocoder", "d2h"} and "vocoder" in one["kernel_time_share_utterance"]
     two = _bench(["--gpus", "2", "--steps", "1", "--warmup", "1", "--depth", "2", "--no-cpu-baseline", "--workload", "short"],
                  env={"LEMAS_SHARE_GPU": "1", "LEMAS_DIST_BACKEND": "gloo"})

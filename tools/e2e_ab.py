@@ -79,20 +79,23 @@ def main():
             else:
                 host.copy_(vocoder.decode(out[:, F - 1:, :].permute(0, 2, 1)), non_blocking=True)
         torch.cuda.synchronize()
+        return out
 
     res = {arm: [] for arm in a.arms}
+    sums = {}
     for r in range(a.rounds):
         for arm in a.arms:
             select(arm)
             ov = int(parsed[arm].get("overlap", 1))
-            run(2, ov)                               # capture + warm
+            o = run(2, ov)                           # capture + warm
+            sums[arm] = (float(o.double().sum()), float(o.double().abs().sum()))     # equal sums = the arms computed the same mel
             t0 = time.perf_counter()
             run(a.steps, ov)
             res[arm].append((time.perf_counter() - t0) / a.steps)
     audio = B * Bn.HOP * (N - F) / Bn.SR
     for arm in a.arms:
         best, med = min(res[arm]), sorted(res[arm])[len(res[arm]) // 2]
-        print(f"{a.workload:9s} {arm:28s} median {1e3 * med:8.2f} ms = {audio / med:7.1f} audio-s/s   best {1e3 * best:8.2f} ms = {audio / best:7.1f}")
+        print(f"{a.workload:9s} {arm:28s} median {1e3 * med:8.2f} ms = {audio / med:7.1f} audio-s/s   best {1e3 * best:8.2f} ms = {audio / best:7.1f}   mel sums {sums[arm][0]:.9e} {sums[arm][1]:.9e}")
     m.engine.check_health()
 
 
