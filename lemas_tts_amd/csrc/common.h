@@ -170,6 +170,12 @@ struct GemmParams {
   int gate_off;          // offset of the gate vector inside a step row
   const int* step_idx;   // device scalar: current ODE step
   const int* kv_len;     // [B] valid frames per sample or nullptr
+  // ragged batches: [B] valid frames per sample; a tile whose 128-row blocks all start at or past their sample's length is not computed at
+  // all (row_block_dead below).  nullptr = every tile is computed.  Every kernel of the block chain uses the same 128-row granularity, so a
+  // live block's rows are produced by every kernel exactly as without the switch and a dead block's rows are never read by a live one
+  // (GEMM rows are independent; attention reads keys < kv_len only).  The reference computes those rows and throws them away
+  // (cfm.py:336-339 mask, utils_infer.py:579-585 trims each sample to its duration).
+  const int* live_len;
   int seq_pitch;         // rows per sample in the activation row space (multiple of 128): m -> (m / pitch, m % pitch)
   int seq_valid;         // real frames per sample (rows with m % pitch >= seq_valid are padding)
   int batch;             // B (kv_len index = (m / seq_pitch) % batch)
@@ -251,12 +257,19 @@ hipError_t launch_gemm_qkv_fused(const GemmParams& pq, const GemmParams& pv, hip
 // workgroups share a CU.
 int gemm_bf16_ln_fusable(const GemmParams& p, int* panels, int* per_cu);
 
+// true when the 128-row block starting at row r0 of the [sample][pitch] row space lies entirely in a sample's padding
+__device__ __forceinline__ bool row_block_dead(const int* __restrict__ live_len, int r0, int pitch, int batch) {
+  const int b2 = r0 / pitch;
+  return r0 - b2 * pitch >= live_len[b2 % batch];
+}
+
 struct AttnParams {
   const bf16_t* q;   // [B2, H, pitch, 64]
   const bf16_t* k;   // [B2, H, pitch, 64]
   const bf16_t* vt;  // [B2, H, 64, npad]
   bf16_t* out;       // [B2*pitch, H*64]
   const int* kv_len; // [B] or nullptr
+  int skip_dead;     // != 0 with kv_len: 128-query blocks that start at or past their sample's length are not computed (GemmParams::live_len)
   int b2, batch, heads, n, npad;
   int pitch;         // rows per sample of q / k / out (>= n)
   float scale;
@@ -279,8 +292,10 @@ hipError_t attention_q64_init();
 bool attention_variant_ok(int variant);
 
 // out_bf16[m][c] = LN(x[m][:])[c] * (1 + scale[c]) + shift[c]; scale/shift read from the AdaLN table row of the current step
+// live_len / pitch / batch (optional): rows of 128-row blocks that lie in a sample's padding are skipped (GemmParams::live_len)
 hipError_t launch_ln_mod(const float* x, bf16_t* out, int M, int D, const float* tab, int tab_stride,
-                         int scale_off, int shift_off, const int* step_idx, hipStream_t s);
+                         int scale_off, int shift_off, const int* step_idx, hipStream_t s,
+                         const int* live_len = nullptr, int pitch = 0, int batch = 0);
 
 // ---- ln fold (see GemmParams): chain entry, and the c1 / c2 table rows of a t-grid ------------------------------------------------
 // xs[m][c] = bf16(x[m][c] (1 + scale[c])), part[m][D / 32][2] = (sum, sum of squares) of x over each 32-column slot

@@ -74,6 +74,11 @@ struct lemas_dit {
   bool f8_ln_fed() const { return (fp8_sites() & 0b0101) == 0b0101; }     // QKV and FF1 both on fp8 operands
   // measurement options (per engine; changing one drops the cached graphs): explicit tile ids for the block GEMMs with N == 1024 /
   // N == 2048, for the fused QK+V launch, and the XCD block grid of the tile order; 0 = the production choice
+  // option "skip_dead" (off by default): ragged batches leave the padding blocks of the block chain uncomputed (run_step).  Off, every sample runs
+  // at the batch's pitch as in the reference, whose unmasked position-embedding conv (dit.py:98 -> modules.py:167-190, kernel 31 twice) lets the
+  // last ~30 valid frames of a sample see the padding rows' ODE state: with the switch on those frames differ from the reference's by 5e-6
+  // mel-MSE instead of 2e-6 (tolerance 1e-4; profiles/r04g_skip_dead_ragged_batches.txt) and configs[2] runs 12.6 % faster.
+  bool skip_dead = false;
   int opt_tile_n1024 = 0, opt_tile_n2048 = 0, opt_tile_qkv = 0, opt_xcd_gx = 0, opt_xcd_runs = 0;
   // attention schedule variant (attention.hip VAR).  19 = no running max (P = exp2(S) on q prescaled by the QK epilogue, one range check
   // per workgroup with a classical second pass if it trips) + static priority for the younger half-workgroup: 25.9 -> 22.5 us per lane
@@ -789,6 +794,10 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
   // around every launch of a block: lane 0 records "stage k done", lane 1 waits for it before its own stage k
   auto skew_pre = [&](int ln, hipStream_t q) -> int { if (skew && ln == 1) HIP_TRY(hipStreamWaitEvent(q, ev_skew[skew_k & 7], 0)); return 0; };
   auto skew_post = [&](int ln, hipStream_t q) -> int { if (skew && ln == 0) HIP_TRY(hipEventRecord(ev_skew[skew_k & 7], q)); ++skew_k; return 0; };
+  // Ragged batch: the 128-row blocks that lie wholly in a sample's padding are not computed by the block chain (GemmParams::live_len; the
+  // reference computes them and trims each sample to its duration afterwards, utils_infer.py:579-585).  Their x rows stay what the input
+  // embedding made them, so the head below still emits finite (and unused) rows there.  bf16 chain without the LayerNorm options only.
+  const int* live = (has_len && skip_dead && !fp8 && !fold && !fuse_ln) ? d_len.as<int>() : nullptr;
   auto block = [&](int l, int ln) -> int {   // one DiTBlock (modules.py:627-641) on one lane's rows
     hipStream_t q = st[ln];
     skew_k = 0;
@@ -799,6 +808,7 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     bf16_t* ffb = d_ff.as<bf16_t>() + r0 * ffd;
     GemmParams g{};
     g.M = rows; g.tab = tab; g.tab_stride = tab_stride; g.step_idx = step; g.seq_pitch = pitch; g.seq_valid = N; g.batch = B;
+    g.live_len = live;
     g.heads = cfg.heads; g.npad = npad; g.rope_cos = d_rope_cos.as<float>(); g.rope_sin = d_rope_sin.as<float>();
     // attention variants with bit 16 take q already multiplied by softmax_scale * log2(e): the QK epilogue does it before rounding
     g.q_scale = (attn_variant & 16) ? (1.0f / sqrtf((float)cfg.dim_head)) * 1.4426950408889634f : 0.f;
@@ -806,7 +816,7 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     AttnParams at{};
     at.q = g.q; at.k = g.k; at.vt = g.vt; at.out = abf;
     at.kv_len = has_len ? d_len.as<int>() : nullptr; at.b2 = bh; at.batch = B; at.heads = cfg.heads; at.n = N; at.npad = npad; at.pitch = pitch;
-    at.scale = 1.0f / sqrtf((float)cfg.dim_head); at.variant = attn_variant;
+    at.scale = 1.0f / sqrtf((float)cfg.dim_head); at.variant = attn_variant; at.skip_dead = live != nullptr;
     const BlockW& w = blocks[l];
     const int base = l * 6 * d;  // [shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp] (modules.py:312)
     uint8_t* h8 = fp8 ? d_h8.as<uint8_t>() + r0 * d : nullptr;
@@ -845,7 +855,7 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     } else if (!(fuse_ln && l > 0)) {      // fused: block l's attn_norm rows were written by block l-1's FF2 launch
       RC_TRY(pbegin(PC_LN, q));
       if (f8_qkv) HIP_TRY(launch_ln_mod_f8(xres, h8, hmx, rows, d, tab, tab_stride, base + d, base, step, q));
-      else HIP_TRY(launch_ln_mod(xres, hbf, rows, d, tab, tab_stride, base + d, base, step, q));
+      else HIP_TRY(launch_ln_mod(xres, hbf, rows, d, tab, tab_stride, base + d, base, step, q, live, pitch, B));
       RC_TRY(pend(q));
     }
     // one launch for QK and V only while all of its workgroups fit the chip in one round (128 + 64 at configs[1]); beyond that two
@@ -907,7 +917,7 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     if (!fuse_ln && !fold) {
       RC_TRY(pbegin(PC_LN, q));
       if (f8_ff1) HIP_TRY(launch_ln_mod_f8(xres, h8, hmx, rows, d, tab, tab_stride, base + 4 * d, base + 3 * d, step, q));
-      else HIP_TRY(launch_ln_mod(xres, hbf, rows, d, tab, tab_stride, base + 4 * d, base + 3 * d, step, q));
+      else HIP_TRY(launch_ln_mod(xres, hbf, rows, d, tab, tab_stride, base + 4 * d, base + 3 * d, step, q, live, pitch, B));
       RC_TRY(pend(q));
     }
     RC_TRY(pkernel(PC_GEMM_FF1, &g.ev_start, &g.ev_stop));
@@ -1136,6 +1146,11 @@ int lemas_dit_set_option(lemas_dit* m, const char* key, int64_t value) {
   if (!strcmp(key, "table_cache")) { m->table_cache = value != 0; return 0; }
   if (!strcmp(key, "dual")) {
     m->dual = value != 0;
+    m->drop_graphs();
+    return 0;
+  }
+  if (!strcmp(key, "skip_dead")) {
+    m->skip_dead = value != 0;
     m->drop_graphs();
     return 0;
   }

@@ -70,7 +70,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // where they are first used, i.e. AFTER the tile coordinates are known, and a second scalar-memory round trip sits in front of the first
 // operand request of every workgroup.
 __device__ __forceinline__ void kernargs_early(const GemmParams& p) {
-  asm volatile("" ::"s"(p.A), "s"(p.W), "s"(p.K), "s"(p.M), "s"(p.N));
+  asm volatile("" ::"s"(p.A), "s"(p.W), "s"(p.K), "s"(p.M), "s"(p.N), "s"(p.live_len), "s"(p.seq_pitch), "s"(p.batch));
+  // (live_len / seq_pitch / batch: tile_dead stands before the first operand request; left to the compiler, the load of the pitch was hoisted
+  // above the test of live_len and its wait sat in front of every workgroup's first request, ragged batch or not: -1.3 % on configs[1])
 }
 __device__ __forceinline__ void tile_coords(int seq, int tiles_m, int tiles_n, int gx, int& tm, int& tn);
 __device__ __forceinline__ bool tile_of(int bid, int tiles_m, int tiles_n, int gx, int runs, int& tm, int& tn) {
@@ -81,6 +83,13 @@ __device__ __forceinline__ bool tile_of(int bid, int tiles_m, int tiles_n, int g
     return true;
   }
   return xcd_tile_coords(bid, tiles_m, tiles_n, gx, tm, tn);
+}
+// ragged batches (GemmParams::live_len): a tile is dead when every 128-row block it covers lies in some sample's padding
+__device__ __forceinline__ bool tile_dead(const GemmParams& p, int m0, int tbm) {
+  if (!p.live_len) return false;
+  for (int r = m0 & ~127; r < m0 + tbm && r < p.M; r += 128)
+    if (!row_block_dead(p.live_len, r, p.seq_pitch, p.batch)) return false;
+  return true;
 }
 static inline int grid_of(int tiles_m, int tiles_n, int gx, int runs) { return runs ? tiles_m * tiles_n : xcd_grid(tiles_m, tiles_n, gx); }
 __device__ __forceinline__ void tile_coords(int seq, int tiles_m, int tiles_n, int gx, int& tm, int& tn) {
@@ -161,6 +170,7 @@ __device__ __forceinline__ bf16x4 pack4(float a, float b, float c, float d) {
 struct RowWin {
   int b2, pos0;      // sample (of the doubled batch) and position of the wave tile's first row
   int kvl;           // kv_len of that sample (INT_MAX: none); folded into `rl` by row_window_kv()
+  int lvl;           // live_len of that sample (GemmParams::live_len; large: none); folded into `rl` by row_window_kv()
   int rl, rows_m;    // rows of the wave tile, counted from its first one, that are stored (pos < seq_valid, m < M) / that exist (m < M)
 };
 __device__ __forceinline__ RowWin row_window(const GemmParams& p, int mw_uniform, bool kv) {
@@ -172,13 +182,18 @@ __device__ __forceinline__ RowWin row_window(const GemmParams& p, int mw_uniform
   if (kv && p.kv_len) w.kvl = p.kv_len[w.b2 % p.batch];
   const int left = p.M - mw;
   w.rows_m = left < 0 ? 0 : left > 128 ? 128 : left;
+  // ragged batch with dead blocks skipped: a half-live 256-row tile computes its dead half from stale rows -- never store them.  Like kvl the
+  // value is only REQUESTED here (this runs one K-tile before the loop ends) and folded into rl after the loop (row_window_kv).
+  w.lvl = p.live_len ? p.live_len[w.b2 % p.batch] : 0x7fffff00;
   const int rl = p.seq_valid - w.pos0;
   w.rl = rl < 0 ? 0 : rl > w.rows_m ? w.rows_m : rl;
   return w;
 }
 // (separate from row_window: the kv_len load is requested one K-tile before the loop ends and first looked at after it)
 __device__ __forceinline__ void row_window_kv(RowWin& w) {
-  const int rl = w.kvl - w.pos0;
+  const int lv = ((w.lvl + 127) & ~127) - w.pos0;      // rows of 128-row blocks past the sample's last live block
+  int rl = w.kvl - w.pos0;
+  rl = lv < rl ? lv : rl;
   w.rl = rl < 0 ? 0 : rl < w.rl ? rl : w.rl;
 }
 constexpr int BUF_WORD3 = 0x00020000;      // gfx950 raw buffer descriptor, dword 3: 32-bit data format, no swizzle, no stride
@@ -228,7 +243,8 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, f32x16 (&acc)
   // a 32-column block of one row lives in two lanes (l, l ^ 32) x 16 registers
   using S = SlabF8<WTM, WTN>;
   const int mxld = p.ldc >> 5;
-  const RowWin win = row_window(p, mw, false);
+  RowWin win = row_window(p, mw, false);
+  row_window_kv(win);
   const int mwu = __builtin_amdgcn_readfirstlane(mw);
 #pragma unroll
   for (int i = 0; i < TI; ++i) {
@@ -482,6 +498,7 @@ __device__ __forceinline__ void epilogue_row_blocks(const GemmParams& p, f32x16 
     const int which = nwu / inner, head = (nwu % inner) >> 6, d = (nw + ch * 8) & 63;     // uniform: q or k, the head
     const bf16_t* qk = which == 0 ? p.q : p.k;
     const long long row0 = ((long long)pre.win.b2 * p.heads + head) * p.seq_pitch + pre.win.pos0;    // [b2][head][pos][64]
+    row_window_kv(pre.win);
     const int rl = pre.win.rl, vo = (rr * 64 + d) * 2;
     const float qs = (which == 0 && p.q_scale != 0.f) ? p.q_scale : 1.0f;
     float4 cnext[ITERS], snext[ITERS];
@@ -537,6 +554,7 @@ __device__ __forceinline__ void epilogue_row_blocks(const GemmParams& p, f32x16 
   } else if constexpr (EPI == EPI_BIAS_F32) {
     using S = SlabF32<32, WTN>;
     const int rr = lane / S::CPR, ch = lane % S::CPR;
+    row_window_kv(pre.win);
     int vo = (rr * p.ldc + nw + ch * 4) * 4;
     if (nw + ch * 4 >= p.n_valid) vo = BUF_OOB;
     const int rstep = S::RPI * p.ldc * 4;
@@ -562,6 +580,7 @@ __device__ __forceinline__ void epilogue_row_blocks(const GemmParams& p, f32x16 
   } else {   // bf16 outputs: plain, GELU-tanh
     using S = SlabBf16<32, WTN>;
     const int rr = lane / S::CPR, ch = lane % S::CPR;
+    row_window_kv(pre.win);
     int vo = (rr * p.ldc + nw + ch * 8) * 2;
     if (nw + ch * 8 >= p.n_valid) vo = BUF_OOB;
     const int rstep = S::RPI * p.ldc * 2;
@@ -1391,7 +1410,7 @@ __global__ __launch_bounds__(512) void gemm_pp2_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int tm, tn;
   kernargs_early(p);
-  if (!tile_of(blockIdx.x, (p.M + 255) / 256, p.N / 128, p.xcd_gx, p.xcd_runs, tm, tn)) return;
+  if (!tile_of(blockIdx.x, (p.M + 255) / 256, p.N / 128, p.xcd_gx, p.xcd_runs, tm, tn) || tile_dead(p, tm * 256, 256)) return;
   gemm_body_pp2<EPI, EPI != EPI_V_T>(p, smem, tm * 256, tn * 128, reinterpret_cast<float*>(smem + 3 * (256 + 128) * 128));
 }
 
@@ -1417,7 +1436,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int tm, tn;
   kernargs_early(p);
-  if (!tile_of(blockIdx.x, (p.M + 255) / 256, p.N / 256, p.xcd_gx, p.xcd_runs, tm, tn)) return;
+  if (!tile_of(blockIdx.x, (p.M + 255) / 256, p.N / 256, p.xcd_gx, p.xcd_runs, tm, tn) || tile_dead(p, tm * 256, 256)) return;
   gemm_body_pp<EPI, EPI != EPI_V_T>(p, smem, tm * 256, tn * 256, reinterpret_cast<float*>(smem + 8 * 16384));
 }
 
@@ -1451,7 +1470,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_bf16_kernel(const GemmPar
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int tm, tn;
   kernargs_early(p);
-  if (!tile_of(blockIdx.x, (p.M + TBM - 1) / TBM, p.N / TBN, p.xcd_gx, p.xcd_runs, tm, tn)) return;
+  if (!tile_of(blockIdx.x, (p.M + TBM - 1) / TBM, p.N / TBN, p.xcd_gx, p.xcd_runs, tm, tn) || tile_dead(p, tm * TBM, TBM)) return;
   gemm_body<EPI, TBM, TBN, NSTAGE, NWM, NWN, EPI != EPI_V_T, F8>(p, smem, tm * TBM, tn * TBN,
       reinterpret_cast<float*>(smem + body_lds_base<EPI, TBM, TBN, NSTAGE, NWM, NWN, F8>()));
 }
@@ -1598,12 +1617,12 @@ __global__ __launch_bounds__(64 * TileCfg<TILE>::WM * TileCfg<TILE>::WN) void ge
   int tm, tn;
   if (bid < tiles_q) {       // tiles_q / tiles_v: the PADDED workgroup counts of the two parts (multiples of 8: both parts keep the XCD phase)
     kernargs_early(pq);
-    if (!tile_of(bid, (pq.M + C::BM - 1) / C::BM, pq.N / C::BN, pq.xcd_gx, pq.xcd_runs, tm, tn)) return;
+    if (!tile_of(bid, (pq.M + C::BM - 1) / C::BM, pq.N / C::BN, pq.xcd_gx, pq.xcd_runs, tm, tn) || tile_dead(pq, tm * C::BM, C::BM)) return;
     if constexpr (!F8 && TILE == T256x128) gemm_body_pp2<EPI_QK_ROPE, true>(pq, smem, tm * 256, tn * 128, rs);
     else gemm_body<EPI_QK_ROPE, C::BM, C::BN, C::ST, C::WM, C::WN, true, F8>(pq, smem, tm * C::BM, tn * C::BN, rs);
   } else {
     kernargs_early(pv);
-    if (!tile_of(bid - tiles_q, (pv.M + C::BM - 1) / C::BM, pv.N / C::BN, pv.xcd_gx, pv.xcd_runs, tm, tn)) return;
+    if (!tile_of(bid - tiles_q, (pv.M + C::BM - 1) / C::BM, pv.N / C::BN, pv.xcd_gx, pv.xcd_runs, tm, tn) || tile_dead(pv, tm * C::BM, C::BM)) return;
     if constexpr (!F8 && TILE == T256x128) gemm_body_pp2<EPI_V_T, false>(pv, smem, tm * 256, tn * 128, rs);
     else gemm_body<EPI_V_T, C::BM, C::BN, C::ST, C::WM, C::WN, false, F8>(pv, smem, tm * C::BM, tn * C::BN, rs);
   }

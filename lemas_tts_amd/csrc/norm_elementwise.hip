@@ -15,11 +15,14 @@ namespace {
 template <int D, int ROWS>
 __global__ __launch_bounds__(256) void ln_mod_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, int M,
                                                      const float* __restrict__ tab, int tab_stride, int scale_off,
-                                                     int shift_off, const int* __restrict__ step_idx) {
+                                                     int shift_off, const int* __restrict__ step_idx,
+                                                     const int* __restrict__ live_len, int pitch, int batch) {
   static_assert(D == LN_D, "row width");
+  static_assert(128 % ROWS == 0, "a wave's rows share one 128-row block");
   constexpr int PER = LN_PER;
   const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS;
   if (row0 >= M) return;
+  if (live_len && row_block_dead(live_len, row0 & ~127, pitch, batch)) return;     // ragged batch: the block lies in a sample's padding
   const int lane = threadIdx.x & 63;
   const float* base = tab + (step_idx ? (size_t)step_idx[0] * tab_stride : 0);
   // ROWS rows per wave: all their loads are issued before the first reduction (a wave with one row has 64 B per lane in flight
@@ -304,10 +307,12 @@ inline int grid_for(size_t n, int block = 256) {
 }  // namespace
 
 hipError_t launch_ln_mod(const float* x, bf16_t* out, int M, int D, const float* tab, int tab_stride, int scale_off,
-                         int shift_off, const int* step_idx, hipStream_t s) {
+                         int shift_off, const int* step_idx, hipStream_t s, const int* live_len, int pitch, int batch) {
   if (D != 1024) return hipErrorInvalidValue;
+  if (live_len && (pitch <= 0 || pitch % 128 != 0 || batch <= 0)) return hipErrorInvalidValue;
   // two rows per wave: +0.4 ... 1.3 % end to end over one (tools/e2e_ab.py, all three workloads)
-  hipLaunchKernelGGL((ln_mod_kernel<1024, 2>), dim3((M + 7) / 8), dim3(256), 0, s, x, out, M, tab, tab_stride, scale_off, shift_off, step_idx);
+  hipLaunchKernelGGL((ln_mod_kernel<1024, 2>), dim3((M + 7) / 8), dim3(256), 0, s, x, out, M, tab, tab_stride, scale_off, shift_off, step_idx,
+                     live_len, pitch, batch);
   return hipGetLastError();
 }
 

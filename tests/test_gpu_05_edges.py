@@ -102,6 +102,51 @@ def test_ragged_batch_with_one_frame_generation_and_full_mask_rows():
     assert _mse(out.cpu(), ref, Fs, Ns) <= 1e-4
 
 
+@pytest.mark.parametrize("dual,big", [(1, False), (0, False), (1, True)])
+def test_ragged_batch_with_padding_blocks_left_uncomputed(dual, big):
+    """Option skip_dead (off by default): the 128-row blocks that lie wholly in a sample's padding are skipped by every kernel of the block
+    chain.  Lengths straddle the 128-row blocks in every way (1, 2, 3 live blocks of 4; one sample fills the batch; one ends exactly on a
+    block edge).  Against the fp32 oracle the generated frames stay inside 1e-4; against the default path every valid frame more than 30
+    before its sample's end (the reach of the reference's unmasked position-embedding conv into the padding, modules.py:167-190) agrees to
+    bf16 noise, and nothing in the output -- padding rows included -- is non-finite."""
+    m, o = _pair()
+    # pitch 640 = five 128-row blocks: the 256-row tiles straddle samples and live / dead blocks
+    Fs, Ns = [10, 40, 64, 5, 90, 100], [11, 200, 256, 131, 600, 385]
+    nts = [4, 60, 10, 40, 33, 120]
+    if big:        # 12 x 640 rows per lane: the 256 x 256 tile for the N = 2048 GEMMs (gemm_bf16.hip pick_tile)
+        Fs, Ns, nts = Fs * 2, Ns + [129, 513, 70, 640, 300, 257], nts * 2
+    B = len(Fs)
+    cond = torch.zeros(B, max(Fs), 100); text = torch.full((B, max(nts)), -1, dtype=torch.long); y0 = torch.zeros(B, max(Ns), 100)
+    for b in range(B):
+        cond[b, :Fs[b]] = torch.from_numpy(synth.synth_cond_mel(300 + b, Fs[b]))
+        text[b, :nts[b]] = torch.from_numpy(synth.synth_tokens(310 + b, nts[b], VOCAB))
+        y0[b, :Ns[b]] = torch.from_numpy(synth.synth_noise(320 + b, Ns[b]))
+    lens, dur = torch.tensor(Fs), torch.tensor(Ns)
+    kw = dict(steps=4, cfg_strength=2.0, sway_sampling_coef=5)
+    ref, _ = o.sample(cond, text, dur, y0=y0, lens=lens, **kw)
+    outs = {}
+    try:
+        m.engine.set_option("dual", dual)
+        for skip in (0, 1):
+            m.engine.set_option("skip_dead", skip)
+            for graph in (0, 1):
+                m.engine.set_option("graph", graph)
+                outs[(skip, graph)] = m.sample(cond, text, dur, lens=lens, y0=y0, use_acc_grl=False, **kw)[0].cpu()
+    finally:
+        m.engine.set_option("skip_dead", 0); m.engine.set_option("graph", 1); m.engine.set_option("dual", 1)
+    m.engine.check_health()
+    for skip in (0, 1):
+        assert torch.equal(outs[(skip, 0)], outs[(skip, 1)])                # eager == replayed graph, with and without the switch
+        assert torch.isfinite(outs[(skip, 0)]).all()
+        assert _mse(outs[(skip, 0)], ref, Fs, Ns) <= 1e-4
+    for b in range(B):
+        far = max(Fs[b], Ns[b] - 30)
+        if far > Fs[b]:
+            d = (outs[(1, 0)][b, Fs[b]:far] - outs[(0, 0)][b, Fs[b]:far]).abs().max().item()
+            assert d < 5e-2, (b, d)
+        assert torch.equal(outs[(1, 0)][b, :Fs[b]], outs[(0, 0)][b, :Fs[b]])     # the prompt frames are the prompt, either way
+
+
 def test_no_cfg_and_no_sway_paths():
     """cfg_strength < 1e-5 skips the unconditional branch (cfm.py:404-405); sway None uses the plain power warp (:452-453)"""
     m, o = _pair()
