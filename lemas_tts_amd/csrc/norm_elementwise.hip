@@ -20,11 +20,18 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const float* __restrict__ x
   static_assert(D == LN_D, "row width");
   static_assert(128 % ROWS == 0, "a wave's rows share one 128-row block");
   constexpr int PER = LN_PER;
+  // every kernel argument in ONE scalar request: left alone the compiler fetched them where they are first used -- M, then live_len, then the
+  // pointers, then step_idx[0], four dependent scalar-memory round trips (~0.2 us each) in front of the first row load of a ~5 us kernel
+  // (not step_idx, which is read with a scalar load: handing a pointer to an asm statement makes it "captured" and its loads vector loads)
+  asm volatile("" ::"s"(x), "s"(out), "s"(M), "s"(tab), "s"(tab_stride), "s"(scale_off), "s"(shift_off), "s"(live_len), "s"(pitch), "s"(batch));
+  // the step index: REQUESTED here, in the entry block (a scalar load there; behind the row tests the compiler made it a vector load with a
+  // vmcnt(0) of its own), and looked at only after the row loads below are out
+  int st = 0;
+  if (step_idx) st = step_idx[0];
   const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS;
   if (row0 >= M) return;
   if (live_len && row_block_dead(live_len, row0 & ~127, pitch, batch)) return;     // ragged batch: the block lies in a sample's padding
   const int lane = threadIdx.x & 63;
-  const float* base = tab + (step_idx ? (size_t)step_idx[0] * tab_stride : 0);
   // ROWS rows per wave: all their loads are issued before the first reduction (a wave with one row has 64 B per lane in flight
   // and then sits through two dependent shuffle reductions; the kernel is latency-, not bandwidth-bound at batch 1)
   float4 v[ROWS][PER][2];
@@ -37,9 +44,25 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const float* __restrict__ x
 #pragma unroll
       for (int h = 0; h < 2; ++h) v[r][i][h] = xr[(lane + 64 * i) * 2 + h];
   }
+  // the row loads are on their way BEFORE the step index is looked at (the modulation vectors' addresses need it)
+  __builtin_amdgcn_sched_barrier(0);
+  const float* base = tab + (size_t)st * tab_stride;
   float4 a[PER][2], b[PER][2];
   ln_load_vec(base + scale_off, lane, a);
   ln_load_vec(base + shift_off, lane, b);
+  // ... and the modulation vectors are requested HERE, behind the rows and ahead of any arithmetic: left alone the compiler sinks each of
+  // these (L2-resident) loads to its first use, and the row's store waits through three more memory round trips one after the other
+#pragma unroll
+  for (int i = 0; i < PER; ++i)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) { asm volatile("" : "+v"(a[i][h].x)); asm volatile("" : "+v"(b[i][h].x)); }
+  // (the rows pass through the same gate: without it the first partial sums are scheduled ahead of the vector requests)
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+    for (int i = 0; i < PER; ++i)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) asm volatile("" : "+v"(v[r][i][h].x), "+v"(v[r][i][h].y), "+v"(v[r][i][h].z), "+v"(v[r][i][h].w));
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) ln_row_store(v[r], a, b, out + (size_t)(row0 + r) * D, lane, row0 + r < M);
 }
