@@ -1150,8 +1150,10 @@ int lemas_dit_set_option(lemas_dit* m, const char* key, int64_t value) {
     return 0;
   }
   if (!strcmp(key, "skip_dead")) {
-    m->skip_dead = value != 0;
-    m->drop_graphs();
+    if (m->skip_dead != (value != 0)) {       // (a caller may set it before every batch: only a CHANGE invalidates the captured graphs)
+      m->skip_dead = value != 0;
+      m->drop_graphs();
+    }
     return 0;
   }
   if (!strcmp(key, "qkv_fused")) {

@@ -204,13 +204,16 @@ def infer_batch_process(ref_audio, ref_text, gen_text_batches, model_obj, vocode
                         target_rms=0.1, cross_fade_duration=0.15, nfe_step=32, cfg_strength=2.0, sway_sampling_coef=-1,
                         use_acc_grl=True, use_prosody_encoder=True, ref_ratio=None, no_ref_audio=False, speed=1,
                         fix_duration=None, device=None, streaming=False, chunk_size=2048, seed=None,
-                        prosody_embeds=None, noise=None, batch_lines=1):
+                        prosody_embeds=None, noise=None, batch_lines=1, skip_padding_blocks=False):
     """:464-625 generator.  Yields ``(final_wave, 24000, combined_mel)`` (or chunks when ``streaming``).
     ``noise`` (list of y0 tensors, one per line) and ``prosody_embeds`` are explicit inputs the reference draws /
     computes on its own device.  ``batch_lines`` > 1 runs up to that many lines of ``gen_text`` as ONE
     ``CFM.sample`` batch (one captured graph per step for all of them) instead of the reference's serial loop
     (:572-579); lines of unequal length then follow the reference's own B > 1 semantics (``lens`` / duration masks,
-    cfm.py:336-339)."""
+    cfm.py:336-339).  ``skip_padding_blocks`` (with ``batch_lines`` > 1; engine option ``skip_dead``): the
+    128-row blocks that lie wholly in a shorter line's padding are not computed -- ~10 % faster on a ragged batch of 8; a line's
+    last ~30 frames then differ from the B > 1 reference's by 1e-5 instead of 2e-6 mel-MSE (the reference's position-embedding
+    conv reads the padding rows behind a line; a line sampled alone has none)."""
     rms = None
     if isinstance(ref_audio, tuple):
         audio, sr = ref_audio
@@ -245,6 +248,8 @@ def infer_batch_process(ref_audio, ref_text, gen_text_batches, model_obj, vocode
 
     lines = list(gen_text_batches)
     group = max(1, int(batch_lines)) if not streaming else 1
+    if group > 1 and hasattr(model_obj, "engine"):
+        model_obj.engine.set_option("skip_dead", 1 if skip_padding_blocks else 0)
     for g0 in range(0, len(lines), group):
         chunk = lines[g0: g0 + group]
         if len(chunk) == 1:                                                      # the reference's path: one line, B = 1

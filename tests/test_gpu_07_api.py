@@ -140,6 +140,23 @@ def test_infer_batch_process_batched_lines_vs_oracle_batch():
     print(f"\n[batch_lines=3 vs oracle batch] mel-MSE {mse:.3e}  waveform relative rms error {rel:.3e}")
     assert mse <= 1e-4 and rel < 5e-2
 
+    # lines of very unequal length (durations 129 / 400 / 259 frames: 2, 4 and 3 live 128-row blocks of a 512-row pitch) with the padding
+    # blocks left uncomputed (skip_padding_blocks -> engine option skip_dead): still inside the tolerance against the oracle's batch
+    lines2 = [[f"p{i}" for i in synth.synth_tokens(185 + k, n, 898)] for k, n in enumerate((9, 57, 32))]
+    durs2 = [ref_len + int(ref_len / len(ref_text) * len(g)) for g in lines2]
+    noise2 = [torch.from_numpy(synth.synth_noise(190 + k, d))[None] for k, d in enumerate(durs2)]
+    _, _, spec2 = next(infer_batch_process(ref_mel, ref_text, lines2, model, _V, noise=noise2, batch_lines=3, skip_padding_blocks=True, **kw))
+    text2 = O.tokens_to_idx([ref_text + g for g in lines2], vocab)
+    y02 = torch.nn.utils.rnn.pad_sequence([n[0] for n in noise2], batch_first=True)
+    out2, _ = O.OracleCFM(sd, arch).sample(ref_mel[None].expand(3, -1, -1), text2, torch.tensor(durs2), y0=y02, steps=3, cfg_strength=2.0,
+                                           sway_sampling_coef=5)
+    ref_spec2 = np.concatenate([out2[j, ref_len: durs2[j], :].T.numpy() for j in range(3)], axis=1)
+    assert spec2.shape == ref_spec2.shape
+    mse2 = float(((spec2 - ref_spec2) ** 2).mean())
+    print(f"[batch_lines=3, padding blocks skipped, durations {durs2}] mel-MSE {mse2:.3e}")
+    assert mse2 <= 1e-4
+    model.engine.set_option("skip_dead", 0)
+
     # equal lengths: batched == serial, bit for bit
     same = [lines[1], [f"p{i}" for i in synth.synth_tokens(99, len(lines[1]), 898)]]
     nz = [noise[1], torch.from_numpy(synth.synth_noise(98, durs[1]))[None]]
