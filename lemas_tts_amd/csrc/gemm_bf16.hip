@@ -974,6 +974,13 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, int m
         return __builtin_bit_cast(bf16x8, f[0]);
       }
     };
+    // measurement builds only (-DLEMAS_ABLATE=bits; compile-time so that the loop keeps its shape): 1 = no MFMAs, 2 = no refill LDS-DMA after
+    // the prologue's stages, 4 = no fragment reads from LDS (wrong results; what each removes is that pipe's share of the loop)
+#ifdef LEMAS_ABLATE
+    constexpr int abl = LEMAS_ABLATE;
+#else
+    constexpr int abl = 0;
+#endif
     int stage = 0;
     for (int kt = 0; kt < nk; ++kt) {
       if (kt + NSTAGE - 2 < nk) wait_vmcnt<PW * (NSTAGE - 2)>();
@@ -984,14 +991,16 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, int m
       const int nt = kt + NSTAGE - 1;
       int ns = stage + NSTAGE - 1;
       ns = ns >= NSTAGE ? ns - NSTAGE : ns;
-      const bool refill = nt < nk;
+      const bool refill = nt < nk && !(abl & 2);
       const unsigned sb = lds_base + stage * STAGE;
       if constexpr (F8) ReadScales<0, TI>::run(asc, sb + aS);
-      ReadFrags<0, TI, RPF>::run(fa[0], aA[0], sb);
-      ReadFrags<0, TJ, RPF>::run(fb[0], aB[0], sb);
+      if (!(abl & 4)) {
+        ReadFrags<0, TI, RPF>::run(fa[0], aA[0], sb);
+        ReadFrags<0, TJ, RPF>::run(fb[0], aB[0], sb);
+      }
 #pragma unroll
       for (int kk = 0; kk < KS; ++kk) {
-        if (kk < KS - 1) {
+        if (kk < KS - 1 && !(abl & 4)) {
           ReadFrags<0, TI, RPF>::run(fa[(kk + 1) & 1], aA[kk + 1], sb);
           ReadFrags<0, TJ, RPF>::run(fb[(kk + 1) & 1], aB[kk + 1], sb);
         }
@@ -1000,17 +1009,20 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, int m
           for (int x = (PW * kk) / KS; x < (PW * (kk + 1)) / KS; ++x) issue_piece(ns, nt, x);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (kk < KS - 1) wait_lgkmcnt<NR>();
+        if (abl & 4) wait_lgkmcnt<0>();
+        else if (kk < KS - 1) wait_lgkmcnt<NR>();
         else wait_lgkmcnt<0>();
         if (F8 && kk == 0) {
 #pragma unroll
           for (int t = 0; t < TI; ++t) asc[t] >>= (8 * hi);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (!(abl & 1)) {
 #pragma unroll
-        for (int i = 0; i < TI; ++i)
+          for (int i = 0; i < TI; ++i)
 #pragma unroll
-          for (int j = 0; j < TJ; ++j) mfma1(as_frag(fa[kk & 1][i]), as_frag(fb[kk & 1][j]), acc[i][j], kk, F8 ? asc[i] : 0);
+            for (int j = 0; j < TJ; ++j) mfma1(as_frag(fa[kk & 1][i]), as_frag(fb[kk & 1][j]), acc[i][j], kk, F8 ? asc[i] : 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
       stage = stage + 1 == NSTAGE ? 0 : stage + 1;
