@@ -704,6 +704,15 @@ def main():
                               # the MFMA peak is the roof the figure of merit is priced against (arithmetic intensity ~2 700
                               # flop/B); what the kernel is held up BY, from the counters, is `limited_by`
                               "limited_by": dom_bound, "limited_by_source": bounds_src}
+        if dom == "gemm_bf16_kernel<EPI_GATE_RES>" and not a.fp8 and a.workload in ("configs1", "short"):
+            # the 128 x 128 tile's K loop taken apart with compile-time ablation builds (measurement only): three pipes that each need about
+            # the same time per K-tile, and a loop that overlaps them to 56 %
+            result["roofline"]["k_loop_pipes"] = {
+                "tile": "128 x 128 x 64, 8 waves, one workgroup per CU", "us_per_k_tile": {
+                    "mfma_alone_ideal": 0.24, "lds_fragment_reads_alone": 0.24, "l2_to_lds_64B_per_clk_ideal": 0.24, "barrier_and_waits_alone": 0.05,
+                    "mfma_plus_fragment_reads": 0.34, "mfma_plus_lds_dma": 0.41, "full_loop": 0.425},
+                "outside_the_loop_us": {"prologue": 1.6, "epilogue": 1.8, "launch_ramp_and_drain": 2.3},
+                "source": "profiles/r04g_kloop_ablations_128x128.txt (-DLEMAS_ABLATE builds, tools/r4/probe44.sh)"}
         if bounds_all:
             result["roofline_kernels"] = {k: v for k, v in bounds_all.items() if not k.startswith("_")}
         g_ms = sum(v["ms"] for s, v in by_sym.items() if s != "attn_fwd_splitkv_kernel")
