@@ -34,6 +34,28 @@ def test_bench_spawns_its_own_ranks():
 
 
 @pytest.mark.timeout(900)
+def test_bench_under_the_drivers_own_launcher():
+    """N > 1 the way the driver starts it: ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...`` (two ranks sharing the box's one GPU, gloo for the collectives): exactly ONE JSON line on
+    the launcher's stdout, from rank 0, whole-job value."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--depth", "2",
+           "--no-cpu-baseline", "--workload", "short"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT,
+                       env=dict(os.environ, LEMAS_SHARE_GPU="1", LEMAS_DIST_BACKEND="gloo"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    two = json.loads(lines[0])
+    assert two["n_gpus"] == 2 and two["steps"] == 1 and two["warmup"] == 1 and two["scaling"] == "weak" and two["value"] > 0
+    assert len(two["per_rank_ms"]["all"]) == 2 and two["config"]["utterances_total"] == 2
+
+
+@pytest.mark.timeout(900)
 def test_bench_runs_every_rccl_call_of_the_multi_gpu_path_in_a_world_of_one():
     """LEMAS_FORCE_DIST=1 sends ``--gpus 1`` through the N > 1 code: RCCL process group bound to the device, the flat weight
     broadcast INTO DEVICE MEMORY, device-to-device engine loads from views of that buffer, the barriers / all_gather / all_reduce
