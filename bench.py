@@ -427,6 +427,8 @@ def main():
     ap.add_argument("--skip-dead", type=int, default=-1, help="engine option skip_dead (-1 = engine default 0: every sample of a ragged batch runs at "
                     "the batch's pitch, as in the reference; 1 = the 128-row blocks that lie wholly in a sample's padding are left uncomputed: "
                     "+12.6 %% on configs2, the last ~30 frames of a sample then differ from the reference's by 5e-6 instead of 2e-6 mel-MSE)")
+    ap.add_argument("--skip-masked", type=int, default=-1, help="engine option skip_masked (-1 = engine default 1: the attention half of every block "
+                    "skips a ragged batch's padding blocks -- exact, the reference zeroes that half's output there; 0 = compute them, for A/B runs)")
     ap.add_argument("--no-clock-power", action="store_true", help="skip the rocm-smi clock / power sampling pass (profiler runs)")
     a = ap.parse_args()
 
@@ -512,6 +514,8 @@ def main():
         model.engine.set_option("ln_fold", a.ln_fold)
     if a.skip_dead >= 0:
         model.engine.set_option("skip_dead", a.skip_dead)
+    if a.skip_masked >= 0:
+        model.engine.set_option("skip_masked", a.skip_masked)
     model.engine.set_option("table_cache", 0)      # hoists are redone for every utterance: nothing cached across steps
     vocoder = VocosEngine(vsd, device=device)
     if a.vocoder_graph >= 0:
@@ -610,8 +614,12 @@ def main():
         real_rows, rows_pitch = sum(case["dur_list"]), B * ((N_TOT + 127) // 128 * 128)
         # ragged batches: with --skip-dead 1 the block chain leaves the 128-row blocks that lie wholly in a sample's padding uncomputed (bf16
         # path); the reference -- and the default -- run every sample at the batch's pitch
-        skipping = case["lens"] is not None and a.skip_dead == 1 and not a.fp8
-        rows_computed = sum((n + 127) // 128 * 128 for n in case["dur_list"]) if skipping else rows_pitch
+        ragged = case["lens"] is not None and not a.fp8
+        live128 = [(n + 127) // 128 * 128 for n in case["dur_list"]]
+        live_ff = [min(v + 128, rows_pitch // B) for v in live128] if a.skip_dead == 2 else live128
+        rows_ff = sum(live_ff) if (ragged and a.skip_dead >= 1) else rows_pitch              # rows the FF half of a block computes
+        rows_attn = sum(live128) if (ragged and a.skip_masked != 0) else rows_pitch         # rows its attention half computes (exact skipping)
+        rows_computed = rows_ff
         flops_step = 2 * nfe * sum(fwd_flops(1, n) for n in case["dur_list"]) * (a.depth / 22.0)
         path_tflops = flops_step / (elapsed / a.steps) / 1e12
         result = {
@@ -635,6 +643,7 @@ def main():
                        "depth": a.depth, "weights": f"synthetic N(0,0.02^2), seed {w['wseed']}",
                        "real_frames_per_step": real_rows, "rows_computed_per_step": rows_computed,
                        "padded_row_waste": 1.0 - real_rows / rows_computed,       # rows the block chain computes beyond the real frames
+                       "rows_computed_attention_half": rows_attn,     # attn_norm, QK / V, attention, out-projection: padding blocks always skipped (exact)
                        "rows_at_batch_pitch": rows_pitch, "padded_row_waste_at_batch_pitch": 1.0 - real_rows / rows_pitch,   # what the reference computes
                        "waveforms_per_step": len(segs), "vocode": w["vocode"],
                        "parity_fixture": w["golden"] if mse is not None else None},

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int N = p.n;
   const int kvlen = p.kv_len ? p.kv_len[b2 % p.batch] : N;
   static_assert(QB == 128, "dead query blocks are the 128-row blocks of GemmParams::live_len");
-  if (p.skip_dead && qblk * QB >= kvlen) return;      // ragged batch: this block's queries are all padding (nothing live reads its rows)
+  if (p.live_len && qblk * QB >= p.live_len[b2 % p.batch]) return;      // ragged batch: this block's queries are all padding nobody reads
   const int ntiles = (kvlen + KB - 1) / KB, nsup = (ntiles + 1) >> 1;
   const float c = (VAR & 16) != 0 ? 1.0f : p.scale * 1.4426950408889634f;    // VAR & 16: q arrives prescaled
   const char* kg = reinterpret_cast<const char*>(p.k + (size_t)bh * p.pitch * 64);

@@ -269,7 +269,7 @@ struct AttnParams {
   const bf16_t* vt;  // [B2, H, 64, npad]
   bf16_t* out;       // [B2*pitch, H*64]
   const int* kv_len; // [B] or nullptr
-  int skip_dead;     // != 0 with kv_len: 128-query blocks that start at or past their sample's length are not computed (GemmParams::live_len)
+  const int* live_len;  // [B] or nullptr: 128-query blocks that start at or past live_len of their sample are not computed (GemmParams::live_len)
   int b2, batch, heads, n, npad;
   int pitch;         // rows per sample of q / k / out (>= n)
   float scale;

@@ -74,11 +74,14 @@ struct lemas_dit {
   bool f8_ln_fed() const { return (fp8_sites() & 0b0101) == 0b0101; }     // QKV and FF1 both on fp8 operands
   // measurement options (per engine; changing one drops the cached graphs): explicit tile ids for the block GEMMs with N == 1024 /
   // N == 2048, for the fused QK+V launch, and the XCD block grid of the tile order; 0 = the production choice
-  // option "skip_dead" (off by default): ragged batches leave the padding blocks of the block chain uncomputed (run_step).  Off, every sample runs
-  // at the batch's pitch as in the reference, whose unmasked position-embedding conv (dit.py:98 -> modules.py:167-190, kernel 31 twice) lets the
-  // last ~30 valid frames of a sample see the padding rows' ODE state: with the switch on those frames differ from the reference's by 5e-6
-  // mel-MSE instead of 2e-6 (tolerance 1e-4; profiles/r04g_skip_dead_ragged_batches.txt) and configs[2] runs 12.6 % faster.
-  bool skip_dead = false;
+  // option "skip_dead" (0 by default): what the FF HALF of a block does with a ragged batch's padding blocks (the attention half skips them
+  // always and exactly: skip_masked below).  0 = computes them, as the reference does -- its unmasked position-embedding conv (dit.py:98 ->
+  // modules.py:167-190, kernel 31 twice) lets the last ~30 valid frames of a sample see the padding rows' ODE state.  1 = skips them all: those
+  // frames differ from the reference's by 1e-5 mel-MSE instead of 2e-6 (tolerance 1e-4; profiles/r04g_skip_dead_ragged_batches.txt).
+  // 2 = skips all but ONE block behind every sample's last live block (d_live = min(len + 128, N)): the padding rows the position conv
+  // reaches into are then evolved by the chain as the reference evolves them -- the reference's own error level -- at most of the saving
+  int skip_dead = 0;
+  bool skip_masked = true;    // option "skip_masked": the attention half of every block skips padding blocks (exact; see run_step); 0 for A/B runs
   int opt_tile_n1024 = 0, opt_tile_n2048 = 0, opt_tile_qkv = 0, opt_xcd_gx = 0, opt_xcd_runs = 0;
   // attention schedule variant (attention.hip VAR).  19 = no running max (P = exp2(S) on q prescaled by the QK epilogue, one range check
   // per workgroup with a classical second pass if it trips) + static priority for the younger half-workgroup: 25.9 -> 22.5 us per lane
@@ -120,7 +123,7 @@ struct lemas_dit {
   int rope_n = 0;
   std::vector<float> h_dt, h_cfg, h_t;
 
-  DevBuf d_step, d_dt, d_cfg, d_t, d_tab, d_rope_cos, d_rope_sin, d_len;
+  DevBuf d_step, d_dt, d_cfg, d_t, d_tab, d_rope_cos, d_rope_sin, d_len, d_live;
   DevBuf d_sin, d_h1, d_temb, d_st;                       // time path scratch
   DevBuf d_cond_eff, d_step_cond, d_pm, d_pt;             // conditioning
   DevBuf d_te, d_rowmask, d_t1, d_t2, d_t3, d_gx, d_ct;   // text embedding scratch
@@ -155,7 +158,7 @@ struct lemas_dit {
 
   std::vector<DevBuf*> own_bufs() {
     return {&wproj_out, &bproj_out, &d_tabW, &d_tabB, &wconv[0], &wconv[1], &d_step, &d_dt, &d_cfg, &d_t, &d_tab, &d_rope_cos,
-            &d_rope_sin, &d_len, &d_sin, &d_h1, &d_temb, &d_st, &d_cond_eff, &d_step_cond, &d_pm, &d_pt, &d_te,
+            &d_rope_sin, &d_len, &d_live, &d_sin, &d_h1, &d_temb, &d_st, &d_cond_eff, &d_step_cond, &d_pm, &d_pt, &d_te,
             &d_rowmask, &d_t1, &d_t2, &d_t3, &d_gx, &d_ct, &d_pconst, &d_y, &d_xres, &d_hbf, &d_q, &d_k, &d_vt,
             &d_abf, &d_ff, &d_cmid, &d_pred, &d_h8, &d_hmx, &d_a8, &d_amx, &d_ff8, &d_ffmx, &d_lncnt, &d_lnpart,
             &d_foldA, &d_foldtmp, &d_foldsites, &d_foldparams, &d_zero};
@@ -643,6 +646,7 @@ int lemas_dit::prepare(const lemas_sample_args* a, hipStream_t s) {
   RC_TRY(build_tables(a, s));
   if (has_len) {
     RC_TRY(d_len.ensure((size_t)B * 4));
+    RC_TRY(d_live.ensure((size_t)B * 4));
     HIP_TRY(hipMemcpyAsync(d_len.p, a->seq_len, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
   }
   // conditioning
@@ -797,7 +801,14 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
   // Ragged batch: the 128-row blocks that lie wholly in a sample's padding are not computed by the block chain (GemmParams::live_len; the
   // reference computes them and trims each sample to its duration afterwards, utils_infer.py:579-585).  Their x rows stay what the input
   // embedding made them, so the head below still emits finite (and unused) rows there.  bf16 chain without the LayerNorm options only.
-  const int* live = (has_len && skip_dead && !fp8 && !fold && !fuse_ln) ? d_len.as<int>() : nullptr;
+  const bool can_skip = has_len && !fp8 && !fold && !fuse_ln;
+  const int* live = (can_skip && skip_dead) ? (skip_dead == 2 ? d_live.as<int>() : d_len.as<int>()) : nullptr;
+  // The ATTENTION HALF of a block contributes exactly nothing to rows past a sample's length -- the reference zeroes the out-projection's
+  // output there (modules.py AttnProcessor: x.masked_fill(~mask, 0) behind to_out; EPI_GATE_RES "rows past kv_len contribute 0") -- and nothing
+  // else reads what it computes for them (keys are masked, q rows are only their own).  So attn_norm, the QK / V projections, attention and
+  // the out-projection skip the padding blocks ALWAYS (option skip_masked, default 1): bit-identical results, padding rows included.  The
+  // FF half does update padding rows in the reference; it skips them only under skip_dead.
+  const int* live_a = (can_skip && skip_masked) ? d_len.as<int>() : nullptr;
   auto block = [&](int l, int ln) -> int {   // one DiTBlock (modules.py:627-641) on one lane's rows
     hipStream_t q = st[ln];
     skew_k = 0;
@@ -808,7 +819,7 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     bf16_t* ffb = d_ff.as<bf16_t>() + r0 * ffd;
     GemmParams g{};
     g.M = rows; g.tab = tab; g.tab_stride = tab_stride; g.step_idx = step; g.seq_pitch = pitch; g.seq_valid = N; g.batch = B;
-    g.live_len = live;
+    g.live_len = live_a;      // attention half; the FF half switches to `live` below
     g.heads = cfg.heads; g.npad = npad; g.rope_cos = d_rope_cos.as<float>(); g.rope_sin = d_rope_sin.as<float>();
     // attention variants with bit 16 take q already multiplied by softmax_scale * log2(e): the QK epilogue does it before rounding
     g.q_scale = (attn_variant & 16) ? (1.0f / sqrtf((float)cfg.dim_head)) * 1.4426950408889634f : 0.f;
@@ -816,7 +827,7 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     AttnParams at{};
     at.q = g.q; at.k = g.k; at.vt = g.vt; at.out = abf;
     at.kv_len = has_len ? d_len.as<int>() : nullptr; at.b2 = bh; at.batch = B; at.heads = cfg.heads; at.n = N; at.npad = npad; at.pitch = pitch;
-    at.scale = 1.0f / sqrtf((float)cfg.dim_head); at.variant = attn_variant; at.skip_dead = live != nullptr;
+    at.scale = 1.0f / sqrtf((float)cfg.dim_head); at.variant = attn_variant; at.live_len = live_a;
     const BlockW& w = blocks[l];
     const int base = l * 6 * d;  // [shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp] (modules.py:312)
     uint8_t* h8 = fp8 ? d_h8.as<uint8_t>() + r0 * d : nullptr;
@@ -855,7 +866,7 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     } else if (!(fuse_ln && l > 0)) {      // fused: block l's attn_norm rows were written by block l-1's FF2 launch
       RC_TRY(pbegin(PC_LN, q));
       if (f8_qkv) HIP_TRY(launch_ln_mod_f8(xres, h8, hmx, rows, d, tab, tab_stride, base + d, base, step, q));
-      else HIP_TRY(launch_ln_mod(xres, hbf, rows, d, tab, tab_stride, base + d, base, step, q, live, pitch, B));
+      else HIP_TRY(launch_ln_mod(xres, hbf, rows, d, tab, tab_stride, base + d, base, step, q, live_a, pitch, B));
       RC_TRY(pend(q));
     }
     // one launch for QK and V only while all of its workgroups fit the chip in one round (128 + 64 at configs[1]); beyond that two
@@ -914,6 +925,7 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     HIP_TRY(launch_gemm_bf16(EPI_GATE_RES, g, q));
     RC_TRY(skew_post(ln, q));
     g.ln_out = nullptr; g.xs_out = nullptr;
+    g.live_len = live;        // FF half
     if (!fuse_ln && !fold) {
       RC_TRY(pbegin(PC_LN, q));
       if (f8_ff1) HIP_TRY(launch_ln_mod_f8(xres, h8, hmx, rows, d, tab, tab_stride, base + 4 * d, base + 3 * d, step, q));
@@ -1065,6 +1077,12 @@ int lemas_dit::step_graph(hipStream_t s, hipGraphExec_t* exec, hipEvent_t* done)
   return 0;
 }
 
+// skip_dead 2: the rows the block chain keeps alive = the sample's own frames and one more 128-row block behind them
+__global__ void live_len_kernel(const int* __restrict__ len, int* __restrict__ live, int B, int halo, int N) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b < B) live[b] = min(((len[b] + 127) & ~127) + halo, N);
+}
+
 int lemas_dit::solve(const lemas_sample_args* a, hipStream_t s) {
   if (!finalized || !prepared) { set_error("lemas_dit_solve: prepare() has not run on the finalized weights"); return LEMAS_E_STATE; }
   RC_TRY(health());
@@ -1077,6 +1095,7 @@ int lemas_dit::solve(const lemas_sample_args* a, hipStream_t s) {
   HIP_TRY(hipMemcpy2DAsync(d_y.p, ypitch, y_src, yw, yw, B, hipMemcpyDeviceToDevice, s));
   if (a->trajectory) HIP_TRY(hipMemcpyAsync(a->trajectory, y_src, ybytes, hipMemcpyDeviceToDevice, s));
   HIP_TRY(launch_step_set(d_step.as<int>(), 0, s));
+  if (has_len && skip_dead == 2) hipLaunchKernelGGL(live_len_kernel, dim3((B + 63) / 64), dim3(64), 0, s, d_len.as<int>(), d_live.as<int>(), B, 128, N);
 
   const bool graph_ok = use_graph && !profile && !a->trajectory && s != nullptr;  // the legacy NULL stream cannot be captured
   if (graph_ok) {
@@ -1149,9 +1168,17 @@ int lemas_dit_set_option(lemas_dit* m, const char* key, int64_t value) {
     m->drop_graphs();
     return 0;
   }
+  if (!strcmp(key, "skip_masked")) {
+    if (m->skip_masked != (value != 0)) {
+      m->skip_masked = value != 0;
+      m->drop_graphs();
+    }
+    return 0;
+  }
   if (!strcmp(key, "skip_dead")) {
-    if (m->skip_dead != (value != 0)) {       // (a caller may set it before every batch: only a CHANGE invalidates the captured graphs)
-      m->skip_dead = value != 0;
+    if (value < 0 || value > 2) { set_error("lemas_dit_set_option: skip_dead is 0 (off), 1 (padding blocks skipped) or 2 (all but the first padding block skipped)"); return LEMAS_E_ARG; }
+    if (m->skip_dead != (int)value) {         // (a caller may set it before every batch: only a CHANGE invalidates the captured graphs)
+      m->skip_dead = (int)value;
       m->drop_graphs();
     }
     return 0;

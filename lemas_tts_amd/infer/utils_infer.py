@@ -210,10 +210,11 @@ def infer_batch_process(ref_audio, ref_text, gen_text_batches, model_obj, vocode
     computes on its own device.  ``batch_lines`` > 1 runs up to that many lines of ``gen_text`` as ONE
     ``CFM.sample`` batch (one captured graph per step for all of them) instead of the reference's serial loop
     (:572-579); lines of unequal length then follow the reference's own B > 1 semantics (``lens`` / duration masks,
-    cfm.py:336-339).  ``skip_padding_blocks`` (with ``batch_lines`` > 1; engine option ``skip_dead``): the
-    128-row blocks that lie wholly in a shorter line's padding are not computed -- ~10 % faster on a ragged batch of 8; a line's
-    last ~30 frames then differ from the B > 1 reference's by 1e-5 instead of 2e-6 mel-MSE (the reference's position-embedding
-    conv reads the padding rows behind a line; a line sampled alone has none)."""
+    cfm.py:336-339).  The attention half of every block always skips the 128-row blocks that lie wholly in a shorter line's padding (exact:
+    the reference zeroes that half's output there).  ``skip_padding_blocks`` (with ``batch_lines`` > 1; engine option ``skip_dead``,
+    DESIGN.md section 8) lets the FF half skip them too: ``True`` / 2 keeps one padding block alive behind every line (the rows the
+    reference's position-embedding conv reads: results at the reference's own error level, ~+2 % on a ragged batch of 8), 1 skips
+    them all (~+4 %; a line's last ~30 frames then differ from the B > 1 reference's by 1e-5 instead of 2e-6 mel-MSE)."""
     rms = None
     if isinstance(ref_audio, tuple):
         audio, sr = ref_audio
@@ -249,7 +250,7 @@ def infer_batch_process(ref_audio, ref_text, gen_text_batches, model_obj, vocode
     lines = list(gen_text_batches)
     group = max(1, int(batch_lines)) if not streaming else 1
     if group > 1 and hasattr(model_obj, "engine"):
-        model_obj.engine.set_option("skip_dead", 1 if skip_padding_blocks else 0)
+        model_obj.engine.set_option("skip_dead", 0 if not skip_padding_blocks else 1 if skip_padding_blocks == 1 and skip_padding_blocks is not True else 2)
     for g0 in range(0, len(lines), group):
         chunk = lines[g0: g0 + group]
         if len(chunk) == 1:                                                      # the reference's path: one line, B = 1

@@ -127,7 +127,7 @@ def test_ragged_batch_with_padding_blocks_left_uncomputed(dual, big):
     outs = {}
     try:
         m.engine.set_option("dual", dual)
-        for skip in (0, 1):
+        for skip in (0, 1, 2):
             m.engine.set_option("skip_dead", skip)
             for graph in (0, 1):
                 m.engine.set_option("graph", graph)
@@ -135,7 +135,15 @@ def test_ragged_batch_with_padding_blocks_left_uncomputed(dual, big):
     finally:
         m.engine.set_option("skip_dead", 0); m.engine.set_option("graph", 1); m.engine.set_option("dual", 1)
     m.engine.check_health()
-    for skip in (0, 1):
+    # the attention half of a block skips padding blocks by default (exact: the reference zeroes that half's output there): not a bit of the
+    # output, padding rows included, may differ from computing them
+    try:
+        m.engine.set_option("dual", dual); m.engine.set_option("skip_masked", 0)
+        full = m.sample(cond, text, dur, lens=lens, y0=y0, use_acc_grl=False, **kw)[0].cpu()
+    finally:
+        m.engine.set_option("skip_masked", 1); m.engine.set_option("dual", 1)
+    assert torch.equal(full, outs[(0, 0)])
+    for skip in (0, 1, 2):
         assert torch.equal(outs[(skip, 0)], outs[(skip, 1)])                # eager == replayed graph, with and without the switch
         assert torch.isfinite(outs[(skip, 0)]).all()
         assert _mse(outs[(skip, 0)], ref, Fs, Ns) <= 1e-4

@@ -14,7 +14,7 @@ fx, arch, sd = T._load(gd, name)
 fx = synth.expand_reference_fixture(fx)
 m = T._model(arch, int(fx["vocab"]), int(fx["wseed"]), bool(fx["prosody"]), sd)
 outs = {}
-for skip in (0, 1):
+for skip in (0, 1, 2):
     m.engine.set_option("skip_dead", skip)
     out, _ = T._run_case(fx, arch, sd, graph=True, traj=False)
     outs[skip] = np.asarray(out, dtype=np.float64)
@@ -28,7 +28,11 @@ for skip in (0, 1):
         tail_max = max(tail_max, np.abs(dt).max()); body_max = max(body_max, np.abs(db).max() if db.size else 0.0)
     print(f"{name} skip_dead={skip}: mel-MSE vs the reference  all generated {T._gen_mse(out, fx['out'], fx):.3e}   last 16 frames of each sample "
           f"{tail_se / tail_n:.3e} (max |err| {tail_max:.3e})   the other generated frames {body_se / max(body_n, 1):.3e} (max |err| {body_max:.3e})")
-m.engine.set_option("skip_dead", 1)
+m.engine.set_option("skip_dead", 0)
+m.engine.set_option("skip_masked", 0)
+full = np.asarray(T._run_case(fx, arch, sd, graph=True, traj=False)[0], dtype=np.float64)
+m.engine.set_option("skip_masked", 1)
+print("attention half computed for the padding blocks too (skip_masked 0) vs the default: whole output tensors equal:", bool((full == outs[0]).all()))
 d = 0.0; dmax = 0.0; far = 0.0
 for b in range(int(fx["B"])):
     L, D = int(fx["lens"][b]), int(fx["duration"][b])
