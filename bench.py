@@ -57,7 +57,8 @@ The JSON line also carries
 Measurement switches (none changes what the timed region computes): ``--no-phases`` skips the serial hoists / step loop / vocoder / D2H
 timing after the timed region (profiler passes with counters on the batched workloads: DESIGN.md section 8, profiler note),
 ``--no-clock-power`` the rocm-smi sampling pass, ``--no-cpu-baseline`` the oracle leg; ``--graph 0`` / ``--vocoder-graph 0`` launch eagerly,
-``--xcd-runs 1`` is round 3's GEMM tile order, ``--attn-variant`` / ``--ln-fused`` / ``--ln-fold`` / ``--dual 0`` select the engine's
+``--skip-dead 1|2`` / ``--skip-masked 0`` select what a ragged batch's padding blocks cost (the attention half of a block
+skips them by default, exactly; the FF half on request), ``--xcd-runs 1`` is round 3's GEMM tile order, ``--attn-variant`` / ``--ln-fused`` / ``--ln-fold`` / ``--dual 0`` select the engine's
 non-default kernels and schedules (the A/Bs of DESIGN.md section 8).
 """
 from __future__ import annotations
