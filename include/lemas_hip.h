@@ -130,7 +130,14 @@ int lemas_dit_finalize(lemas_dit* m);
  *        grid of the tile order (8, 4, 2, 1), "attn_variant" = schedule variant of the attention kernel (csrc/attention.hip; default
  *        19, 0 = classical online softmax).  Per engine: there is no process-global dispatch switch. */
 int lemas_dit_set_option(lemas_dit* m, const char* key, int64_t value);
-/* further options: "graph_cache" (step-graph buckets kept, least recently used evicted; default 16), "graph_update" (1 = a new
+/* ragged batches (lemas_sample_args.seq_len set; cfm.py:336-339): "skip_masked" (default 1: the ATTENTION half of every block -- attn_norm, the
+ * QK / V projections, attention, the out-projection -- skips the 128-row blocks that lie wholly in a sample's padding.  Exact: the reference zeroes
+ * that half's output for rows past a sample's length (modules.py AttnProcessor) and nothing else reads what it computes for them; the output is
+ * bit-identical, padding rows included.  0 = compute them, for A/B runs), "skip_dead" (what the FF half does with those blocks: 0 = computes them
+ * (default, the reference's arithmetic: its unmasked position-embedding conv, dit.py:98, lets a sample's last ~30 frames see the padding rows
+ * behind it); 2 = skips all but ONE block behind every sample, results at the reference's own error level; 1 = skips them all, a sample's last ~30
+ * frames then differ from the reference's by 1e-5 instead of 2e-6 mel-MSE).  bf16 chain only.
+ * further options: "graph_cache" (step-graph buckets kept, least recently used evicted; default 16), "graph_update" (1 = a new
  * frame count inside a cached bucket -- same batch, same 128-row pitch -- patches one of the bucket's instantiated graphs with
  * hipGraphExecUpdate instead of instantiating another; default 1), "fp8_outlier_guard" (default 1: with option "fp8" = 1, a checkpoint
  * whose residual-writing projections (attn.to_out, ff.2) show outlier output channels -- per-channel weight scale > 8x the median --
