@@ -145,7 +145,7 @@ class DiTEngine(_Streamed):
     def _canon(self, cond, cond_mask, text, seq_len, prosody):
         dev = self.device
         cond = cond.to(dev, torch.float32).contiguous()
-        cond_mask = cond_mask.to(dev).to(torch.uint8).contiguous()
+        cond_mask = cond_mask.to(torch.uint8).to(dev).contiguous()      # (converted where it lives -- the host, in the mirror's flow -- not by a torch kernel on the device)
         text = text.to(dev, torch.int64).contiguous()
         seq_len = None if seq_len is None else seq_len.to(dev, torch.int32).contiguous()
         prosody = None if prosody is None else prosody.to(dev, torch.float32).contiguous()
