@@ -116,19 +116,18 @@ int lemas_dit_finalize(lemas_dit* m);
  *        activations (one E8M0 scale per 32 K); attention, norms, residual stream and ODE state unchanged; default 0;
  *        takes effect at the next prepare()/sample().  2 = accuracy point, not a speed path: the same e4m3 weights with bf16
  *        ACTIVATIONS (weights-only fp8), computed by the bf16 kernels on the dequantised weights),
- * "ln_fused" (needs EXCLUSIVE use of the device -- its co-residency estimate does not see other tenants; a wait that times out flags the
- *        engine, see lemas_dit_health.  1 = the AdaLN LayerNorms that follow the gated residual updates (modules.py:637, the next block's :314, the final
- *        :335) run as the tail of the out-projection / FF2 launches whenever all workgroups of those launches fit the chip at
- *        once; default 0 = separate ln_mod launches: the fused form measured slower),
  * "ln_fold" (1 = those LayerNorms folded ACROSS the GEMMs on either side -- the gate + residual epilogues write the scaled bf16 rows and
  *        per-row partial sums, the QKV / FF1 epilogues apply the row statistics, c1 / c2 rows per ODE step in the AdaLN table: no
  *        LayerNorm launch after a step's first; bf16 activations only; a different rounding of the same arithmetic, inside the
- *        sampler's tolerance; default 0: measured neutral to 2 % slower), "lane_skew" (1 = lane 1 runs one
- *        stage behind lane 0 through event edges; measurement only, 1.7x slower),
+ *        sampler's tolerance; default 0: measured neutral to 2 % slower),
  * measurement options (0 = the production choice; each drops the cached graphs): "tile_n1024", "tile_n2048", "tile_qkv" = explicit
  *        GEMM tile ids (include/lemas_hip_test.h) for the block GEMMs of that width / the fused QK+V launch, "xcd_gx" = XCD block
  *        grid of the tile order (8, 4, 2, 1), "attn_variant" = schedule variant of the attention kernel (csrc/attention.hip; default
- *        19, 0 = classical online softmax).  Per engine: there is no process-global dispatch switch. */
+ *        19, 0 = classical online softmax).  Per engine: there is no process-global dispatch switch.
+ * NOT in this library: the experiments that were measured, lost and are kept reproducible -- "ln_fused" (LayerNorm as the tail of the gate +
+ *        residual GEMM launch), "lane_skew" (the CFG lanes one stage apart), "xcd_runs" (round 3's tile order) and the 64-queries-per-wave
+ *        attention kernel.  The first three exist in builds with -DLEMAS_MEASUREMENT_BUILD only (this library refuses a non-zero value), the
+ *        attention kernel in liblemas_hip_test.so only (include/lemas_hip_test.h: lemas_k_attention_variant, lemas_k_bench). */
 int lemas_dit_set_option(lemas_dit* m, const char* key, int64_t value);
 /* ragged batches (lemas_sample_args.seq_len set; cfm.py:336-339): "skip_masked" (default 1: the ATTENTION half of every block -- attn_norm, the
  * QK / V projections, attention, the out-projection -- skips the 128-row blocks that lie wholly in a sample's padding.  Exact: the reference zeroes

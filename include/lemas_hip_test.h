@@ -80,6 +80,9 @@ int lemas_k_ln_fold_pair(int32_t prod_tile, int32_t cons_epi, int32_t cons_tile,
  * on stamps its workgroups' start / end (100 MHz wall clock) into slot k of `buf` (u64 [slots][4096]: [workgroup][4]), k counting the
  * launches of one forward pass in enqueue order; buf = NULL switches it off.  In a product build this returns LEMAS_E_STATE. */
 int lemas_k_timeline(void* buf, int32_t slots);
+/* how both libraries were built: bit 0 = -DLEMAS_MEASUREMENT_BUILD (the kept-reproducible experiments exist: engine options "ln_fused", "lane_skew",
+ * "xcd_runs", lemas_k_gemm_gate_ln), bit 1 = -DLEMAS_PHASE_TIMESTAMPS (lemas_k_timeline, phase stamps).  0 = the product build. */
+int lemas_k_build_flags(void);
 
 /* micro-benchmark of one step-loop kernel on synthetic operands: what = "gemm_gelu" | "gemm_gate" | "gemm_qk" | "gemm_v" |
  * "gemm_f32out" | "gemm_gate_ln" (gemm_gate with its LayerNorm tail, N = 1024) (M,N,K = GEMM shape; prefix "f8_" for the MXFP8 path) or "attention" (M = frames, N = batch*heads); returns

@@ -20,7 +20,8 @@ OBJ = os.path.join(CSRC, "_build")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "liblemas_hip.so")
 TEST_LIB = os.path.join(LIBDIR, "liblemas_hip_test.so")
-TEST_ONLY = {"engine_ktests.hip"}          # sources that go into the test library, not the product
+TEST_ONLY = {"engine_ktests.hip", "attention_q64.hip"}     # sources that go into the test library, not the product (test entry points,
+                                                           # measurement-only kernels)
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -537,7 +537,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 }  // namespace
 
 bool attention_variant_ok(int v) {
-  if ((v & ATTN_Q64) != 0) return (v & ~(ATTN_Q64 | 16 | 3)) == 0 && (v & 16) != 0;
+  if ((v & ATTN_Q64) != 0) return false;     // the 64-queries-per-wave kernel lives in the test library (lemas_k_attention), not in an engine
   switch (v) {
     case 0: case 1: case 2: case 3: case 4: case 5: case 7: case 17: case 19: case 17 + 1024: case 19 + 1024: return true;
     default: return false;
@@ -554,7 +554,7 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
     if (p.ev_start) hipExtLaunchKernelGGL(attn_fwd_splitkv_kernel<V>, grid, dim3(512), 0, s, p.ev_start, p.ev_stop, 0, p);    \
     else hipLaunchKernelGGL(attn_fwd_splitkv_kernel<V>, grid, dim3(512), 0, s, p);                                             \
     break;
-  if ((p.variant & ATTN_Q64) != 0) return (p.variant & 16) != 0 ? launch_attention_q64(p, s) : hipErrorInvalidValue;
+  if ((p.variant & ATTN_Q64) != 0) return hipErrorInvalidValue;      // attention_q64.hip is a measurement kernel: liblemas_hip_test.so only
   switch (p.variant) {
     LEMAS_ATTN_LAUNCH(0) LEMAS_ATTN_LAUNCH(1) LEMAS_ATTN_LAUNCH(2) LEMAS_ATTN_LAUNCH(3) LEMAS_ATTN_LAUNCH(4) LEMAS_ATTN_LAUNCH(5)
     LEMAS_ATTN_LAUNCH(7) LEMAS_ATTN_LAUNCH(17) LEMAS_ATTN_LAUNCH(19) LEMAS_ATTN_LAUNCH(17 + 1024) LEMAS_ATTN_LAUNCH(19 + 1024)

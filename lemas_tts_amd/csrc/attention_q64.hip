@@ -70,6 +70,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int bh = lid / nqb, qblk = lid - bh * nqb;
   const int b2 = bh / p.heads, h = bh - b2 * p.heads;
   const int N = p.n;
+  // ragged batch: both 128-row blocks of this 256-query block are padding nobody reads, and with skip_masked their q rows were never
+  // written -- return as attention.hip does for its 128-query blocks (a half-live block runs: its dead half's rows are finite garbage
+  // that no live row depends on, stored to rows nobody reads)
+  if (p.live_len && qblk * QB2 >= ((p.live_len[b2 % p.batch] + 127) & ~127)) return;
   const int kvlen = p.kv_len ? p.kv_len[b2 % p.batch] : N;
   const int ntiles = (kvlen + KB - 1) / KB, nsup = (ntiles + 1) >> 1;
   const char* kg = reinterpret_cast<const char*>(p.k + (size_t)bh * p.pitch * 64);

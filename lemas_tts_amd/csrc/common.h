@@ -14,6 +14,14 @@ typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 #define LEMAS_WAVE 64
 
+// Measurement builds (LEMAS_EXTRA_HIPCC_FLAGS=-DLEMAS_MEASUREMENT_BUILD; implied by -DLEMAS_PHASE_TIMESTAMPS): the experiments that were measured,
+// lost and are kept reproducible -- the LayerNorm tail inside the gate + residual GEMM launch (engine option "ln_fused"), the lanes one stage apart
+// ("lane_skew"), round 3's XCD tile order ("xcd_runs") -- exist only there.  The product library carries neither their device code nor their options
+// (lemas_dit_set_option refuses them).
+#if defined(LEMAS_PHASE_TIMESTAMPS) && !defined(LEMAS_MEASUREMENT_BUILD)
+#define LEMAS_MEASUREMENT_BUILD 1
+#endif
+
 // 16-byte global store with the sc1 (write-through) cache policy: the line goes to memory now instead of sitting dirty
 // in this XCD's L2 until the end-of-kernel write-back, which otherwise serialises ~B/6 TB/s behind every producer
 // kernel (MI355X_MICROARCH.md price list, rows 'boundary' and 'publish-large').  Consumers run on other XCDs anyway

@@ -33,8 +33,6 @@ int kernels_init() {
   if (done[dev]) return 0;
   const hipError_t err = gemm_bf16_init();
   if (err != hipSuccess) return hip_fail(err, "gemm_bf16_init()", __FILE__, __LINE__);
-  const hipError_t err2 = attention_q64_init();
-  if (err2 != hipSuccess) return hip_fail(err2, "attention_q64_init()", __FILE__, __LINE__);
   done[dev] = true;
   return 0;
 }

@@ -71,7 +71,6 @@ struct lemas_dit {
   // four choices are independent.
   int fp8_sites_opt = 15;
   int fp8_sites() const { return !fp8 ? 0 : (fp8_guard && fp8_guard_tripped) ? 0 : fp8_sites_opt; }
-  bool f8_ln_fed() const { return (fp8_sites() & 0b0101) == 0b0101; }     // QKV and FF1 both on fp8 operands
   // measurement options (per engine; changing one drops the cached graphs): explicit tile ids for the block GEMMs with N == 1024 /
   // N == 2048, for the fused QK+V launch, and the XCD block grid of the tile order; 0 = the production choice
   // option "skip_dead" (0 by default): what the FF HALF of a block does with a ragged batch's padding blocks (the attention half skips them
@@ -610,6 +609,12 @@ int lemas_dit::text_embed(const lemas_sample_args* a, hipStream_t s) {
   return 0;
 }
 
+// skip_dead 2: the rows the block chain keeps alive = the sample's own frames and one more 128-row block behind them
+__global__ void live_len_kernel(const int* __restrict__ len, int* __restrict__ live, int B, int halo, int N) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b < B) live[b] = min(((len[b] + 127) & ~127) + halo, N);
+}
+
 int lemas_dit::prepare(const lemas_sample_args* a, hipStream_t s) {
   if (!finalized) { set_error("lemas_dit_prepare: weights not finalized"); return LEMAS_E_STATE; }
   RC_TRY(health());
@@ -648,6 +653,10 @@ int lemas_dit::prepare(const lemas_sample_args* a, hipStream_t s) {
     RC_TRY(d_len.ensure((size_t)B * 4));
     RC_TRY(d_live.ensure((size_t)B * 4));
     HIP_TRY(hipMemcpyAsync(d_len.p, a->seq_len, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+    // skip_dead == 2 reads these; filled HERE, whatever the option says now, so that every path behind prepare() -- solve(), a bare
+    // lemas_dit_forward(), an option change between the two -- finds them
+    hipLaunchKernelGGL(live_len_kernel, dim3((B + 63) / 64), dim3(64), 0, s, d_len.as<int>(), d_live.as<int>(), B, 128, N);
+    HIP_TRY(hipGetLastError());
   }
   // conditioning
   RC_TRY(d_cond_eff.ensure((size_t)B * pitch * md * 4));
@@ -836,7 +845,7 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     uint8_t* amx = fp8 ? d_amx.as<uint8_t>() + r0 * (in / 32) : nullptr;
     uint8_t* ff8 = fp8 ? d_ff8.as<uint8_t>() + r0 * ffd : nullptr;
     uint8_t* ffmx = fp8 ? d_ffmx.as<uint8_t>() + r0 * (ffd / 32) : nullptr;
-    // which of the block's GEMMs take fp8 operands: all of them, or (outlier guard tripped) only the two whose inputs are not LayerNorm outputs
+    // which of the block's GEMMs take fp8 operands (fp8_sites(): every site the option mask names, or none once the outlier guard has tripped)
     const int sites = fp8_sites();
     const bool f8_qkv = sites & 1, f8_out = sites & 2, f8_ff1 = sites & 4, f8_ff2 = sites & 8;
     g.concurrency = lanes;
@@ -1077,12 +1086,6 @@ int lemas_dit::step_graph(hipStream_t s, hipGraphExec_t* exec, hipEvent_t* done)
   return 0;
 }
 
-// skip_dead 2: the rows the block chain keeps alive = the sample's own frames and one more 128-row block behind them
-__global__ void live_len_kernel(const int* __restrict__ len, int* __restrict__ live, int B, int halo, int N) {
-  const int b = blockIdx.x * 64 + threadIdx.x;
-  if (b < B) live[b] = min(((len[b] + 127) & ~127) + halo, N);
-}
-
 int lemas_dit::solve(const lemas_sample_args* a, hipStream_t s) {
   if (!finalized || !prepared) { set_error("lemas_dit_solve: prepare() has not run on the finalized weights"); return LEMAS_E_STATE; }
   RC_TRY(health());
@@ -1095,7 +1098,6 @@ int lemas_dit::solve(const lemas_sample_args* a, hipStream_t s) {
   HIP_TRY(hipMemcpy2DAsync(d_y.p, ypitch, y_src, yw, yw, B, hipMemcpyDeviceToDevice, s));
   if (a->trajectory) HIP_TRY(hipMemcpyAsync(a->trajectory, y_src, ybytes, hipMemcpyDeviceToDevice, s));
   HIP_TRY(launch_step_set(d_step.as<int>(), 0, s));
-  if (has_len && skip_dead == 2) hipLaunchKernelGGL(live_len_kernel, dim3((B + 63) / 64), dim3(64), 0, s, d_len.as<int>(), d_live.as<int>(), B, 128, N);
 
   const bool graph_ok = use_graph && !profile && !a->trajectory && s != nullptr;  // the legacy NULL stream cannot be captured
   if (graph_ok) {
@@ -1106,8 +1108,13 @@ int lemas_dit::solve(const lemas_sample_args* a, hipStream_t s) {
     hipGraphExec_t exec = nullptr;
     hipEvent_t done = nullptr;
     RC_TRY(step_graph(s, &exec, &done));
-    for (int k = 0; k < S; ++k) HIP_TRY(hipGraphLaunch(exec, s));
-    HIP_TRY(hipEventRecord(done, s));
+    // `done` fences this graph's launches for a later hipGraphExecUpdate / destroy: recorded also when a launch fails mid-loop, so that a
+    // graph whose earlier launches are still running is never patched or destroyed under them
+    hipError_t el = hipSuccess;
+    for (int k = 0; k < S && el == hipSuccess; ++k) el = hipGraphLaunch(exec, s);
+    const hipError_t er = hipEventRecord(done, s);
+    HIP_TRY(el);
+    HIP_TRY(er);
   } else {
     for (int k = 0; k < S; ++k) {
       RC_TRY(enqueue_forward(s));
@@ -1188,6 +1195,14 @@ int lemas_dit_set_option(lemas_dit* m, const char* key, int64_t value) {
     m->drop_graphs();
     return 0;
   }
+#ifndef LEMAS_MEASUREMENT_BUILD
+  if (!strcmp(key, "ln_fused") || !strcmp(key, "lane_skew") || !strcmp(key, "xcd_runs")) {
+    if (value == 0) return 0;       // "off" is what the product does anyway
+    set_error("lemas_dit_set_option: '%s' is a measurement option -- its code exists only in builds of the library with -DLEMAS_MEASUREMENT_BUILD "
+              "(LEMAS_EXTRA_HIPCC_FLAGS, lemas_tts_amd/build.py); the product library does not carry it", key);
+    return LEMAS_E_ARG;
+  }
+#endif
   {
     int* slot = !strcmp(key, "tile_n1024") ? &m->opt_tile_n1024 : !strcmp(key, "tile_n2048") ? &m->opt_tile_n2048
               : !strcmp(key, "tile_qkv") ? &m->opt_tile_qkv : !strcmp(key, "xcd_gx") ? &m->opt_xcd_gx : !strcmp(key, "xcd_runs") ? &m->opt_xcd_runs

@@ -8,6 +8,7 @@
 #include <string>
 #include <vector>
 
+#include <mutex>
 #include "engine_common.h"
 #include "../../include/lemas_hip_test.h"
 
@@ -80,6 +81,16 @@ __global__ void fill_pattern_kernel(bf16_t* p, size_t n, unsigned seed) {
 extern "C" {
 
 int lemas_k_timeline(void* buf, int32_t slots) { return lemas_internal_timeline(buf, slots); }
+int lemas_k_build_flags(void) {
+  int f = 0;
+#ifdef LEMAS_MEASUREMENT_BUILD
+  f |= 1;
+#endif
+#ifdef LEMAS_PHASE_TIMESTAMPS
+  f |= 2;
+#endif
+  return f;
+}
 
 int lemas_k_linear_bf16(const float* A, const float* W, const float* bias, float* out, int32_t M, int32_t N, int32_t K,
                         int32_t act, void* stream) {
@@ -398,6 +409,18 @@ int lemas_k_linear_f8(const float* A, const float* W, const float* bias, float* 
   return 0;
 }
 
+// attention by variant: the product kernel (attention.hip), or -- variants with bit ATTN_Q64 -- the 64-queries-per-wave measurement kernel of
+// attention_q64.hip, which is compiled into THIS library only (no engine can select it)
+static hipError_t launch_attention_any(const AttnParams& p, hipStream_t s) {
+  if ((p.variant & ATTN_Q64) == 0) return launch_attention(p, s);
+  if ((p.variant & 16) == 0 || (p.variant & ~(ATTN_Q64 | 16 | 3)) != 0) return hipErrorInvalidValue;
+  static std::once_flag once;
+  static hipError_t init_err = hipSuccess;
+  std::call_once(once, []() { init_err = attention_q64_init(); });     // > 64 KB dynamic LDS opt-in (one device per test process)
+  if (init_err != hipSuccess) return init_err;
+  return launch_attention_q64(p, s);
+}
+
 int lemas_k_attention(const float* q, const float* k, const float* v, const int32_t* seq_len, float* out, int32_t B,
                       int32_t H, int32_t N, void* stream) {
   return lemas_k_attention_variant(q, k, v, seq_len, out, B, H, N, 0, stream);
@@ -421,7 +444,7 @@ int lemas_k_attention_variant(const float* q, const float* k, const float* v, co
   AttnParams p{};
   p.q = qb; p.k = kb; p.vt = vt; p.out = ob; p.kv_len = seq_len; p.b2 = B; p.batch = B; p.heads = H; p.n = N; p.npad = npad; p.pitch = pitch;
   p.scale = 0.125f; p.variant = variant;
-  HIP_TRY(launch_attention(p, s));
+  HIP_TRY(launch_attention_any(p, s));
   hipLaunchKernelGGL(unpad_widen_kernel, dim3(2048), dim3(256), 0, s, ob, out, B, N, pitch, H * 64);
   HIP_TRY(hipStreamSynchronize(s));
   return 0;
@@ -592,13 +615,13 @@ extern "C" int lemas_k_bench(const char* what, int32_t M, int32_t N, int32_t K, 
     AttnParams p{};
     p.q = q; p.k = k; p.vt = vt; p.out = o; p.kv_len = nullptr; p.b2 = bh / 16; p.batch = bh / 16; p.heads = 16; p.n = n; p.npad = npad; p.pitch = pitch;
     p.scale = 0.125f; p.variant = variant;
-    rc = time_it([&]() { return launch_attention(p, s); });
+    rc = time_it([&]() { return launch_attention_any(p, s); });
 #ifdef LEMAS_PHASE_TIMESTAMPS
     if (rc == 0) {   // phase timestamps of one more launch
       const int grid = ((n + 127) / 128) * bh;
       unsigned long long* d = sc.get<unsigned long long>((size_t)grid * 4);
       p.dbg = d;
-      (void)launch_attention(p, s);
+      (void)launch_attention_any(p, s);
       HIP_TRY(hipStreamSynchronize(s));
       std::vector<unsigned long long> h((size_t)grid * 4);
       HIP_TRY(hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost));

@@ -23,7 +23,14 @@ struct lemas_vocos {
   // the engine's own buffers) is replayed as ONE hipGraph per (batch, frames) shape.  A shape is captured the SECOND time it is seen (a
   // serving process decodes a different length almost every utterance: a capture costs about what the decode does); at most `graph_cap`
   // shapes are kept, least recently used evicted; a (re)allocated workspace or reloaded weight drops them all.
-  struct Slot { hipGraphExec_t exec = nullptr; unsigned long long used = 0; int seen = 0; };
+  // `done` is recorded behind every launch of `exec` on the stream it went to: a graph is destroyed only after its last launch finished,
+  // whichever stream that was (the caller may decode on several)
+  struct Slot { hipGraphExec_t exec = nullptr; hipEvent_t done = nullptr; unsigned long long used = 0; int seen = 0; };
+  static void drop_slot(Slot& sl) {
+    if (sl.done) { (void)hipEventSynchronize(sl.done); (void)hipEventDestroy(sl.done); }
+    if (sl.exec) (void)hipGraphExecDestroy(sl.exec);
+    sl = Slot{};
+  }
   std::map<std::pair<int, int>, Slot> graphs;
   unsigned long long tick = 0, moved = 1, generation = 0;
   int graph_cap = 8;
@@ -33,8 +40,7 @@ struct lemas_vocos {
     for (DevBuf* b : {&basis, &d_col, &d_a, &d_b, &d_c, &d_mid, &d_head, &d_spec, &d_frames}) b->moved = &moved;
   }
   void drop_graphs() {
-    for (auto& g : graphs)
-      if (g.second.exec) (void)hipGraphExecDestroy(g.second.exec);
+    for (auto& g : graphs) drop_slot(g.second);
     graphs.clear();
   }
   ~lemas_vocos() {
@@ -149,12 +155,19 @@ struct lemas_vocos {
         auto lru = graphs.begin();
         for (auto j = graphs.begin(); j != graphs.end(); ++j)
           if (j->second.used < lru->second.used) lru = j;
-        if (lru->second.exec) { HIP_TRY(hipStreamSynchronize(s)); (void)hipGraphExecDestroy(lru->second.exec); }
+        drop_slot(lru->second);                    // waits for that graph's own last launch, on whatever stream it ran
         graphs.erase(lru);
       }
     }
-    if (exec) HIP_TRY(hipGraphLaunch(exec, s));
-    else RC_TRY(body(B, L, s));
+    if (exec) {
+      Slot& slot = graphs[{B, L}];
+      if (!slot.done) HIP_TRY(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
+      const hipError_t el = hipGraphLaunch(exec, s);
+      (void)hipEventRecord(slot.done, s);          // also when the launch failed: whatever did get enqueued is fenced
+      HIP_TRY(el);
+    } else {
+      RC_TRY(body(B, L, s));
+    }
     HIP_TRY(launch_overlap_add(d_frames.as<float>(), ws.ptr("head.istft.window"), B, L, nfft, hop, wav, s));
     if (gain != 1.0f) HIP_TRY(launch_scale(wav, gain, (size_t)B * hop * (L - 1), s));
     return 0;

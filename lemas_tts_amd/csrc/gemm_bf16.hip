@@ -76,6 +76,9 @@ __device__ __forceinline__ void kernargs_early(const GemmParams& p) {
 }
 __device__ __forceinline__ void tile_coords(int seq, int tiles_m, int tiles_n, int gx, int& tm, int& tn);
 __device__ __forceinline__ bool tile_of(int bid, int tiles_m, int tiles_n, int gx, int runs, int& tm, int& tn) {
+#ifndef LEMAS_MEASUREMENT_BUILD
+  runs = 0;      // round 3's order is an A/B arm of measurement builds (engine option "xcd_runs")
+#endif
   if (runs) {
     const int nwg = tiles_m * tiles_n;
     if (bid >= nwg) return false;
@@ -91,7 +94,12 @@ __device__ __forceinline__ bool tile_dead(const GemmParams& p, int m0, int tbm) 
     if (!row_block_dead(p.live_len, r, p.seq_pitch, p.batch)) return false;
   return true;
 }
-static inline int grid_of(int tiles_m, int tiles_n, int gx, int runs) { return runs ? tiles_m * tiles_n : xcd_grid(tiles_m, tiles_n, gx); }
+static inline int grid_of(int tiles_m, int tiles_n, int gx, int runs) {
+#ifndef LEMAS_MEASUREMENT_BUILD
+  runs = 0;
+#endif
+  return runs ? tiles_m * tiles_n : xcd_grid(tiles_m, tiles_n, gx);
+}
 __device__ __forceinline__ void tile_coords(int seq, int tiles_m, int tiles_n, int gx, int& tm, int& tn) {
   const int gy = 8 / gx;
   const int bm = (tiles_m + gx - 1) / gx, bn = (tiles_n + gy - 1) / gy;
@@ -1068,9 +1076,11 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, int m
       else epilogue_vt<1, TJ>(p, blk, slab, m0 + wm * WTM + 32 * i, n0 + wn * WTN, lane, rs_lds + 2 * (wm * WTM + 32 * i));
     }
   }
+#ifdef LEMAS_MEASUREMENT_BUILD
   if constexpr (EPI == EPI_GATE_RES && SWAP && !F8) {
     if (p.ln_out) ln_tail<TBM, TBN, NW>(p, m0, n0, smem);      // (its first barrier retires every wave's epilogue slab: LDS is free behind it)
   }
+#endif
   PHASE_STAMP_END();
 }
 
@@ -1756,6 +1766,9 @@ static bool ln_tile_shape(int tile, int* bm, int* bn, int* per_cu) {
 }
 
 int gemm_bf16_ln_fusable(const GemmParams& p, int* panels, int* per_cu) {
+#ifndef LEMAS_MEASUREMENT_BUILD
+  return 0;
+#endif
   int bm, bn;
   if (p.f8 || p.N != LN_D || p.ldc != LN_D || p.n_valid != LN_D || p.M <= 0) return 0;
   if (!ln_tile_shape(pick_tile(p), &bm, &bn, per_cu) || p.M % bm != 0) return 0;
@@ -1769,6 +1782,9 @@ hipError_t launch_gemm_bf16_tile(int epi, const GemmParams& p_in, int tile, hipS
   if (p.K % BK != 0 || p.N % 128 != 0 || p.M <= 0 || p.seq_pitch <= 0) return hipErrorInvalidValue;
   if (!ln_fold_ok(epi, p)) return hipErrorInvalidValue;
   if (p.ln_out) {   // LayerNorm tail: only on the tiles that carry it, with complete row panels and the counters in place
+#ifndef LEMAS_MEASUREMENT_BUILD
+    return hipErrorInvalidValue;      // the tail's device code is compiled into measurement builds only (common.h)
+#endif
     int bm, bn, per_cu;
     if (epi != EPI_GATE_RES || p.f8 || p.N != LN_D || p.ldc != LN_D || p.n_valid != LN_D || !p.ln_cnt || !p.ln_err || !p.tab || !p.step_idx)
       return hipErrorInvalidValue;

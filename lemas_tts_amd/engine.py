@@ -107,6 +107,11 @@ class DiTEngine(_Streamed):
 
     def set_option(self, key: str, value: int):
         _lib.check(_lib.lib().lemas_dit_set_option(self._h, key.encode(), int(value)), f"set_option({key})")
+        self.__dict__.setdefault("_options", {})[key] = int(value)
+
+    def option(self, key: str, default: int = 0) -> int:
+        """the value this object last set for ``key`` (``default``: the library's own default when it was never set here)"""
+        return self.__dict__.get("_options", {}).get(key, default)
 
     def stat(self, key: str) -> int:
         """counters of the engine's step-graph cache etc. (``lemas_dit_get_stat``)"""
@@ -200,8 +205,12 @@ class DiTEngine(_Streamed):
 
     def forward(self, x, step_index: int):
         """One DiT forward (both CFG branches) at step ``step_index`` of the prepared grid -> [BB, N, mel]."""
-        cond = self._prep_keep[0]
-        B, N, md = cond.shape
+        cond, cond_mask = self._prep_keep[0], self._prep_keep[1]
+        B, N = cond_mask.shape          # cond may hold fewer rows than N (cond_rows): the library works on N = frames
+        md = cond.shape[2]
+        assert N == self._prep_args.frames
+        if tuple(x.shape) != (B, N, md):
+            raise ValueError(f"forward: x must be [{B}, {N}, {md}] (the prepared batch / frames / mel), got {tuple(x.shape)}")
         with torch.cuda.device(self.device):
             x = x.to(self.device, torch.float32).contiguous()
             bb = 2 * B if self._prep_args.cfg_strength >= 1e-5 else B

@@ -249,8 +249,34 @@ def infer_batch_process(ref_audio, ref_text, gen_text_batches, model_obj, vocode
 
     lines = list(gen_text_batches)
     group = max(1, int(batch_lines)) if not streaming else 1
-    if group > 1 and hasattr(model_obj, "engine"):
-        model_obj.engine.set_option("skip_dead", 0 if not skip_padding_blocks else 1 if skip_padding_blocks == 1 and skip_padding_blocks is not True else 2)
+    # skip_padding_blocks: False / 0 = the reference's arithmetic, True / 2 = engine option skip_dead 2 (all but one padding block behind every
+    # line skipped: the reference's error level), the integer 1 = skip_dead 1 (all of them).  The engine's setting is restored when this call
+    # ends, however it ends: the option belongs to this batch, not to the model.
+    engine = getattr(model_obj, "engine", None) if group > 1 else None
+    if engine is not None:
+        level = 0 if not skip_padding_blocks else 2 if skip_padding_blocks is True else int(skip_padding_blocks)
+        skip_dead_before = engine.option("skip_dead", 0)
+        engine.set_option("skip_dead", level)
+    try:
+        yield from _infer_lines(lines, group, model_obj, cond, ref_text, line_duration, nfe_step, cfg_strength, sway_sampling_coef, use_acc_grl,
+                                use_prosody_encoder, ref_ratio, no_ref_audio, seed, noise, prosody_embeds, ref_audio_len, vocode, streaming, chunk_size,
+                                generated_waves, spectrograms)
+    finally:
+        if engine is not None:
+            engine.set_option("skip_dead", skip_dead_before)
+    if streaming:
+        return
+    if generated_waves:
+        final_wave = cross_fade_concat(generated_waves, cross_fade_duration)
+        yield np.clip(final_wave, -0.999, 0.999), target_sample_rate, np.concatenate(spectrograms, axis=1)   # :620-622
+    else:
+        yield None, target_sample_rate, None
+
+
+def _infer_lines(lines, group, model_obj, cond, ref_text, line_duration, nfe_step, cfg_strength, sway_sampling_coef, use_acc_grl,
+                 use_prosody_encoder, ref_ratio, no_ref_audio, seed, noise, prosody_embeds, ref_audio_len, vocode, streaming, chunk_size,
+                 generated_waves, spectrograms):
+    """the per-line loop of ``infer_batch_process`` (utils_infer.py:506-565 per line, :572-618 around it); yields only when streaming"""
     for g0 in range(0, len(lines), group):
         chunk = lines[g0: g0 + group]
         if len(chunk) == 1:                                                      # the reference's path: one line, B = 1
@@ -289,10 +315,3 @@ def infer_batch_process(ref_audio, ref_text, gen_text_batches, model_obj, vocode
             else:
                 generated_waves.append(wave)
                 spectrograms.append(gen_mel[0].cpu().numpy())
-    if streaming:
-        return
-    if generated_waves:
-        final_wave = cross_fade_concat(generated_waves, cross_fade_duration)
-        yield np.clip(final_wave, -0.999, 0.999), target_sample_rate, np.concatenate(spectrograms, axis=1)   # :620-622
-    else:
-        yield None, target_sample_rate, None

@@ -69,10 +69,11 @@ def compute_sway_max(steps: int, t_start: float = 0.0, min_ratio: float = 1e-9, 
     return max(0.0, p_max - 1.0) * float(safety_factor)
 
 
-def time_grid(steps: int, sway_sampling_coef) -> torch.Tensor:
-    """``cfm.py:445-453``: linspace(0,1,steps+1) ** (1 + min(sway_max, coef)), fp32, python ``min`` semantics."""
-    t = torch.linspace(0, 1, int(steps + 1), dtype=torch.float32)
-    sway_max = torch.tensor(compute_sway_max(steps), dtype=torch.float32)
+def time_grid(steps: int, sway_sampling_coef, t_start: float = 0.0) -> torch.Tensor:
+    """``cfm.py:445-453``: linspace(t_start,1,steps+1) ** (1 + min(sway_max, coef)), fp32, python ``min`` semantics (``t_start`` > 0 only in
+    the ``duplicate_test`` corner, :438-443)."""
+    t = torch.linspace(t_start, 1, int(steps + 1), dtype=torch.float32)
+    sway_max = torch.tensor(compute_sway_max(steps, t_start=t_start), dtype=torch.float32)
     if sway_sampling_coef is not None:
         return t ** (1 + min(sway_max, sway_sampling_coef))
     return t ** (1 + sway_max)
@@ -118,8 +119,6 @@ class CFM:
         """Extra keyword-only inputs over the reference: ``y0`` (explicit ODE start; the reference draws it on
         its own device, cfm.py:430-435), ``prosody_embeds`` [B,512] (what the prosody encoder would return,
         cfm.py:261-263) and ``return_trajectory`` (the reference always returns it; its callers discard it)."""
-        if duplicate_test:
-            raise NotImplementedError("the duplicate_test debug corner (cfm.py:307-309) is outside the hot path")
         if use_acc_grl and ref_ratio is None:
             raise TypeError("'<' not supported between instances of 'NoneType' and 'int'")  # cfm.py:273 hazard
         dev = self.device
@@ -166,6 +165,11 @@ class CFM:
         duration = torch.maximum(torch.maximum((text != -1).sum(dim=-1), lens) + 1, duration).clamp(max=max_duration)
         n = int(duration.amax())
 
+        test_cond = None
+        if duplicate_test:
+            # cfm.py:307-309 ("duplicate test corner for inner time step observation"): the RAW prompt mel shifted behind itself, rows
+            # [F, 2F) of an n-row tensor (a negative right pad crops, as F.pad does there)
+            test_cond = F.pad(cond, (0, 0, cond_seq_len, n - 2 * cond_seq_len), value=0.0)
         # cfm.py:311 right-pads the prompt mel with zeros up to n (and CROPS it when `lens` lets the duration fall below the prompt
         # length: negative pad).  The padding is the library's (lemas_sample_args.cond_rows): no pad copy here
         if cond_seq_len > n:
@@ -194,7 +198,12 @@ class CFM:
             y0 = torch.nn.utils.rnn.pad_sequence(ys, padding_value=0, batch_first=True)
         assert tuple(y0.shape) == (batch, n, self.num_channels), (tuple(y0.shape), (batch, n, self.num_channels))
 
-        t = time_grid(steps, sway_sampling_coef)
+        t_start = 0.0
+        if duplicate_test:                                                   # cfm.py:438-443: start the solve at t_inter from a blend of
+            t_start = t_inter                                                # the noise and the shifted prompt, on a shortened grid
+            y0 = (1 - t_start) * y0.to(torch.float32) + t_start * test_cond.to(y0.device)
+            steps = int(steps * (1 - t_start))
+        t = time_grid(steps, sway_sampling_coef, t_start)
         step_cond = None
         if cond_grl is not None and (pros is not None or no_ref_audio or ref_ratio < 1):
             # the flow is conditioned on cond_grl, not on the (prosody-shifted / replaced) cond (cfm.py:329-330, 387-388);

@@ -41,7 +41,7 @@ def _reference_y0(seed: int, durations) -> torch.Tensor:
 
 def run_case(name, arch, *, wseed, B, F, lens, Nt, duration, steps, cfg, coef, noise_seed,
              edit_spans=None, prosody=False, use_acc_grl=False, no_ref_audio=False, ref_ratio=1, pyseed=None, store_traj=True,
-             outlier=None):
+             outlier=None, duplicate_test=False, t_inter=0.1):
     if ONLY is not None and name not in ONLY:
         return
     sd_np = synth.synth_cfm_state_dict(arch, VOCAB, wseed, prosody=prosody, outlier=outlier)
@@ -65,6 +65,9 @@ def run_case(name, arch, *, wseed, B, F, lens, Nt, duration, steps, cfg, coef, n
 
     kw = dict(steps=steps, cfg_strength=cfg, sway_sampling_coef=coef, seed=noise_seed,
               edit_mask=edit_mask, use_acc_grl=use_acc_grl, ref_ratio=ref_ratio, lens=lens_t)
+    if duplicate_test:              # cfm.py:307-309, 438-443: the solve starts at t_inter from a blend of the noise and the shifted prompt
+        kw["duplicate_test"] = True
+        kw["t_inter"] = t_inter
     pros = None
     cond_in = torch.from_numpy(cond)
     if prosody:
@@ -110,9 +113,13 @@ def run_case(name, arch, *, wseed, B, F, lens, Nt, duration, steps, cfg, coef, n
                                        torch.tensor(lens_eff)) + 1,
                          torch.full((B,), duration) if isinstance(duration, int) else torch.tensor(duration))
     y0 = _reference_y0(noise_seed, durs.tolist())
-    assert y0.shape == out.shape and torch.equal(y0, traj[0]), "y0 replication drifted"
+    if duplicate_test:              # traj[0] is the blend; the fixture stores the NOISE (the sampler's input), like every other case
+        tc = torch.nn.functional.pad(torch.from_numpy(cond), (0, 0, F, N - 2 * F))
+        assert y0.shape == out.shape and torch.equal((1 - t_inter) * y0 + t_inter * tc, traj[0]), "y0 replication drifted"
+    else:
+        assert y0.shape == out.shape and torch.equal(y0, traj[0]), "y0 replication drifted"
 
-    if use_acc_grl is False and not prosody and edit_spans is None and B == 1 and not no_ref_audio and ref_ratio >= 1:
+    if use_acc_grl is False and not prosody and edit_spans is None and B == 1 and not no_ref_audio and ref_ratio >= 1 and not duplicate_test:
         out2, _ = cfm.sample(cond=cond_in, text=torch.from_numpy(text), duration=dur_arg,
                              **{**kw, "use_acc_grl": True})
         assert torch.equal(out, out2), "accent-GRL flag must be a forward no-op at ref_ratio>=1"
@@ -159,6 +166,9 @@ def run_case(name, arch, *, wseed, B, F, lens, Nt, duration, steps, cfg, coef, n
         fx["pyseed"] = np.int64(pyseed)
     if outlier is not None:
         fx["outlier"] = np.asarray(outlier, dtype=np.float64)
+    if duplicate_test:
+        fx["duplicate_test"] = np.int64(1)
+        fx["t_inter"] = np.float64(t_inter)
     np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), **fx)
     print(f"{name}: N={N} steps={steps} ref {dt:.1f}s |out| mean {out.abs().mean():.4f} "
           f"traj[-1] std {traj[-1].std():.4f}")
@@ -247,6 +257,10 @@ def main():
              cfg=2.0, coef=5, noise_seed=110, prosody=True, no_ref_audio=True)
     run_case("mini_grl_shuffle", MINI, wseed=21, B=1, F=230, lens=None, Nt=[40], duration=400, steps=3,
              cfg=2.0, coef=5, noise_seed=109, use_acc_grl=True, ref_ratio=0.5, pyseed=4242)
+    # the duplicate_test corner (cfm.py:307-309, 438-443): steps = int(10 * 0.75) = 7 on a grid that starts at 0.25; batch of 2 with ragged
+    # durations so that the shifted prompt is cropped for neither and zero-padded differently for each
+    run_case("mini_duplicate", MINI, wseed=25, B=2, F=40, lens=None, Nt=[18, 22], duration=[110, 96], steps=10,
+             cfg=2.0, coef=5, noise_seed=112, duplicate_test=True, t_inter=0.25)
     if ONLY is None:
         run_edit_mask_cases()
         run_prosody_case("prosody_enc_short", 17, 41)

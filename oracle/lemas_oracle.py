@@ -53,17 +53,17 @@ def tokens_to_idx(tokens: list, vocab: dict, pad: int = -1) -> Tensor:
     return torch.tensor([r + [pad] * (n - len(r)) for r in rows], dtype=torch.long)
 
 
-def sway_max(steps: int, min_ratio: float = 1e-9, safety: float = 0.7) -> float:
-    """cfm.py:343-373 as called at :447 (t_start=0)."""
-    dt = 1.0 / max(1, steps)
+def sway_max(steps: int, min_ratio: float = 1e-9, safety: float = 0.7, t_start: float = 0.0) -> float:
+    """cfm.py:343-373 as called at :447 (t_start=0 except in the duplicate_test corner)."""
+    dt = (1.0 - t_start) / max(1, steps)
     p_max = 11.0 if dt >= 0.9 else math.log(min_ratio) / math.log(dt)
     return max(0.0, p_max - 1.0) * safety
 
 
-def time_grid(steps: int, sway_sampling_coef: Optional[float]) -> Tensor:
+def time_grid(steps: int, sway_sampling_coef: Optional[float], t_start: float = 0.0) -> Tensor:
     """cfm.py:445-453: power-law warp t**(1+s), s capped by ``sway_max`` (fp32 throughout)."""
-    t = torch.linspace(0, 1, steps + 1, dtype=torch.float32)
-    smax = torch.tensor(sway_max(steps), dtype=torch.float32)
+    t = torch.linspace(t_start, 1, steps + 1, dtype=torch.float32)
+    smax = torch.tensor(sway_max(steps, t_start=t_start), dtype=torch.float32)
     # the reference takes python ``min(tensor, number)``: the exponent is either the fp32 tensor cap or
     # the caller's python number (then ``t ** float``) -- kept distinct so the grid matches bit-for-bit
     s = smax if sway_sampling_coef is None else min(smax, sway_sampling_coef)
@@ -303,7 +303,7 @@ class OracleCFM:
                max_duration: int = 4096, edit_mask: Optional[Tensor] = None,
                prosody_embeds: Optional[Tensor] = None, t_grid: Optional[Tensor] = None,
                no_ref_audio: bool = False, cond_noise: Optional[Tensor] = None,
-               use_acc_grl: bool = False, ref_ratio: float = 1):
+               use_acc_grl: bool = False, ref_ratio: float = 1, duplicate_test: bool = False, t_inter: float = 0.1):
         """``cond`` is a mel [B,F,100]; ``text`` int64 [B,Nt] padded with -1; ``y0`` [B,N,100] is the
         explicit ODE start (the reference draws it at cfm.py:430-435).  ``prosody_embeds`` [B,512]
         stands for the prosody-encoder output (cfm.py:248-265, a "next" row).  ``no_ref_audio`` (cfm.py:320-324, 464-466)
@@ -324,6 +324,7 @@ class OracleCFM:
         duration = torch.maximum(torch.maximum((text != -1).sum(-1), lens) + 1, duration)   # :300-302
         duration = duration.clamp(max=max_duration)
         n = int(duration.amax())
+        test_cond = F.pad(cond, (0, 0, f, n - 2 * f)) if duplicate_test else None   # :307-309
         cond = F.pad(cond, (0, 0, 0, n - f))                               # :311
         prosody_text = None
         if prosody_embeds is not None and self.prosody_to_mel is not None:
@@ -347,8 +348,14 @@ class OracleCFM:
             return (pred + (pred - null) * (cfg_strength * (1 - t) ** 2)).clamp(-20, 20)
 
         assert y0.shape == (b, n, self.a.mel_dim), (y0.shape, (b, n))
-        t = time_grid(steps, sway_sampling_coef) if t_grid is None else t_grid
-        traj = euler_solve(fn, y0.float(), t)                              # :456
+        y0 = y0.float()
+        t_start = 0.0
+        if duplicate_test:                                                 # :438-443
+            t_start = t_inter
+            y0 = (1 - t_start) * y0 + t_start * test_cond
+            steps = int(steps * (1 - t_start))
+        t = time_grid(steps, sway_sampling_coef, t_start) if t_grid is None else t_grid
+        traj = euler_solve(fn, y0, t)                                      # :456
         self.dit.clear_cache()                                             # :457
         out = torch.where(cond_mask, cond, traj[-1])                       # :459-461
         if no_ref_audio:                                                   # :464-466

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import needs_measurement_build
 from test_gpu_01_kernels import EPI_GATE, _bf, _lib  # helpers of the kernel tests
 
 pytestmark = pytest.mark.gpu
@@ -54,6 +55,7 @@ def _gate_ln_case(tile, batch, frames, K, seed, concurrent=1, ragged=False):
     assert float(((h - _bf(hr)).abs() / hr.abs().clamp(min=1.0)).max()) < 1.01 / 128
 
 
+@needs_measurement_build
 @pytest.mark.parametrize("tile", [17, 18, 19, 26])
 @pytest.mark.parametrize("K", [1024, 2048])
 def test_gemm_gate_with_layernorm_tail_every_tile(tile, K):
@@ -61,12 +63,14 @@ def test_gemm_gate_with_layernorm_tail_every_tile(tile, K):
     _gate_ln_case(tile, 1, 1875, K, seed=tile * 7 + K)
 
 
+@needs_measurement_build
 @pytest.mark.parametrize("tile,batch,frames", [(17, 1, 1875), (19, 1, 750), (18, 1, 750), (17, 2, 900)])
 def test_gemm_gate_with_layernorm_tail_two_concurrent_lanes(tile, batch, frames):
     """two launches at once on two streams, as the CFG lanes run them: each waits only for its own panels; identical results"""
     _gate_ln_case(tile, batch, frames, 2048, seed=tile + frames, concurrent=2, ragged=batch > 1)
 
 
+@needs_measurement_build
 def test_gemm_gate_with_layernorm_tail_repeated_under_load():
     """the tail's hand-off (write-through stores, drained, one arrival per workgroup, relaxed poll, L1-bypassing loads) repeated with
     fresh data while a second pair of launches keeps the chip busy: a stale row would show as a bit difference against the
@@ -76,6 +80,7 @@ def test_gemm_gate_with_layernorm_tail_repeated_under_load():
 
 
 def test_gemm_gate_layernorm_tail_refuses_tiles_without_it():
+    """(in the product build: refuses every tile -- the tail's device code is not there)"""
     L, lib = _lib()
     dev = "cuda:0"
     a, w = torch.zeros(256, 1024, device=dev), torch.zeros(1024, 1024, device=dev)

@@ -14,7 +14,7 @@ from lemas_tts_amd import synth
 from lemas_tts_amd.model.layout import DiTArch
 from oracle import lemas_oracle as O
 
-CASES = ["mini_plain", "mini_nocfg_nosway", "mini_batch", "mini_edit", "mini_prosody", "mini_noref", "mini_noref_prosody", "mini_grl_prosody", "mini_grl_shuffle", "full_plain", "full_outlier"]
+CASES = ["mini_plain", "mini_nocfg_nosway", "mini_batch", "mini_edit", "mini_prosody", "mini_noref", "mini_noref_prosody", "mini_grl_prosody", "mini_grl_shuffle", "mini_duplicate", "full_plain", "full_outlier"]
 ATOL = 5e-5   # measured max |err| 3.7e-6 (fp32 vs fp32, different summation order); |out| ~ 1.8
 
 
@@ -41,6 +41,8 @@ def oracle_sample(fx, arch, sd):
         kw.update(no_ref_audio=True, cond_noise=torch.from_numpy(fx["cond_noise"]))
     if "use_acc_grl" in fx:
         kw.update(use_acc_grl=True, ref_ratio=float(fx["ref_ratio"]))
+    if "duplicate_test" in fx:              # cfm.py:307-309, 438-443
+        kw.update(duplicate_test=True, t_inter=float(fx["t_inter"]))
     if "pyseed" in fx:                      # clip_and_shuffle draws from Python's random (cfm.py:39-84)
         import random
         random.seed(int(fx["pyseed"]))
