@@ -120,6 +120,59 @@ def class_flops(cls: str, rows: float, nsq: float, d: int = 1024, ff: int = 2048
             "attention": 4.0 * nsq * 64 * heads}[cls]
 
 
+def class_bytes(cls: str, rows: float, nsq_over_rows: float, d: int = 1024, ff: int = 2048) -> float:
+    """Algorithmic HBM bytes of one launch (operands in + results out, each once; bf16 activations and weights, the
+    fp32 residual stream read and written by the gate + residual launches)."""
+    return {"gemm_qkv_fused": rows * d * 2 + 3 * d * d * 2 + rows * 3 * d * 2, "gemm_qk_rope": rows * d * 2 + 2 * d * d * 2 + rows * 2 * d * 2,
+            "gemm_v_t": rows * d * 2 + d * d * 2 + rows * d * 2, "gemm_attn_out": rows * d * 2 + d * d * 2 + 2 * rows * d * 4,
+            "gemm_ff1_gelu": rows * d * 2 + ff * d * 2 + rows * ff * 2, "gemm_ff2": rows * ff * 2 + ff * d * 2 + 2 * rows * d * 4,
+            "attention": 4 * rows * d * 2}[cls]
+
+
+def latency_roofline(kernel_avg_us: dict, pipes: dict, rows_lane: int, block_us_measured: float, lanes: int, clock_ghz: float):
+    """The LATENCY roofline of one CFG lane's block at batch 1: the block is a dependent chain of seven launches (LN, QK+V, attention, out-proj,
+    LN, FF1, FF2), so its floor is not FLOPs / peak but   sum over the launches of (ideal K loop + what a launch costs outside its loop) +
+    boundaries.  Inputs: per K-tile pipe times and the prologue / epilogue / ramp + drain of the 128 x 128 tile from the committed ablation
+    builds (`pipes`, profiles/r04g_kloop_pipes.json), the launch boundary from MI355X_MICROARCH.md's price list ("boundary": 1.1-1.4 us inside a
+    GEMM chain), and this run's own per-launch averages (eager pass) for the launches the model has no pipe figures for (LayerNorm, attention).
+    An "ideal K loop" runs at the slower of its two equally loaded pipes -- 512 MFMA clocks per SIMD and 32 KB through the CU's 64 B/clk
+    vector-memory path per 128 x 128 x 64 K-tile -- i.e. with the fragment reads and the LDS-DMA requests perfectly hidden."""
+    t17 = pipes["tiles"]["17"]
+    fixed = t17["outside_the_loop_us"]
+    out_loop = fixed["prologue"] + fixed["epilogue"] + fixed["launch_ramp_and_drain"]
+    boundary = 1.25
+    tiles_m = (rows_lane + 127) // 128
+    cus = 256 // lanes if lanes > 1 else 256                    # with two lanes on the chip a lane's launch has half of it
+    def gemm(n, k, bm=128, bn=128):
+        tiles = ((rows_lane + bm - 1) // bm) * (n // bn)
+        rounds = -(-tiles // cus)
+        clk = max(bm * bn / 32.0, 2.0 * (bm + bn))               # MFMA clocks per SIMD vs bytes / 64 B per clock, per K-tile
+        return rounds * (k // 64) * clk / (clock_ghz * 1e3)
+    chain = {
+        "ln_mod_x2": 2 * kernel_avg_us.get("ln_mod", 5.0),       # measured (one round trip in, one write-through out: no pipe model)
+        "qkv": gemm(3072, 1024, 256, 128) + out_loop,
+        "attention": kernel_avg_us.get("attention", 22.0),       # measured: VALU (softmax) and MFMA about equally loaded, no K-loop model
+        "out_proj": gemm(1024, 1024) + out_loop,
+        "ff1": gemm(2048, 1024) + out_loop,
+        "ff2": gemm(1024, 2048) + out_loop,
+    }
+    ideal = sum(chain.values()) + 7 * boundary
+    alone = {k: kernel_avg_us.get(k) for k in ("ln_mod", "gemm_qkv_fused", "attention", "gemm_attn_out", "gemm_ff1_gelu", "gemm_ff2")}
+    have = all(v is not None for v in alone.values())
+    alone_sum = (2 * alone["ln_mod"] + sum(v for k, v in alone.items() if k != "ln_mod") + 7 * boundary) if have else None
+    return {"what": "per DiT block and CFG lane, dependent chain of 7 launches: sum of (ideal K loop at the measured pipe rates + measured prologue / "
+                    "epilogue / ramp + drain) + 7 launch boundaries; LayerNorm and attention at their measured stand-alone times",
+            "chain_ideal_us": round(ideal, 1), "chain_ideal_terms_us": {k: round(v, 2) for k, v in chain.items()},
+            "chain_of_measured_launches_us": round(alone_sum, 1) if alone_sum else None,
+            "block_measured_us": round(block_us_measured, 1),
+            "frac": round(ideal / block_us_measured, 3),
+            "inputs": {"outside_the_loop_us": fixed, "boundary_us": boundary, "boundary_source": "MI355X_MICROARCH.md price list, row 'boundary' (1.1-1.4 inside a GEMM chain)",
+                       "cus_per_lane": cus, "clock_ghz": clock_ghz, "tiles_m": tiles_m, "pipes_source": pipes.get("_source")},
+            "reading": "block_measured_us is both lanes' blocks overlapped on one chip (one block of each lane per block_measured_us); a lane alone on half "
+                       "the chip cannot finish its block faster than chain_ideal_us, and the MFMA roofline of the same block (FLOPs / peak) is "
+                       "several times lower than either"}
+
+
 # kernel classes of the profile pass -> the symbol rocprofv3 lists them under (out-proj and FF2 are ONE instantiation)
 SYMBOL = {"gemm_qkv_fused": "gemm_qkv_fused_kernel", "gemm_qk_rope": "gemm_bf16_kernel<EPI_QK_ROPE>", "gemm_v_t": "gemm_bf16_kernel<EPI_V_T>",
           "gemm_attn_out": "gemm_bf16_kernel<EPI_GATE_RES>", "gemm_ff2": "gemm_bf16_kernel<EPI_GATE_RES>",
@@ -417,6 +470,8 @@ def main():
     ap.add_argument("--attn-variant", type=int, default=-1, help="engine option attn_variant (-1 = engine default)")
     ap.add_argument("--no-phases", action="store_true", help="skip the serial hoists / step loop / vocoder / D2H timing after the timed region "
                     "(profiler passes: rocprofv3 --pmc aborts in that section on the batched workloads, DESIGN.md section 8)")
+    ap.add_argument("--bcast-bf16", type=int, default=-1, help="N > 1: the DiT blocks' GEMM weights travel in bf16 (0.98 instead of 1.35 GB over xGMI; the bf16 step "
+                    "loop's results are unchanged bit for bit).  -1 = on for the bf16 path, off for fp8 (its quantiser starts from the fp32 masters)")
     ap.add_argument("--xcd-runs", type=int, default=-1, help="engine measurement option xcd_runs (1 = round 3's GEMM tile order)")
     ap.add_argument("--graph", type=int, default=-1, help="engine option graph (-1 = engine default: one hipGraph launch per ODE step)")
     ap.add_argument("--vocoder-graph", type=int, default=-1, help="vocoder option graph (-1 = default: backbone + head replayed as one hipGraph)")
@@ -495,10 +550,12 @@ def main():
     bcast = None
     if use_dist:
         t_b = time.perf_counter()
-        sd = broadcast_state_dict(sd, arch, VOCAB, comm_device, dist, prosody=w["prosody"])
+        from lemas_tts_amd.parallel import broadcast_bytes
+        bf16_w = (not a.fp8 and a.ln_fold <= 0) if a.bcast_bf16 < 0 else bool(a.bcast_bf16)
+        sd = broadcast_state_dict(sd, arch, VOCAB, comm_device, dist, prosody=w["prosody"], block_weights_bf16=bf16_w)
         vsd = broadcast_state_dict(vsd, None, None, comm_device, dist, vocos=True)
-        nbytes = 4 * (sum(int(np.prod(v.shape)) for v in sd.values()) + sum(int(np.prod(v.shape)) for v in vsd.values()))
-        bcast = {"backend": backend, "bytes": nbytes, "seconds": time.perf_counter() - t_b,
+        nbytes = broadcast_bytes(arch, VOCAB, prosody=w["prosody"], block_weights_bf16=bf16_w) + broadcast_bytes(None, None, vocos=True)
+        bcast = {"backend": backend, "bytes": nbytes, "seconds": time.perf_counter() - t_b, "block_gemm_weights": "bf16" if bf16_w else "fp32",
                  "on_device": bool(comm_device.type == "cuda"), "world": world}
     model = CFM(arch, VOCAB, sd, device=device, use_prosody_encoder=w["prosody"])
     if a.attn_variant >= 0:
@@ -657,8 +714,9 @@ def main():
         if affinity is not None:
             result["config"]["cpu_affinity"] = affinity
 
-    # ---- roofline of the dominant kernel: short eager pass with per-launch HIP events (rank 0, N == 1 only)
-    if rank == 0 and world == 1:
+    # ---- roofline of the dominant kernel: short eager pass with per-launch HIP events (rank 0; for N > 1 the other ranks wait at the last
+    # barrier meanwhile -- every rank runs the same launches on its own GPU, so rank 0's kernel figures are the job's)
+    if rank == 0:
         eng = model.engine
         eng.set_option("profile", 1)
         sample(4)                                  # four Euler steps of the same batch, eager, every big launch stamped by its dispatch
@@ -695,15 +753,24 @@ def main():
                     continue
             return None, None
         wkey = a.workload + ("_fp8" if a.fp8 and a.workload != "configs4" else "")
-        traffic_e, traffic_src = committed(("r04_traffic.json", "r03_traffic.json", "r02_traffic.json"), wkey, dom)
+        traffic_e, traffic_src = committed(("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json"), wkey, dom)
         traffic = traffic_e.get("hbm_bytes_per_launch") if traffic_e else None
-        rocprof_e, rocprof_src = committed(("r04_kernel_avgs.json", "r03_kernel_avgs.json"), wkey, dom)
+        rocprof_e, rocprof_src = committed(("r05_kernel_avgs.json", "r04_kernel_avgs.json", "r03_kernel_avgs.json"), wkey, dom)
         rocprof_us = rocprof_e.get("avg_us") if rocprof_e else None
-        bounds_all, bounds_src = committed(("r04_kernel_bounds.json",), wkey)
+        bounds_all, bounds_src = committed(("r05_kernel_bounds.json", "r04_kernel_bounds.json"), wkey)
         is_gemm = dom != "attn_fwd_splitkv_kernel"
         peak = MFMA_FP8_PEAK_TFLOPS if (a.fp8 and is_gemm) else MFMA_BF16_PEAK_TFLOPS   # attention stays bf16
         dom_bound = (bounds_all or {}).get(dom)
-        result["roofline"] = {"bound": "mfma", "kernel": dom, "classes": d["classes"], "achieved": ach, "peak": peak,
+        # which roof the kernel is priced against follows from its arithmetic intensity (algorithmic flop per algorithmic byte of the launch)
+        # against the machine balance (2.5 PFLOP/s over 8 TB/s = 312 flop/B); what holds it BELOW that roof is the counters' verdict
+        dom_bytes = sum(class_bytes(k, rows, nsq / max(rows, 1.0)) * mm[k][1] for k in d["classes"]) / d["launches"]
+        intensity = fl / dom_bytes
+        roof = "mfma" if intensity > (peak * 1e12) / 8e12 else "hbm"
+        result["roofline"] = {"bound": roof, "bound_from": f"arithmetic intensity {intensity:.0f} flop/B (algorithmic) against the machine balance "
+                                                           f"{peak * 1e12 / 8e12:.0f} flop/B",
+                              "algorithmic_bytes_per_launch": dom_bytes,
+                              "limited_by_verdict": (dom_bound or {}).get("verdict"),
+                              "kernel": dom, "classes": d["classes"], "achieved": ach, "peak": peak,
                               "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src,
                               "avg_launch_us": avg_us, "avg_launch_us_source": "this run: eager pass, per-launch HIP event pairs, lanes serialised",
                               "avg_launch_us_rocprof": rocprof_us, "avg_launch_us_rocprof_source": rocprof_src,
@@ -714,15 +781,15 @@ def main():
                               # the MFMA peak is the roof the figure of merit is priced against (arithmetic intensity ~2 700
                               # flop/B); what the kernel is held up BY, from the counters, is `limited_by`
                               "limited_by": dom_bound, "limited_by_source": bounds_src}
-        if dom == "gemm_bf16_kernel<EPI_GATE_RES>" and not a.fp8 and a.workload in ("configs1", "short"):
+        pipes, pipes_src = committed(("r05_kloop_pipes.json", "r04g_kloop_pipes.json"))
+        if pipes and dom == "gemm_bf16_kernel<EPI_GATE_RES>" and not a.fp8 and a.workload in ("configs1", "short"):
             # the 128 x 128 tile's K loop taken apart with compile-time ablation builds (measurement only): three pipes that each need about
-            # the same time per K-tile, and a loop that overlaps them to 56 %
-            result["roofline"]["k_loop_pipes"] = {
-                "tile": "128 x 128 x 64, 8 waves, one workgroup per CU", "us_per_k_tile": {
-                    "mfma_alone_ideal": 0.24, "lds_fragment_reads_alone": 0.24, "l2_to_lds_64B_per_clk_ideal": 0.24, "barrier_and_waits_alone": 0.05,
-                    "mfma_plus_fragment_reads": 0.34, "mfma_plus_lds_dma": 0.41, "full_loop": 0.425},
-                "outside_the_loop_us": {"prologue": 1.6, "epilogue": 1.8, "launch_ramp_and_drain": 2.3},
-                "source": "profiles/r04g_kloop_ablations_128x128.txt (-DLEMAS_ABLATE builds, tools/r4/probe44.sh)"}
+            # the same time per K-tile, and a loop that overlaps them to 56 %.  Read from the committed JSON that tools/kloop_pipes_json.py
+            # derives from the raw profile lines -- no number is typed in here.
+            t17 = pipes["tiles"]["17"]
+            result["roofline"]["k_loop_pipes"] = {"tile": "128 x 128 x 64, 8 waves, one workgroup per CU",
+                                                  "us_per_k_tile": dict(t17["us_per_k_tile"], **{k + "_ideal": v for k, v in pipes["ideal_us_per_k_tile"].items() if k != "clock_ghz"}),
+                                                  "outside_the_loop_us": t17["outside_the_loop_us"], "source": pipes_src}
         if bounds_all:
             result["roofline_kernels"] = {k: v for k, v in bounds_all.items() if not k.startswith("_")}
         g_ms = sum(v["ms"] for s, v in by_sym.items() if s != "attn_fwd_splitkv_kernel")
@@ -734,7 +801,14 @@ def main():
         result["kernel_time_share"] = {k: round(v[0] / total_ms, 4) for k, v in prof.items() if v[1] > 0}
         result["kernel_avg_us"] = {k: round(1e3 * v[0] / v[1], 2) for k, v in prof.items() if v[1] > 0}
 
-        if a.no_phases:
+        def add_latency_roofline(step_loop_ms, clock_ghz):
+            # batch 1, two lanes, bf16: the block is a dependent chain per lane, priced against its latency floor next to the MFMA figure
+            if pipes and B == 1 and a.dual and not a.fp8 and a.depth > 0:
+                result["latency_roofline"] = latency_roofline(result["kernel_avg_us"], pipes, int(rows), 1e3 * step_loop_ms / nfe / a.depth, lanes, clock_ghz)
+                result["roofline"]["latency"] = result["latency_roofline"]      # (also inside `roofline`: the driver's record keeps that object whole)
+
+        if a.no_phases or world > 1:
+            add_latency_roofline(1e3 * elapsed / a.steps, 2.13)       # (the whole utterance stands in for the step loop: ~3 % more than it)
             if dist:
                 dist.barrier()
                 dist.destroy_process_group()
@@ -783,7 +857,8 @@ def main():
         L1 = e0 - s0                                                          # frames of the decode timed alone above
         nb1 = one_mel.shape[0]
         voc_bytes = nb1 * (400.0 * L1 + 1024.0 * (L1 - 1)) + wbytes           # weights + mel in + wav out
-        voc_traffic, voc_traffic_src = committed(("r04_traffic.json",), a.workload, "vocoder")
+        voc_traffic, voc_traffic_src = committed(("r05_traffic.json", "r04_traffic.json"), a.workload, "vocoder")
+        voc_hbm = voc_traffic.get("hbm_bytes_per_decode") if voc_traffic else None
         # the decode is fp32 GEMM work (exact fp32 MFMA, 157.3 TFLOP/s dense: MI355X_MICROARCH.md "Peak FP32 (matrix)"), not a byte stream:
         # every weight matrix is applied once per frame, plus the windowed inverse rDFT as a GEMM against its (n_fft + 2) x n_fft basis
         n_fft = int(np.shape(vsd_host["head.istft.window"])[0])
@@ -796,12 +871,21 @@ def main():
                                                            "the 25 GFLOP of exact-fp32 MFMA work 0.16 ms: the phase is bound by the fp32 matrix rate"},
                                       "algorithmic_bytes": voc_bytes, "decode_ms": dec_ms,
                                       "frames": L1, "batch": nb1, "decodes_per_step": len(segs) if w["vocode"] != "generated" else 1,
-                                      "traffic": voc_traffic.get("hbm_bytes_per_decode") if voc_traffic else None, "traffic_source": voc_traffic_src,
+                                      "traffic": voc_hbm, "traffic_source": voc_traffic_src,
+                                      # both roofs side by side: SURVEY.md 8d's byte pricing and the fp32 matrix rate that actually bounds exact-fp32 GEMMs
+                                      "frac_vs_hbm_roof": voc_bytes / (dec_ms * 1e-3) / 8e12, "frac_vs_fp32_mfma_roof": voc_flops / (dec_ms * 1e-3) / 157.3e12,
+                                      "traffic_over_algorithmic": (voc_hbm / voc_bytes) if voc_hbm else None,
+                                      "traffic_note": "the launches round-trip the [L, 512] / [L, 1536] fp32 activations between them: HBM-side traffic is this many "
+                                                      "times the algorithmic bytes (weights + mel in + waveform out)",
                                       "note": "a chain of 36 small exact-fp32 launches replayed as one hipGraph; the GEMMs run at 40-60 % of the fp32 MFMA rate, the rest is launch boundaries and the dwconv / LN / overlap-add launches"}
+        v_ = result["roofline_vocoder"]
+        result["roofline"]["vocoder"] = {k: v_[k] for k in ("frac_vs_hbm_roof", "frac_vs_fp32_mfma_roof", "traffic", "traffic_over_algorithmic", "algorithmic_bytes",
+                                                            "algorithmic_flops", "decode_ms", "frames", "traffic_source")}
         result["clock_power"] = None if a.no_clock_power else clock_power(step)
         if result["clock_power"]:
             # the MFMA peak the roofline prices against is the 2.4 GHz figure; what the package was clocked to deliver while this ran
             result["roofline"]["peak_at_measured_clock"] = result["roofline"]["peak"] * result["clock_power"]["sclk_mhz"] / 2400.0
+        add_latency_roofline(loop_ms, (result["clock_power"] or {}).get("sclk_mhz", 2130.0) / 1e3)
         if not a.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(sd_host, vsd_host, arch, w)
     if dist:

@@ -117,3 +117,21 @@ def test_bench_times_the_ragged_prosody_batch_and_the_speech_edit_case(wl):
     else:
         assert c["waveforms_per_step"] == 1 and c["vocode"] == "whole" and c["audio_seconds_per_step"] == pytest.approx(256 * 2813 / 24000)
         assert line["dtype"] == "fp8" and "NFE=48" in line["metric"]
+
+
+@pytest.mark.timeout(1500)
+def test_eight_ranks_share_the_one_gpu_weak_line_and_sharded_job():
+    """The 8-GPU run the driver launches, rehearsed end to end with EIGHT ranks on the one GPU over gloo (reduced depth): eight processes
+    each broadcasting / loading weights, capturing graphs and replaying 32 steps per utterance from one host at once, then the sharded job
+    with 7 peers' scatter and gather in flight together (parallel.scatter_from_rank0 / gather_to_rank0 are non-blocking).  Rank 0 also
+    reports the roofline of its kernels for N > 1."""
+    env = {"LEMAS_SHARE_GPU": "1", "LEMAS_DIST_BACKEND": "gloo"}
+    eight = _bench(["--gpus", "8", "--steps", "1", "--warmup", "1", "--depth", "2", "--no-cpu-baseline", "--workload", "configs3"], env=env)
+    assert eight["n_gpus"] == 8 and eight["scaling"] == "weak" and eight["value"] > 0
+    assert eight["config"]["utterances_total"] == 64 and len(eight["per_rank_ms"]["all"]) == 8
+    assert eight["weight_broadcast"]["world"] == 8 and eight["weight_broadcast"]["block_gemm_weights"] == "bf16"
+    assert "roofline" in eight and eight["roofline"]["frac"] > 0 and eight["roofline"]["bound"] in ("mfma", "hbm")
+    job = _bench(["--gpus", "8", "--steps", "1", "--warmup", "1", "--depth", "2", "--job", "configs3_full"], env=env)
+    c = job["config"]
+    assert job["n_gpus"] == 8 and c["utterances_total"] == 64 and c["utterances_per_rank"] == 8 and c["batches_per_rank"] == 1
+    assert c["utterance_alone_equals_in_batch"] is True and len(job["per_rank_ms"]["compute"]) == 8

@@ -87,7 +87,7 @@ def _job_worker(rank, world, port, q):
     from lemas_tts_amd.parallel import gather_to_rank0, scatter_from_rank0
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    U, F_, nt = 12, 7, 5
+    U, F_, nt = (12 if world < 8 else 64), 7, 5            # world 8: the real job's 64 utterances, 8 per rank, 7 peers in flight at once
     shards = shard_utterances([100] * U, world)
     per = len(shards[rank])
     packed = None
@@ -112,12 +112,51 @@ def _job_worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_job_scatter_and_gather_over_gloo(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_job_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(a and b for a, b in got), got
+
+
+def _bf16_bcast_worker(rank, world, port, q):
+    from lemas_tts_amd.parallel import block_gemm_weight, broadcast_bytes
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    arch, vocab = DiTArch(depth=2, conv_layers=1), 50
+    ref = synth.synth_cfm_state_dict(arch, vocab, 9)
+    sd = broadcast_state_dict(ref if rank == 0 else None, arch, vocab, "cpu", dist, block_weights_bf16=True)
+    ok_order = list(sd) == list(ref)
+    n_block = sum(block_gemm_weight(k) for k in ref)
+    ok = n_block == 2 * 6
+    for k, v in ref.items():
+        if block_gemm_weight(k):       # travelled in bf16: exactly the value the bf16 step loop would have rounded to anyway
+            ok &= bool(np.array_equal(sd[k], torch.from_numpy(v).to(torch.bfloat16).float().numpy()))
+        else:                          # everything the fp32 hoists read is untouched
+            ok &= bool(np.array_equal(sd[k], v))
+    full, half = broadcast_bytes(arch, vocab), broadcast_bytes(arch, vocab, block_weights_bf16=True)
+    ok &= full - half == 2 * sum(int(np.prod(v.shape)) for k, v in ref.items() if block_gemm_weight(k))
+    q.put((ok_order, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_block_gemm_weights_can_travel_in_bf16():
+    """broadcast_state_dict(block_weights_bf16=True): the DiT blocks' GEMM weights go out as a second, bf16 buffer (what the bf16 step loop
+    rounds them to anyway: its results cannot change), every other tensor -- AdaLN linears, embeddings, biases -- stays fp32 bit for bit."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bf16_bcast_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
     got = [q.get(timeout=240) for _ in procs]

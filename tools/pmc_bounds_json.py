@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Counter-backed bound per big launch: the PMC group passes of tools/r4/evidence.sh (rocprofv3 --pmc in separate passes over bench.py, summed
+"""Counter-backed bound per big launch: the PMC group passes of tools/gpu_session.sh pmc:<workload> (rocprofv3 --pmc in separate passes over bench.py, summed
 per dispatch by tools/rocpd_pmc.py) -> the JSON bench.py reads for `roofline.limited_by` / `roofline_kernels`.
 
     python tools/pmc_bounds_json.py configs1=profiles/r04_pmc_groups_configs1.txt [configs3=...] > profiles/r04_kernel_bounds.json
@@ -58,17 +58,57 @@ def get(e, name):
     return None
 
 
+HBM_ACHIEVABLE_TBS = 6.3      # MI355X_MICROARCH.md: float4 copy, 79 % of the 8 TB/s spec
+
+
 def classify(r):
-    if r.get("mfma_busy") and r["mfma_busy"] > 0.6:
-        return "mfma"
-    if r.get("wave_parked") and r["wave_parked"] > 0.35 and (r.get("mfma_busy") or 0) < 0.45:
-        return ("latency: the waves sit at s_waitcnt / s_barrier more than a third of their life (operand arrival and the per-K-tile hand-off), "
-                "the matrix pipe is busy under half of the time on the launch's own CUs, L2 and LDS are far from saturated")
-    return "issue: the waves are issuing or issue-stalled; neither the matrix pipe nor a memory level is saturated"
+    """(verdict, sentence) from THIS kernel's counters -- no text is shared between kernels.  verdict: "mfma" (matrix pipe busy > 0.6 on the
+    launch's own CUs), "hbm" (fabric bytes per launch at > 0.6 of the achievable HBM rate), "latency" (waves parked at s_waitcnt / s_barrier
+    > 0.35 of their life with no pipe saturated), "valu" (VALU active > 0.5), else "issue"."""
+    busy, parked, stalled, issuing = r.get("mfma_busy"), r.get("wave_parked"), r.get("wave_stalled"), r.get("wave_issuing")
+    valu, l2 = r.get("valu_active"), r.get("l2_hit")
+    mb = (r.get("fabric_read_mb") or 0.0) + (r.get("fabric_write_mb") or 0.0)
+    dur = r.get("avg_us_under_pmc")
+    mem_frac = (mb * 1e6 / (dur * 1e-6) / (HBM_ACHIEVABLE_TBS * 1e12)) if (mb and dur) else None
+    if mem_frac is not None:
+        r["fabric_frac_of_hbm"] = round(mem_frac, 3)
+    facts = []
+    chip = r.get("mfma_busy_chip")
+    has_mfma = busy is not None or (chip is not None and chip > 0)
+    if busy is not None:
+        facts.append(f"matrix pipe busy {busy:.2f} of the time on the launch's own CUs ({chip or 0:.2f} chip-wide)")
+    elif has_mfma:
+        facts.append(f"matrix pipe busy {chip:.2f} chip-wide")
+        busy = chip          # (a lower bound of the own-CU figure: the launch's workgroup count per CU is not tabulated for this symbol)
+    else:
+        facts.append("no MFMA work")
+    if parked is not None:
+        facts.append(f"waves parked at s_waitcnt / s_barrier {parked:.2f}, issue-stalled {stalled:.2f}, issuing {issuing:.2f}")
+    if valu is not None:
+        facts.append(f"VALU active {valu:.2f}")
+    if mem_frac is not None:
+        facts.append(f"{mb:.1f} MB of fabric traffic per launch = {mem_frac:.2f} of the achievable HBM rate" + (f", L2 hit {l2:.2f}" if l2 is not None else ""))
+    if r.get("lds_conflict") is not None:
+        facts.append(f"LDS conflict share {r['lds_conflict']:.2f}")
+    if busy is not None and busy > 0.6:
+        v = "mfma"
+    elif mem_frac is not None and mem_frac > 0.6:
+        v = "hbm"
+    elif parked is not None and parked > 0.35:
+        v = "latency"
+    elif valu is not None and valu > 0.5:
+        v = "valu"
+    else:
+        v = "issue"
+    why = {"mfma": "the matrix pipe is the busiest resource", "hbm": "the launch moves its bytes at the memory system's rate",
+           "latency": ("no pipe is saturated: the waves wait -- " + ("for operand arrival and the per-K-tile hand-off" if has_mfma
+                       else "for one memory round trip in and one write-through round trip out, with too few bytes in flight per CU to cover it")),
+           "valu": "the vector ALU is the busiest resource", "issue": "the waves are issuing or issue-stalled; no pipe and no memory level is saturated"}[v]
+    return v, f"{v}: {why} ({'; '.join(facts)})"
 
 
 def main(args):
-    out = {"_source": "rocprofv3 --pmc group passes over bench.py (tools/r4/evidence.sh), per-launch averages: " + ", ".join(a.split("=")[1] for a in args)}
+    out = {"_source": "rocprofv3 --pmc group passes over bench.py (tools/gpu_session.sh pmc:<workload>), per-launch averages: " + ", ".join(a.split("=")[1] for a in args)}
     for a in args:
         wl, path = a.split("=")
         res = {}
@@ -108,7 +148,7 @@ def main(args):
             c, ia = get(e, "SQ_LDS_BANK_CONFLICT"), get(e, "SQ_LDS_IDX_ACTIVE")
             if c is not None and ia:
                 r["lds_conflict"] = round(c / ia, 4)
-            r["bound"] = classify(r)
+            r["verdict"], r["bound"] = classify(r)
             res[sym] = r
         out[wl] = res
     print(json.dumps(out, indent=1))
