@@ -257,6 +257,10 @@ hipError_t launch_gemm_bf16_tile(int epi, const GemmParams& p, int tile, hipStre
 hipError_t gemm_bf16_init();
 // `groups` independent EPI_BIAS_F32 GEMMs (parameter blocks in DEVICE memory, 128 x 128 tiles, at most max_tiles tiles each) as one launch
 hipError_t launch_gemm_bf16_group(const GemmParams* dev_params, int groups, int max_tiles, hipStream_t s);
+// measurement builds only (engine option "block_persist"): out-projection -> ff_norm -> FF1 -> FF2 of one lane as ONE persistent launch with
+// grid barriers between the stages; sync = 16 zeroed words, err = the engine's sticky error word; *grid_out = workgroups of the launch
+hipError_t launch_gemm_chain_ffhalf(const GemmParams& out, const GemmParams& ff1, const GemmParams& ff2, int ln_scale_off, int ln_shift_off,
+                                    unsigned int* sync, unsigned int* err, int prefetch, int* grid_out, hipStream_t s);
 // one launch for a lane's QK (+RoPE) and V^T projections (same A, different W / bias / epilogue)
 hipError_t launch_gemm_qkv_fused(const GemmParams& pq, const GemmParams& pv, hipStream_t s);
 // EPI_GATE_RES with the LayerNorm-modulate tail (GemmParams::ln_out): number of workgroups the launch would have if the production

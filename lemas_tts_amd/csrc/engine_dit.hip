@@ -90,6 +90,9 @@ struct lemas_dit {
   // instead of in lock-step, so unlike kernels share the chip)
   int lane_skew = 0;
   hipEvent_t ev_skew[8] = {};
+  // measurement option (measurement builds only): the FF half of every block -- out-projection, ff_norm, FF1, FF2 -- as ONE persistent launch per
+  // lane with grid barriers between the stages (gemm_bf16.hip gemm_chain_ffhalf_kernel); 2 = with the next stage's weights prefetched across the barrier
+  int block_persist = 0;
   // the AdaLN LayerNorms behind the gated residual updates as the tail of those GEMM launches (gemm_bf16.hip ln_tail).  OFF: measured on
   // configs[1] it is 1.5x SLOWER end to end (88.9 -> 59.8 audio-s/s, profiles/r03_ln_tail_experiment.txt): with two lanes sharing the chip a
   // panel's column tiles do not run at the same time, so finished workgroups sit on their CUs waiting for panel-mates that have not started
@@ -777,6 +780,15 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     HIP_TRY(hipMemsetAsync(lncnt, 0, nb, s));      // ahead of the fork: both lanes start from zeroed counters (a memset node in the graph)
   }
   auto ln_site = [&](int l, int site, int ln) { return lncnt + ((size_t)(l * 2 + site) * lanes + ln) * ln_panels; };
+  // block_persist: 16 barrier words per (block, lane), zeroed by a memset node ahead of the fork (the LayerNorm tails' counter buffer)
+  const bool persist = block_persist != 0 && !fp8 && !fold && !fuse_ln && !has_len && s != nullptr && cfg.dim == 1024;
+  unsigned int* psync = nullptr;
+  if (persist) {
+    const size_t nb = (size_t)cfg.depth * lanes * 16 * sizeof(unsigned int);
+    if (nb > d_lncnt.bytes) { set_error("lemas_dit: barrier words were not sized by prepare()"); return LEMAS_E_STATE; }
+    psync = d_lncnt.as<unsigned int>();
+    HIP_TRY(hipMemsetAsync(psync, 0, nb, s));
+  }
   if (fork) {
     HIP_TRY(hipEventRecord(ev_fork, s));
     HIP_TRY(hipStreamWaitEvent(s2, ev_fork, 0));
@@ -931,11 +943,13 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     if (fold) { g.xs_out = hbf; g.xs_scale_off = base + 4 * d; g.ln_part_out = lnpart; g.ln_np = d / 32; }     // ff_norm's scale (modules.py:637)
     TL_SLOT(g);
     RC_TRY(skew_pre(ln, q));
-    HIP_TRY(launch_gemm_bf16(EPI_GATE_RES, g, q));
+    GemmParams g_out = g;
+    if (persist) { g_out.tile = 0; g_out.ev_start = g_out.ev_stop = nullptr; }
+    else HIP_TRY(launch_gemm_bf16(EPI_GATE_RES, g, q));
     RC_TRY(skew_post(ln, q));
     g.ln_out = nullptr; g.xs_out = nullptr;
     g.live_len = live;        // FF half
-    if (!fuse_ln && !fold) {
+    if (!fuse_ln && !fold && !persist) {
       RC_TRY(pbegin(PC_LN, q));
       if (f8_ff1) HIP_TRY(launch_ln_mod_f8(xres, h8, hmx, rows, d, tab, tab_stride, base + 4 * d, base + 3 * d, step, q));
       else HIP_TRY(launch_ln_mod(xres, hbf, rows, d, tab, tab_stride, base + 4 * d, base + 3 * d, step, q, live, pitch, B));
@@ -948,7 +962,8 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     if (fold) { g.ln_part = lnpart; g.lnc1_off = fo + 6 * in; g.lnc2_off = fo + 6 * in + ffd; }
     TL_SLOT(g);
     RC_TRY(skew_pre(ln, q));
-    HIP_TRY(launch_gemm_bf16(f8_ff2 ? EPI_BIAS_GELU_F8 : EPI_BIAS_GELU_BF16, g, q));       // FF1 writes what FF2 reads
+    GemmParams g_ff1 = g;
+    if (!persist) HIP_TRY(launch_gemm_bf16(f8_ff2 ? EPI_BIAS_GELU_F8 : EPI_BIAS_GELU_BF16, g, q));       // FF1 writes what FF2 reads
     RC_TRY(skew_post(ln, q));
     g.ln_part = nullptr;
     RC_TRY(pkernel(PC_GEMM_FF2, &g.ev_start, &g.ev_stop));
@@ -965,7 +980,18 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     if (fold && l + 1 < cfg.depth) { g.xs_out = hbf; g.xs_scale_off = (l + 1) * 6 * d + d; g.ln_part_out = lnpart; g.ln_np = d / 32; }
     TL_SLOT(g);
     RC_TRY(skew_pre(ln, q));
-    HIP_TRY(launch_gemm_bf16(EPI_GATE_RES, g, q));
+    if (persist) {      // out-projection -> ff_norm -> FF1 -> FF2 as one persistent launch (measurement build)
+      GemmParams g_ff2 = g;
+      g_ff1.ev_start = g_ff1.ev_stop = g_ff2.ev_start = g_ff2.ev_stop = nullptr;
+      g_ff1.tile = g_ff2.tile = 0;
+      // every workgroup of the launch waits for the others: both lanes' launches must fit the chip at one workgroup (96 KB of LDS) per CU
+      const int wgs = xcd_grid((rows + 127) / 128, d / 128, opt_xcd_gx ? opt_xcd_gx : pick_xcd_gx(rows, d));
+      if ((long)lanes * wgs > (long)n_cus) { set_error("lemas_dit: block_persist needs %d x %d workgroups co-resident on %d CUs", lanes, wgs, n_cus); return LEMAS_E_STATE; }
+      HIP_TRY(launch_gemm_chain_ffhalf(g_out, g_ff1, g_ff2, base + 4 * d, base + 3 * d, psync + ((size_t)l * lanes + ln) * 16, ln_err_dev,
+                                       block_persist == 2 ? 1 : 0, nullptr, q));
+    } else {
+      HIP_TRY(launch_gemm_bf16(EPI_GATE_RES, g, q));
+    }
     RC_TRY(skew_post(ln, q));
     g.ln_out = nullptr; g.xs_out = nullptr;
     return 0;
@@ -1195,8 +1221,16 @@ int lemas_dit_set_option(lemas_dit* m, const char* key, int64_t value) {
     m->drop_graphs();
     return 0;
   }
+#ifdef LEMAS_MEASUREMENT_BUILD
+  if (!strcmp(key, "block_persist")) {
+    if (value < 0 || value > 2) { set_error("lemas_dit_set_option: block_persist is 0, 1 or 2 (with the weight prefetch across the barrier)"); return LEMAS_E_ARG; }
+    m->block_persist = (int)value;
+    m->drop_graphs();
+    return 0;
+  }
+#endif
 #ifndef LEMAS_MEASUREMENT_BUILD
-  if (!strcmp(key, "ln_fused") || !strcmp(key, "lane_skew") || !strcmp(key, "xcd_runs")) {
+  if (!strcmp(key, "ln_fused") || !strcmp(key, "lane_skew") || !strcmp(key, "xcd_runs") || !strcmp(key, "block_persist")) {
     if (value == 0) return 0;       // "off" is what the product does anyway
     set_error("lemas_dit_set_option: '%s' is a measurement option -- its code exists only in builds of the library with -DLEMAS_MEASUREMENT_BUILD "
               "(LEMAS_EXTRA_HIPCC_FLAGS, lemas_tts_amd/build.py); the product library does not carry it", key);

@@ -239,3 +239,22 @@ def test_ln_fold_option_meets_the_reference_goldens(golden_dir, name):
     assert mse <= MSE_TOL, mse
     for k, v in outs.items():
         np.testing.assert_array_equal(v, out, err_msg=str(k))
+
+
+@needs_measurement_build
+@pytest.mark.parametrize("name", ["mini_plain", "full_plain"])
+def test_persistent_ff_half_is_bit_identical_to_separate_launches(golden_dir, name):
+    """Measurement option block_persist: out-projection -> ff_norm -> FF1 -> FF2 of a lane as ONE persistent launch with grid barriers between
+    the stages (gemm_bf16.hip gemm_chain_ffhalf_kernel).  The stages are the bodies of the separate launches: not a bit may change, eager or replayed."""
+    fx, arch, sd = _load(golden_dir, name)
+    m = _model(arch, int(fx["vocab"]), int(fx["wseed"]), bool(fx["prosody"]), sd)
+    outs = {}
+    for persist in (0, 1, 2):
+        m.engine.set_option("block_persist", persist)
+        for graph in (False, True):
+            outs[(persist, graph)] = _run_case(fx, arch, sd, graph=graph, traj=False)[0]
+    m.engine.set_option("block_persist", 0)
+    m.engine.check_health()
+    ref = outs[(0, False)]
+    for k, v in outs.items():
+        np.testing.assert_array_equal(v, ref, err_msg=str(k))

@@ -58,6 +58,7 @@ def main():
         m.engine.set_option("ln_fused", int(opts.get("ln_fused", 0)))
         m.engine.set_option("ln_fold", int(opts.get("ln_fold", 0)))
         m.engine.set_option("lane_skew", int(opts.get("skew", 0)))
+        m.engine.set_option("block_persist", int(opts.get("persist", 0)))   # measurement builds: the FF half of a block as one persistent launch
         m.engine.set_option("attn_variant", int(opts.get("attn", DEFAULT_ATTN)))
         m.engine.set_option("fp8", int(opts.get("fp8", 0)))
         m.engine.set_option("qkv_fused", int(opts.get("qkv_fused", 1)))
