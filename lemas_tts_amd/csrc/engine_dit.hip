@@ -111,6 +111,20 @@ struct lemas_dit {
   unsigned int* ln_err_dev = nullptr;
   hipStream_t s2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // option "lane_split" (k = 1, 2, 4; default: see lanes_for()): each CFG branch is cut into k groups of B / k samples, every group an independent
+  // chain of launches on its own stream / graph branch -- 2 k lanes.  Batched shapes only (k divides B): more, smaller launches in flight fill the
+  // CUs a lone multi-round launch leaves idle in its last round and at its boundaries.  Results do not depend on k (rows are independent).
+  int lane_split = 0;                       // 0 = automatic
+  static constexpr int MAX_LANES = 8;
+  hipStream_t sx[MAX_LANES - 2] = {};       // lanes 2 .. 7 (lane 0 runs on the caller's stream, lane 1 on s2)
+  hipEvent_t ev_joinx[MAX_LANES - 2] = {};
+  int lanes_for(hipStream_t s) const {
+    if (!(dual && use_cfg && s != nullptr)) return 1;
+    int k = lane_split;
+    if (k <= 0) k = 1;                      // automatic: one lane per CFG branch (what every workload measured best with so far)
+    while (k > 1 && (B % k != 0 || 2 * k > MAX_LANES)) k >>= 1;
+    return 2 * k;
+  }
 
   std::vector<BlockW> blocks;
   DevBuf wproj_out, bproj_out;  // padded to 128 rows
@@ -190,6 +204,8 @@ struct lemas_dit {
     (void)hipDeviceSynchronize();   // nothing of this engine may still be running when its graphs and buffers go
     drop_graphs();
     if (s2) (void)hipStreamDestroy(s2);
+    for (auto& q : sx) if (q) (void)hipStreamDestroy(q);
+    for (auto& e : ev_joinx) if (e) (void)hipEventDestroy(e);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
     for (auto& e : ev_skew) if (e) (void)hipEventDestroy(e);
@@ -752,13 +768,23 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
   // From here on the two CFG branches (conditional rows, unconditional rows) are independent chains.  With "dual" on
   // they run as two concurrent lanes (second HIP stream / parallel hipGraph branch): each GEMM then has one round of
   // ~120 tiles, and one lane's epilogue / prologue / launch gap overlaps the other lane's K loop.
-  const int lanes = (dual && use_cfg && s != nullptr) ? 2 : 1;
+  const int lanes = lanes_for(s);
   // profile mode keeps the per-lane launch shapes but runs the lanes back to back on one stream, so the HIP events
   // around a launch time that kernel alone (two concurrent streams would add the other lane's queueing to it)
-  const bool fork = lanes == 2 && !profile;
-  hipStream_t st[2] = {s, fork ? s2 : s};
+  const bool fork = lanes >= 2 && !profile;
+  hipStream_t st[MAX_LANES];
+  for (int ln = 0; ln < lanes; ++ln) {
+    if (fork && ln >= 2 && !sx[ln - 2]) {
+      HIP_TRY(hipStreamCreateWithFlags(&sx[ln - 2], hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&ev_joinx[ln - 2], hipEventDisableTiming));
+    }
+    st[ln] = !fork || ln == 0 ? s : ln == 1 ? s2 : sx[ln - 2];
+  }
   const int bh = BB / lanes;                 // samples (branch-rows) per lane
   const int rows = bh * pitch;
+  // per-sample length arrays ([B], shared by the two CFG branches) as a lane sees them: lane ln holds samples (ln % k) * bh .. of its branch
+  const int len_batch = lanes == 1 ? B : bh;
+  auto len_off = [&](int ln) { return lanes == 1 ? 0 : (ln % (lanes / 2)) * bh; };
   // LayerNorm tails inside the gate + residual GEMM launches: only when every workgroup of such a launch -- of BOTH lanes, which
   // run the same kind of launch at about the same time -- is resident at once (a tail waits for the other column tiles of its
   // row panel).  configs[1]: 2 x 120 workgroups of 96 KB LDS on 256 CUs.  Batched shapes keep the separate ln_mod launches.
@@ -791,7 +817,7 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
   }
   if (fork) {
     HIP_TRY(hipEventRecord(ev_fork, s));
-    HIP_TRY(hipStreamWaitEvent(s2, ev_fork, 0));
+    for (int ln = 1; ln < lanes; ++ln) HIP_TRY(hipStreamWaitEvent(st[ln], ev_fork, 0));
   }
 
   auto convpos = [&](int ln) -> int {        // conv position embedding + residual (dit.py:98)
@@ -811,7 +837,7 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     return 0;
   };
 
-  const bool skew = fork && lane_skew != 0;
+  const bool skew = fork && lane_skew != 0 && lanes == 2;
   if (skew)
     for (auto& e : ev_skew)
       if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -839,16 +865,20 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     bf16_t* abf = d_abf.as<bf16_t>() + r0 * in;
     bf16_t* ffb = d_ff.as<bf16_t>() + r0 * ffd;
     GemmParams g{};
-    g.M = rows; g.tab = tab; g.tab_stride = tab_stride; g.step_idx = step; g.seq_pitch = pitch; g.seq_valid = N; g.batch = B;
-    g.live_len = live_a;      // attention half; the FF half switches to `live` below
+    g.M = rows; g.tab = tab; g.tab_stride = tab_stride; g.step_idx = step; g.seq_pitch = pitch; g.seq_valid = N; g.batch = len_batch;
+    const int lo = len_off(ln);
+    const int* live_a_l = live_a ? live_a + lo : nullptr;
+    const int* live_l = live ? live + lo : nullptr;
+    const int* len_l = has_len ? d_len.as<int>() + lo : nullptr;
+    g.live_len = live_a_l;      // attention half; the FF half switches to `live_l` below
     g.heads = cfg.heads; g.npad = npad; g.rope_cos = d_rope_cos.as<float>(); g.rope_sin = d_rope_sin.as<float>();
     // attention variants with bit 16 take q already multiplied by softmax_scale * log2(e): the QK epilogue does it before rounding
     g.q_scale = (attn_variant & 16) ? (1.0f / sqrtf((float)cfg.dim_head)) * 1.4426950408889634f : 0.f;
     g.q = d_q.as<bf16_t>() + r0 * in; g.k = d_k.as<bf16_t>() + r0 * in; g.vt = d_vt.as<bf16_t>() + r0 * in;
     AttnParams at{};
     at.q = g.q; at.k = g.k; at.vt = g.vt; at.out = abf;
-    at.kv_len = has_len ? d_len.as<int>() : nullptr; at.b2 = bh; at.batch = B; at.heads = cfg.heads; at.n = N; at.npad = npad; at.pitch = pitch;
-    at.scale = 1.0f / sqrtf((float)cfg.dim_head); at.variant = attn_variant; at.live_len = live_a;
+    at.kv_len = len_l; at.b2 = bh; at.batch = len_batch; at.heads = cfg.heads; at.n = N; at.npad = npad; at.pitch = pitch;
+    at.scale = 1.0f / sqrtf((float)cfg.dim_head); at.variant = attn_variant; at.live_len = live_a_l;
     const BlockW& w = blocks[l];
     const int base = l * 6 * d;  // [shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp] (modules.py:312)
     uint8_t* h8 = fp8 ? d_h8.as<uint8_t>() + r0 * d : nullptr;
@@ -887,13 +917,13 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     } else if (!(fuse_ln && l > 0)) {      // fused: block l's attn_norm rows were written by block l-1's FF2 launch
       RC_TRY(pbegin(PC_LN, q));
       if (f8_qkv) HIP_TRY(launch_ln_mod_f8(xres, h8, hmx, rows, d, tab, tab_stride, base + d, base, step, q));
-      else HIP_TRY(launch_ln_mod(xres, hbf, rows, d, tab, tab_stride, base + d, base, step, q, live_a, pitch, B));
+      else HIP_TRY(launch_ln_mod(xres, hbf, rows, d, tab, tab_stride, base + d, base, step, q, live_a_l, pitch, len_batch));
       RC_TRY(pend(q));
     }
     // one launch for QK and V only while all of its workgroups fit the chip in one round (128 + 64 at configs[1]); beyond that two
     // separately tiled launches pack better (measured: -5 % at N = 2814 and at batch 8 when fused regardless)
     const long qkv_wgs = (long)((rows + 255) / 256) * (3 * in / 128);
-    const bool fuse_qkv = qkv_fused && lanes == 2 && qkv_wgs <= 250;
+    const bool fuse_qkv = qkv_fused && lanes >= 2 && qkv_wgs <= 250;
     if (fuse_qkv) {
       GemmParams gq = g, gv = g;
       RC_TRY(pkernel(PC_GEMM_QKV, &gq.ev_start, &gq.ev_stop));
@@ -936,7 +966,7 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     RC_TRY(pkernel(PC_GEMM_OUT, &g.ev_start, &g.ev_stop));
     operands(f8_out, abf, a8, amx, w.wo, w.wo8, w.so, w.woq, 0, in);
     g.bias = w.bo; g.N = d; g.K = in; g.n_valid = d;
-    g.out_f32 = xres; g.ldc = d; g.gate_off = base + 2 * d; g.kv_len = has_len ? d_len.as<int>() : nullptr; g.tile = tile_for(g.N);
+    g.out_f32 = xres; g.ldc = d; g.gate_off = base + 2 * d; g.kv_len = len_l; g.tile = tile_for(g.N);
     if (fuse_ln) {   // ff_norm (modules.py:637) as the tail of the out-projection launch
       g.ln_out = hbf; g.ln_scale_off = base + 4 * d; g.ln_shift_off = base + 3 * d; g.ln_cnt = ln_site(l, 0, ln); g.ln_err = ln_err_dev;
     }
@@ -948,11 +978,11 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     else HIP_TRY(launch_gemm_bf16(EPI_GATE_RES, g, q));
     RC_TRY(skew_post(ln, q));
     g.ln_out = nullptr; g.xs_out = nullptr;
-    g.live_len = live;        // FF half
+    g.live_len = live_l;        // FF half
     if (!fuse_ln && !fold && !persist) {
       RC_TRY(pbegin(PC_LN, q));
       if (f8_ff1) HIP_TRY(launch_ln_mod_f8(xres, h8, hmx, rows, d, tab, tab_stride, base + 4 * d, base + 3 * d, step, q));
-      else HIP_TRY(launch_ln_mod(xres, hbf, rows, d, tab, tab_stride, base + 4 * d, base + 3 * d, step, q, live, pitch, B));
+      else HIP_TRY(launch_ln_mod(xres, hbf, rows, d, tab, tab_stride, base + 4 * d, base + 3 * d, step, q, live_l, pitch, len_batch));
       RC_TRY(pend(q));
     }
     RC_TRY(pkernel(PC_GEMM_FF1, &g.ev_start, &g.ev_stop));
@@ -1021,8 +1051,11 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     for (int ln = 0; ln < lanes; ++ln) RC_TRY(block(l, ln));
   for (int ln = 0; ln < lanes; ++ln) RC_TRY(head(ln));
   if (fork) {
-    HIP_TRY(hipEventRecord(ev_join, s2));
-    HIP_TRY(hipStreamWaitEvent(s, ev_join, 0));
+    for (int ln = 1; ln < lanes; ++ln) {
+      hipEvent_t e = ln == 1 ? ev_join : ev_joinx[ln - 2];
+      HIP_TRY(hipEventRecord(e, st[ln]));
+      HIP_TRY(hipStreamWaitEvent(s, e, 0));
+    }
   }
   return 0;
 }
@@ -1061,7 +1094,7 @@ int lemas_dit::step_graph(hipStream_t s, hipGraphExec_t* exec, hipEvent_t* done)
     graph_generation = moved;
   }
   char key[112];
-  snprintf(key, sizeof key, "B%d_P%d_cfg%d_len%d_dual%d_f8%d_ln%d_av%d", B, pitch, (int)use_cfg, (int)has_len, (int)dual, fp8 ? 16 + fp8_sites() : fp8_wonly ? 2 : 0,
+  snprintf(key, sizeof key, "B%d_P%d_cfg%d_len%d_dual%d_f8%d_ln%d_av%d", B, pitch, (int)use_cfg, (int)has_len, dual ? lanes_for(s) : 0, fp8 ? 16 + fp8_sites() : fp8_wonly ? 2 : 0,
            (int)ln_fused + 2 * (int)fold_on(), attn_variant);
   auto it = graphs.find(key);
   if (it == graphs.end()) {
@@ -1214,6 +1247,12 @@ int lemas_dit_set_option(lemas_dit* m, const char* key, int64_t value) {
       m->skip_dead = (int)value;
       m->drop_graphs();
     }
+    return 0;
+  }
+  if (!strcmp(key, "lane_split")) {
+    if (value != 0 && value != 1 && value != 2 && value != 4) { set_error("lemas_dit_set_option: lane_split is 0 (automatic), 1, 2 or 4 sample groups per CFG branch"); return LEMAS_E_ARG; }
+    m->lane_split = (int)value;
+    m->drop_graphs();
     return 0;
   }
   if (!strcmp(key, "qkv_fused")) {

@@ -258,3 +258,21 @@ def test_persistent_ff_half_is_bit_identical_to_separate_launches(golden_dir, na
     ref = outs[(0, False)]
     for k, v in outs.items():
         np.testing.assert_array_equal(v, ref, err_msg=str(k))
+
+
+@pytest.mark.parametrize("name", ["mini_batch", "mini_prosody", "mini_duplicate"])
+def test_lane_split_is_bit_identical(golden_dir, name):
+    """Option lane_split: each CFG branch of a batch cut into k groups of samples, every group its own chain of launches on its own stream /
+    graph branch (2 k lanes).  Rows are independent and the per-sample lengths travel with their group: not a bit may change, ragged batch
+    (mini_batch: lens 50 / 70, durations 120 / 150) included, eager or replayed."""
+    fx, arch, sd = _load(golden_dir, name)
+    m = _model(arch, int(fx["vocab"]), int(fx["wseed"]), bool(fx["prosody"]), sd)
+    outs = {}
+    for split in (1, 2):
+        m.engine.set_option("lane_split", split)
+        for graph in (False, True):
+            outs[(split, graph)] = _run_case(fx, arch, sd, graph=graph, traj=False)[0]
+    m.engine.set_option("lane_split", 0)
+    ref = outs[(1, False)]
+    for k, v in outs.items():
+        np.testing.assert_array_equal(v, ref, err_msg=str(k))

@@ -57,6 +57,7 @@ def main():
         m.engine.set_option("xcd_runs", int(opts.get("runs", 0)))       # 1 = round 3's tile order (equal runs per XCD instead of one block per XCD)
         m.engine.set_option("ln_fused", int(opts.get("ln_fused", 0)))
         m.engine.set_option("ln_fold", int(opts.get("ln_fold", 0)))
+        m.engine.set_option("lane_split", int(opts.get("split", 0)))       # sample groups per CFG branch (2 x split lanes); 0 = automatic
         m.engine.set_option("lane_skew", int(opts.get("skew", 0)))
         m.engine.set_option("block_persist", int(opts.get("persist", 0)))   # measurement builds: the FF half of a block as one persistent launch
         m.engine.set_option("attn_variant", int(opts.get("attn", DEFAULT_ATTN)))
