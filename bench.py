@@ -44,7 +44,7 @@ The JSON line also carries
   roofline     -- the dominant kernel BY SYMBOL (what rocprofv3 --stats lists; out-proj and FF2 share one instantiation):
                   algorithmic FLOPs per launch / average launch duration, measured live with HIP event pairs stamped by the
                   dispatch itself (hipExtLaunchKernelGGL) in a short eager pass with the timed region's launch shapes, vs
-                  2.5 PFLOP/s dense bf16, plus what the committed PMC passes say the kernel is bound BY (profiles/r04_kernel_bounds.json:
+                  2.5 PFLOP/s dense bf16, plus what the committed PMC passes say the kernel is bound BY (profiles/r04/r04_kernel_bounds.json:
                   matrix-pipe busy share, waves parked / stalled, L2 hit rate, fabric bytes); ``roofline_kernels`` = the same for every
                   big launch; ``roofline_gemm_family`` = all block GEMMs together, ``path_frac`` = whole path;
   roofline_vocoder -- the vocoder phase: algorithmic fp32 FLOPs of one decode over its measured duration vs the 157.3 TFLOP/s exact-fp32
@@ -133,7 +133,7 @@ def latency_roofline(kernel_avg_us: dict, pipes: dict, rows_lane: int, block_us_
     """The LATENCY roofline of one CFG lane's block at batch 1: the block is a dependent chain of seven launches (LN, QK+V, attention, out-proj,
     LN, FF1, FF2), so its floor is not FLOPs / peak but   sum over the launches of (ideal K loop + what a launch costs outside its loop) +
     boundaries.  Inputs: per K-tile pipe times and the prologue / epilogue / ramp + drain of the 128 x 128 tile from the committed ablation
-    builds (`pipes`, profiles/r04g_kloop_pipes.json), the launch boundary from MI355X_MICROARCH.md's price list ("boundary": 1.1-1.4 us inside a
+    builds (`pipes`, profiles/r04/r04g_kloop_pipes.json), the launch boundary from MI355X_MICROARCH.md's price list ("boundary": 1.1-1.4 us inside a
     GEMM chain), and this run's own per-launch averages (eager pass) for the launches the model has no pipe figures for (LayerNorm, attention).
     An "ideal K loop" runs at the slower of its two equally loaded pipes -- 512 MFMA clocks per SIMD and 32 KB through the CU's 64 B/clk
     vector-memory path per 128 x 128 x 64 K-tile -- i.e. with the fragment reads and the LDS-DMA requests perfectly hidden."""
@@ -297,7 +297,7 @@ def cpu_baseline(sd, vsd, arch, w):
 def clock_power(step_fn, seconds: float = 4.0):
     """Engine clock and package power WHILE the timed loop's work runs (an untimed repeat of it), read from ``rocm-smi`` in a second
     process: the board manages the clock against a 1400 W package limit, and the solve runs ~9 % under the 2.4 GHz the MFMA peak is
-    quoted at (profiles/r03_power_clocks.txt).  None when rocm-smi is missing or prints something else."""
+    quoted at (profiles/r03/r03_power_clocks.txt).  None when rocm-smi is missing or prints something else."""
     import re
     import shutil
     import subprocess
@@ -480,6 +480,10 @@ def main():
                     "utterance i+1 (default), 0 = strictly serial")
     ap.add_argument("--ln-fused", type=int, default=-1, help="engine option ln_fused (-1 = engine default)")
     ap.add_argument("--ln-fold", type=int, default=-1, help="engine option ln_fold (-1 = engine default)")
+    ap.add_argument("--outlier-weights", type=int, default=0, help="1 = synthetic weights WITH outlier residual channels (1 %% of the channels x30 in every block's "
+                    "residual-writing projections, synth.synth_cfm_state_dict(outlier=(0.01, 30))): what the fp8 path's outlier decomposition costs / buys; "
+                    "the reference fixture does not apply to these weights (no parity check in the line)")
+    ap.add_argument("--fp8-outlier-mode", type=int, default=-1, help="engine option fp8_outlier_mode (-1 = default 1: mixed-precision decomposition; 0 = bf16)")
     ap.add_argument("--skip-dead", type=int, default=-1, help="engine option skip_dead (-1 = engine default 0: every sample of a ragged batch runs at "
                     "the batch's pitch, as in the reference; 1 = the 128-row blocks that lie wholly in a sample's padding are left uncomputed: "
                     "+12.6 %% on configs2, the last ~30 frames of a sample then differ from the reference's by 5e-6 instead of 2e-6 mel-MSE)")
@@ -544,7 +548,7 @@ def main():
         a.fp8 = w["fp8"]
     arch = DiTArch(depth=a.depth)
     # weights: generated on rank 0, broadcast over RCCL/xGMI; every rank loads them device-to-device from the received buffer
-    sd = synth.synth_cfm_state_dict(arch, VOCAB, w["wseed"], prosody=w["prosody"]) if rank == 0 else None
+    sd = synth.synth_cfm_state_dict(arch, VOCAB, w["wseed"], prosody=w["prosody"], outlier=(0.01, 30.0) if a.outlier_weights else None) if rank == 0 else None
     vsd = synth.synth_vocos_state_dict(1234) if rank == 0 else None
     sd_host, vsd_host = sd, vsd
     bcast = None
@@ -570,6 +574,8 @@ def main():
         model.engine.set_option("ln_fused", a.ln_fused)
     if a.ln_fold >= 0:
         model.engine.set_option("ln_fold", a.ln_fold)
+    if a.fp8_outlier_mode >= 0:
+        model.engine.set_option("fp8_outlier_mode", a.fp8_outlier_mode)
     if a.skip_dead >= 0:
         model.engine.set_option("skip_dead", a.skip_dead)
     if a.skip_masked >= 0:
@@ -658,7 +664,7 @@ def main():
 
     # ---- correctness of what was just timed (rank 0 holds the fixture's utterance): reference output on the same inputs
     mse = None
-    if rank == 0 and fx is not None and a.depth == 22 and a.steps + a.warmup > 0:
+    if rank == 0 and fx is not None and a.depth == 22 and a.steps + a.warmup > 0 and not a.outlier_weights:
         if w["golden_steps"] == nfe:
             mse = gen_mse(last["out"].detach().cpu().numpy(), fx["out"], fx)      # the timed region's own last result
         else:                                                        # the fixture is a short solve: one extra untimed sample
@@ -698,7 +704,8 @@ def main():
                                       if a.overlap else "none (strictly serial)"),
                        "parallelism": f"dp{world} ({world} process(es), one per GPU; utterance sharding, RCCL weight broadcast into "
                                       "device memory, no step-loop collectives)",
-                       "depth": a.depth, "weights": f"synthetic N(0,0.02^2), seed {w['wseed']}",
+                       "depth": a.depth, "weights": f"synthetic N(0,0.02^2), seed {w['wseed']}" + (", outlier residual channels (1 % x30)" if a.outlier_weights else ""),
+                       "fp8_gemm_sites_kept_bf16": model.engine.stat("fp8_gemms_kept_bf16") if a.fp8 else None,
                        "real_frames_per_step": real_rows, "rows_computed_per_step": rows_computed,
                        "padded_row_waste": 1.0 - real_rows / rows_computed,       # rows the block chain computes beyond the real frames
                        "rows_computed_attention_half": rows_attn,     # attn_norm, QK / V, attention, out-projection: padding blocks always skipped (exact)
@@ -744,11 +751,11 @@ def main():
         def committed(names, *path):
             for name in names:
                 try:
-                    j = json.load(open(os.path.join(ROOT, "profiles", name)))
+                    j = json.load(open(os.path.join(ROOT, "profiles", name[:3], name)))      # profiles/<round>/<file>
                     v = j
                     for k_ in path:
                         v = v[k_]
-                    return v, f"profiles/{name} <- {j.get('_source', '?')}"
+                    return v, f"profiles/{name[:3]}/{name} <- {j.get('_source', '?')}"
                 except (OSError, KeyError, ValueError, TypeError):
                     continue
             return None, None

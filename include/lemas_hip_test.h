@@ -27,6 +27,12 @@ int lemas_k_linear_f32(const float* A, const float* W, const float* bias, float*
  * 32 consecutive K (OCP MX); weights: e4m3 + one fp32 scale per output channel.  All pointers device. */
 int lemas_k_mx_quant(const float* x, int32_t M, int32_t K, uint8_t* out8, uint8_t* mx, void* stream);
 int lemas_k_w_quant_f8(const float* w, int32_t N, int32_t K, uint8_t* out8, float* scale, void* stream);
+/* the side product of the fp8 path on outlier checkpoints (csrc/outlier_rows.hip): x[m][chan[j]] += gate[chan[j]] * (bf16(A)[m] . bf16(Wside)[j] + bias_side[j])
+ * for j < nf <= 32 and every row m = (sample, position < min(frames, seq_len[sample])) of the [batch][pitch] row space; A [batch * pitch][K], Wside [nf][K],
+ * gate [ldx], x [batch * pitch][ldx] fp32 in place; a8 / amx (optional): the MXFP8 image of bf16(A), [M][K] e4m3 + [M][K / 32] E8M0; K is 1024 or 2048 */
+int lemas_k_outlier_rows(const float* A, const float* Wside, const float* bias_side, const int32_t* chan, int32_t nf, const float* gate,
+                         const int32_t* seq_len, float* x, int32_t batch, int32_t frames, int32_t pitch, int32_t K, int32_t ldx, uint8_t* a8, uint8_t* amx,
+                         void* stream);
 int lemas_k_ln_mod_f8(const float* x, const float* scale, const float* shift, uint8_t* out8, uint8_t* mx, int32_t M, int32_t D,
                       void* stream);
 /* out = act(MXFP8(A) . FP8(W)^T + bias); act 0 none (fp32 out), 1 GELU-tanh (bf16-rounded out), 2 GELU-tanh written as

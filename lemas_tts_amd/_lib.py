@@ -152,6 +152,7 @@ def testlib():
         "lemas_k_mx_quant": (C.c_int, [vp, i32, i32, vp, vp, vp]),
         "lemas_k_w_quant_f8": (C.c_int, [vp, i32, i32, vp, vp, vp]),
         "lemas_k_ln_mod_f8": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, vp]),
+        "lemas_k_outlier_rows": (C.c_int, [vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]),
         "lemas_k_linear_f8": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]),
         "lemas_k_ln_mod": (C.c_int, [vp, vp, vp, vp, i32, i32, vp]),
         "lemas_k_convpos": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
@@ -179,7 +180,7 @@ EXPORTED = [      # include/lemas_hip.h: the product library
 ]
 EXPORTED_TEST = [  # include/lemas_hip_test.h: the test library
     "lemas_k_linear_bf16", "lemas_k_linear_f32", "lemas_k_attention", "lemas_k_attention_variant", "lemas_k_ln_mod", "lemas_k_convpos", "lemas_k_bench", "lemas_k_gemm_epi",
-    "lemas_k_gemm_gate_ln", "lemas_k_ln_fold_pair", "lemas_k_timeline", "lemas_k_build_flags", "lemas_k_mx_quant", "lemas_k_w_quant_f8", "lemas_k_ln_mod_f8", "lemas_k_linear_f8",
+    "lemas_k_gemm_gate_ln", "lemas_k_ln_fold_pair", "lemas_k_timeline", "lemas_k_build_flags", "lemas_k_mx_quant", "lemas_k_w_quant_f8", "lemas_k_ln_mod_f8", "lemas_k_outlier_rows", "lemas_k_linear_f8",
 ]
 
 

@@ -333,6 +333,23 @@ hipError_t launch_w_quant_f8(const float* w, int N, int K, uint8_t* out8, float*
 // and back: bf16(e4m3 * scale[row]) -- the weights-only-fp8 accuracy point runs the bf16 kernels on these
 hipError_t launch_f8_to_bf16(const uint8_t* w8, const float* scale, int N, int K, bf16_t* out, hipStream_t s);
 
+// ---- fp8 path on outlier checkpoints: the flagged output channels of a residual-writing projection from bf16 operands (outlier_rows.hip) ----
+struct OutlierRowsParams {
+  const bf16_t* A;        // [M][K] bf16 activations (attention output / FF1 output)
+  const bf16_t* W;        // [32][K] bf16: row j = the weight row of flagged channel chan[j]; rows past nf are zero
+  const float* bias;      // [32]: bias of channel chan[j]
+  const int* chan;        // [32] device: flagged channel indices (ascending), -1 past nf
+  int nf;                 // flagged channels (1 .. 32)
+  float* x;               // residual stream [M][ldx] fp32, updated in place
+  int ldx, M, K;
+  const float* tab; int tab_stride, gate_off; const int* step_idx;   // gate vector of the current ODE step (GemmParams)
+  const int* kv_len;      // [batch] or nullptr: rows at or past their sample's length contribute 0 (EPI_GATE_RES)
+  int seq_pitch, seq_valid, batch;
+  uint8_t* a8;            // optional: the MXFP8 image of A ([M][K] e4m3 + amx [M][K/32] E8M0) for the fp8 GEMM of the same site, written while
+  uint8_t* amx;           // the rows stream through (every row m < M, live or not)
+};
+hipError_t launch_outlier_rows(const OutlierRowsParams& p, hipStream_t s);
+
 struct ConvPosParams {
   const float* in_f32;    // conv1 input  [B2*N, C] fp32 (nullptr when in_bf16 is used)
   const bf16_t* in_bf16;  // conv2 input  [B2*N, C] bf16

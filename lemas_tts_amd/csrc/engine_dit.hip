@@ -32,6 +32,10 @@ struct BlockW {
   DevBuf sqkv, so, s1, s2;       // fp32 per-output-channel scales
   DevBuf bqkv;              // fp32 [3*inner]
   const float *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
+  // fp8 path on outlier checkpoints (quantize_fp8): bf16 weight rows / biases of the flagged output channels of attn.to_out and ff.2
+  // ([32][K] bf16, [32] fp32; outlier_rows.hip) and copies of the two bias vectors with those channels zeroed (the fp8 GEMM, whose e4m3 image of
+  // those rows is zeroed too, must contribute nothing there)
+  DevBuf wo_side, w2_side, bo_side, b2_side, bo_z, b2_z;
 };
 
 }  // namespace lemas
@@ -56,7 +60,7 @@ struct lemas_dit {
   // fp8 OUTLIER GUARD (option "fp8_outlier_guard", default on).  Trained DiT checkpoints carry a few residual-stream channels tens of times
   // larger than the rest; synth.synth_cfm_state_dict(outlier=...) reproduces the mechanism (rows of attn.to_out / ff.2, weight and bias,
   // scaled up).  Measured against the reference's own output at full depth and NFE 32 (tests/golden/configs0_outlier_nfe32.npz, 1 % of the
-  // channels x30; profiles/r04_fp8_outlier_points.txt): bf16 3.9e-6, the fp8 path 2.9e-4 (weights-only fp8 2.2e-4) against the 1e-4
+  // channels x30; profiles/r04/r04_fp8_outlier_points.txt): bf16 3.9e-6, the fp8 path 2.9e-4 (weights-only fp8 2.2e-4) against the 1e-4
   // target -- and no part of it is safe to keep: ONE GEMM site on fp8 with the other three on bf16 gives 6.4e-5 (QKV), 8.4e-5
   // (out-projection), 1.15e-4 (FF1), 1.05e-4 (FF2), five to seven times what the same site costs on weights without outliers.  So fp8 does
   // not ship for such checkpoints: quantize_fp8() already computes the per-output-channel scales of the residual-writing projections,
@@ -66,17 +70,29 @@ struct lemas_dit {
   // text embedding) are not seen -- a first-contact item for real checkpoints.
   bool fp8_guard = true, fp8_guard_tripped = false;
   int fp8_outlier_channels = 0;
+  // option "fp8_outlier_mode" (round 5; default 0): 1 = when the guard trips on at most 32 channels, fp8 is NOT given up: QKV, out-projection and FF2
+  // keep their fp8 operands (three of the four sites), FF1 runs on bf16 operands, and the flagged OUTPUT channels of out-projection / FF2 are
+  // computed from bf16 operands by outlier_rows.hip (their rows of the e4m3 images and their biases are zeroed), which also writes the MXFP8 image
+  // of its input rows for the fp8 GEMM of the site.  Accuracy against the reference's own outputs: 8.4e-5 at NFE 32 and 9.6e-5 on the 8-step
+  // fixture (target 1e-4; unguarded 2.9e-4 / 6.8e-4; tests/test_gpu_02_fp8.py asserts the tolerance).  Throughput: 125 audio-s/s at configs[4]'s
+  // shape against 136 for 0 = every block GEMM on bf16 (round 4's behaviour, 3.9e-6): at these shapes the three fp8 sites save ~16 us per block
+  // and lane, the two side launches cost ~39 (profiles/r05/r05_fp8_outlier_decomposition.txt) -- which is why 0 stays the default.
+  bool fp8_outlier_mode = false;
+  bool fp8_outlier_split = false;            // set by quantize_fp8(): the decomposition is in force
+  std::vector<int> h_flagged;
+  DevBuf d_flagged;                          // int [32]: flagged channels (ascending), -1 past the count
   // which of a block's four GEMM sites take fp8 operands (bit 0 QKV, 1 out-projection, 2 FF1, 3 FF2): option "fp8_sites" (default all),
   // narrowed by the guard.  Each site's input comes from its own producer (LayerNorm 1, attention, LayerNorm 2, FF1's epilogue), so the
   // four choices are independent.
   int fp8_sites_opt = 15;
-  int fp8_sites() const { return !fp8 ? 0 : (fp8_guard && fp8_guard_tripped) ? 0 : fp8_sites_opt; }
+  int fp8_sites() const { return !fp8 ? 0 : (fp8_guard && fp8_guard_tripped) ? (fp8_outlier_split ? (fp8_sites_opt & 0b1011) : 0) : fp8_sites_opt; }
+  bool outlier_rows_on() const { return fp8 && fp8_guard && fp8_guard_tripped && fp8_outlier_split; }
   // measurement options (per engine; changing one drops the cached graphs): explicit tile ids for the block GEMMs with N == 1024 /
   // N == 2048, for the fused QK+V launch, and the XCD block grid of the tile order; 0 = the production choice
   // option "skip_dead" (0 by default): what the FF HALF of a block does with a ragged batch's padding blocks (the attention half skips them
   // always and exactly: skip_masked below).  0 = computes them, as the reference does -- its unmasked position-embedding conv (dit.py:98 ->
   // modules.py:167-190, kernel 31 twice) lets the last ~30 valid frames of a sample see the padding rows' ODE state.  1 = skips them all: those
-  // frames differ from the reference's by 1e-5 mel-MSE instead of 2e-6 (tolerance 1e-4; profiles/r04g_skip_dead_ragged_batches.txt).
+  // frames differ from the reference's by 1e-5 mel-MSE instead of 2e-6 (tolerance 1e-4; profiles/r04/r04g_skip_dead_ragged_batches.txt).
   // 2 = skips all but ONE block behind every sample's last live block (d_live = min(len + 128, N)): the padding rows the position conv
   // reaches into are then evolved by the chain as the reference evolves them -- the reference's own error level -- at most of the saving
   int skip_dead = 0;
@@ -84,7 +100,7 @@ struct lemas_dit {
   int opt_tile_n1024 = 0, opt_tile_n2048 = 0, opt_tile_qkv = 0, opt_xcd_gx = 0, opt_xcd_runs = 0;
   // attention schedule variant (attention.hip VAR).  19 = no running max (P = exp2(S) on q prescaled by the QK epilogue, one range check
   // per workgroup with a classical second pass if it trips) + static priority for the younger half-workgroup: 25.9 -> 22.5 us per lane
-  // launch at configs[1], +4.6 % end to end (profiles/r03_attention_variants.txt); 0 = the classical online softmax
+  // launch at configs[1], +4.6 % end to end (profiles/r03/r03_attention_variants.txt); 0 = the classical online softmax
   int attn_variant = 19;
   // measurement option: lane 1 launches stage k of a block only after lane 0's stage k has completed (the lanes run one stage apart
   // instead of in lock-step, so unlike kernels share the chip)
@@ -94,14 +110,14 @@ struct lemas_dit {
   // lane with grid barriers between the stages (gemm_bf16.hip gemm_chain_ffhalf_kernel); 2 = with the next stage's weights prefetched across the barrier
   int block_persist = 0;
   // the AdaLN LayerNorms behind the gated residual updates as the tail of those GEMM launches (gemm_bf16.hip ln_tail).  OFF: measured on
-  // configs[1] it is 1.5x SLOWER end to end (88.9 -> 59.8 audio-s/s, profiles/r03_ln_tail_experiment.txt): with two lanes sharing the chip a
+  // configs[1] it is 1.5x SLOWER end to end (88.9 -> 59.8 audio-s/s, profiles/r03/r03_ln_tail_experiment.txt): with two lanes sharing the chip a
   // panel's column tiles do not run at the same time, so finished workgroups sit on their CUs waiting for panel-mates that have not started
   bool ln_fused = false;
   // "ln fold" (common.h GemmParams): the AdaLN LayerNorms of the block chain folded across the GEMMs on either side -- the gate +
   // residual epilogues write the scaled bf16 rows and per-row partial sums, the QKV / FF1 epilogues apply the row statistics, and c1 / c2
   // rows per ODE step live in the AdaLN table.  Two of the seven launches per block and lane disappear.  bf16 activations only (the
   // MXFP8 path keeps its quantising LayerNorm launch).  OFF: end to end it is a wash at configs[1] (95.9 = 95.9 audio-s/s) and 2-2.5 %
-  // slower at the batched and the short workload (profiles/r03_structural_attempts.txt).  What the two removed launches cost a lane's
+  // slower at the batched and the short workload (profiles/r03/r03_structural_attempts.txt).  What the two removed launches cost a lane's
   // chain the other lane was already hiding; what counts with two lanes on the chip is workgroup-time, and there the fold adds (1-2 us per
   // producer launch for the bf16 image and the statistics, 1-2.5 us per consumer launch for re-reading 256 B of statistics per row by
   // every column tile) about what the two small LayerNorm launches took.
@@ -369,9 +385,39 @@ int lemas_dit::quantize_fp8() {
     std::sort(sorted.begin(), sorted.end());
     const float med = sorted[d / 2];
     fp8_outlier_channels = 0;
+    h_flagged.clear();
     for (int c = 0; c < d; ++c)
-      if (chan[c] > 8.0f * med) ++fp8_outlier_channels;
+      if (chan[c] > 8.0f * med) { ++fp8_outlier_channels; h_flagged.push_back(c); }
     fp8_guard_tripped = fp8_outlier_channels > 0;
+  }
+  // mixed-precision decomposition for outlier checkpoints: side operands of the flagged channels, zeroed rows / biases for the fp8 GEMMs
+  fp8_outlier_split = false;
+  if (fp8_guard && fp8_guard_tripped && fp8_outlier_mode && fp8_outlier_channels <= 32) {
+    const int nf = fp8_outlier_channels;
+    std::vector<int> pad(32, -1);
+    for (int j = 0; j < nf; ++j) pad[j] = h_flagged[j];
+    RC_TRY(d_flagged.ensure(32 * sizeof(int)));
+    HIP_TRY(hipMemcpy(d_flagged.p, pad.data(), 32 * sizeof(int), hipMemcpyHostToDevice));
+    for (auto& b : blocks) {
+      struct Site { DevBuf* wbf; DevBuf* w8; const float* bias; DevBuf* wside; DevBuf* bside; DevBuf* bz; int K; };
+      for (const Site& st : {Site{&b.wo, &b.wo8, b.bo, &b.wo_side, &b.bo_side, &b.bo_z, in}, Site{&b.w2, &b.w28, b.b2, &b.w2_side, &b.b2_side, &b.b2_z, ffd}}) {
+        RC_TRY(st.wside->ensure((size_t)32 * st.K * 2));       // zero-filled by ensure(): rows past nf stay zero
+        RC_TRY(st.bside->ensure(32 * 4));
+        RC_TRY(st.bz->ensure((size_t)d * 4));
+        HIP_TRY(hipMemset(st.wside->p, 0, (size_t)32 * st.K * 2));
+        HIP_TRY(hipMemset(st.bside->p, 0, 32 * 4));
+        HIP_TRY(hipMemcpy(st.bz->p, st.bias, (size_t)d * 4, hipMemcpyDeviceToDevice));
+        for (int j = 0; j < nf; ++j) {
+          const int c = h_flagged[j];
+          HIP_TRY(hipMemcpy(st.wside->as<bf16_t>() + (size_t)j * st.K, st.wbf->as<bf16_t>() + (size_t)c * st.K, (size_t)st.K * 2, hipMemcpyDeviceToDevice));
+          HIP_TRY(hipMemcpy(st.bside->as<float>() + j, st.bias + c, 4, hipMemcpyDeviceToDevice));
+          HIP_TRY(hipMemset(st.w8->as<uint8_t>() + (size_t)c * st.K, 0, (size_t)st.K));        // e4m3 0x00 = +0
+          HIP_TRY(hipMemset(st.bz->as<float>() + c, 0, 4));
+        }
+      }
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    fp8_outlier_split = true;
   }
   fp8_ready = true;
   return 0;
@@ -380,7 +426,15 @@ int lemas_dit::quantize_fp8() {
 // option "fp8" = 2: bf16 images of the e4m3-quantised weights (value = e4m3 * per-channel scale, rounded to bf16)
 int lemas_dit::dequantize_fp8() {
   if (fp8_wonly_ready) return 0;
-  RC_TRY(quantize_fp8());
+  // the weights-only accuracy point dequantises the COMPLETE e4m3 images: if the outlier decomposition zeroed the flagged rows, quantise afresh
+  // without it (and leave the images marked stale, so that the next fp8 = 1 prepare() builds the decomposition again)
+  const bool split_mode = fp8_outlier_mode;
+  if (fp8_ready && fp8_outlier_split) fp8_ready = false;
+  fp8_outlier_mode = false;
+  const int qrc = quantize_fp8();
+  fp8_outlier_mode = split_mode;
+  if (split_mode) fp8_ready = false;
+  RC_TRY(qrc);
   const int d = cfg.dim, in = inner(), ffd = cfg.ff_mult * d;
   hipStream_t s = nullptr;
   for (auto& b : blocks) {
@@ -791,7 +845,7 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
   int ln_panels = 0;
   bool fuse_ln = false;
   const bool fold = fold_on();
-  if (ln_fused && !fp8 && !fold) {
+  if (ln_fused && !fp8 && !fold && lanes <= 2) {      // (measurement builds; the counters are sized for at most two lanes)
     GemmParams t{};
     t.M = rows; t.N = d; t.K = in; t.n_valid = d; t.ldc = d; t.concurrency = lanes; t.tile = d == 1024 ? opt_tile_n1024 : 0;
     int per_cu = 1;
@@ -807,7 +861,7 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
   }
   auto ln_site = [&](int l, int site, int ln) { return lncnt + ((size_t)(l * 2 + site) * lanes + ln) * ln_panels; };
   // block_persist: 16 barrier words per (block, lane), zeroed by a memset node ahead of the fork (the LayerNorm tails' counter buffer)
-  const bool persist = block_persist != 0 && !fp8 && !fold && !fuse_ln && !has_len && s != nullptr && cfg.dim == 1024;
+  const bool persist = block_persist != 0 && !fp8 && !fold && !fuse_ln && !has_len && s != nullptr && cfg.dim == 1024 && lanes <= 2;
   unsigned int* psync = nullptr;
   if (persist) {
     const size_t nb = (size_t)cfg.depth * lanes * 16 * sizeof(unsigned int);
@@ -958,14 +1012,25 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     }
     g.ln_part = nullptr;
     RC_TRY(pkernel(PC_ATTN, &at.ev_start, &at.ev_stop));
-    at.out8 = f8_out ? a8 : nullptr; at.out_mx = f8_out ? amx : nullptr;
+    // fp8 on an outlier checkpoint (outlier_rows.hip): the producers of the two residual-writing projections' inputs write bf16, and ONE side
+    // launch per site computes the flagged output channels from those bf16 rows and writes their MXFP8 image for the fp8 GEMM of the site
+    const bool orows = outlier_rows_on();
+    at.out8 = (f8_out && !orows) ? a8 : nullptr; at.out_mx = (f8_out && !orows) ? amx : nullptr;
+    auto outlier_rows = [&](const bf16_t* A, const DevBuf& wside, const DevBuf& bside, int K, int gate_off, const int* kvl, uint8_t* q8, uint8_t* qmx) -> int {
+      OutlierRowsParams o{};
+      o.A = A; o.W = wside.as<bf16_t>(); o.bias = bside.as<float>(); o.chan = d_flagged.as<int>(); o.nf = fp8_outlier_channels;
+      o.x = xres; o.ldx = d; o.M = rows; o.K = K; o.tab = tab; o.tab_stride = tab_stride; o.gate_off = gate_off; o.step_idx = step;
+      o.kv_len = kvl; o.seq_pitch = pitch; o.seq_valid = N; o.batch = len_batch; o.a8 = q8; o.amx = qmx;
+      HIP_TRY(launch_outlier_rows(o, q));
+      return 0;
+    };
     TL_SLOT(at);
     RC_TRY(skew_pre(ln, q));
     HIP_TRY(launch_attention(at, q));
     RC_TRY(skew_post(ln, q));
     RC_TRY(pkernel(PC_GEMM_OUT, &g.ev_start, &g.ev_stop));
     operands(f8_out, abf, a8, amx, w.wo, w.wo8, w.so, w.woq, 0, in);
-    g.bias = w.bo; g.N = d; g.K = in; g.n_valid = d;
+    g.bias = (f8_out && orows) ? w.bo_z.as<float>() : w.bo; g.N = d; g.K = in; g.n_valid = d;
     g.out_f32 = xres; g.ldc = d; g.gate_off = base + 2 * d; g.kv_len = len_l; g.tile = tile_for(g.N);
     if (fuse_ln) {   // ff_norm (modules.py:637) as the tail of the out-projection launch
       g.ln_out = hbf; g.ln_scale_off = base + 4 * d; g.ln_shift_off = base + 3 * d; g.ln_cnt = ln_site(l, 0, ln); g.ln_err = ln_err_dev;
@@ -975,7 +1040,11 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     RC_TRY(skew_pre(ln, q));
     GemmParams g_out = g;
     if (persist) { g_out.tile = 0; g_out.ev_start = g_out.ev_stop = nullptr; }
-    else HIP_TRY(launch_gemm_bf16(EPI_GATE_RES, g, q));
+    else {
+      // (the side launch first: it writes the MXFP8 rows the fp8 GEMM reads; the two update disjoint columns of x)
+      if (f8_out && orows) RC_TRY(outlier_rows(abf, w.wo_side, w.bo_side, in, base + 2 * d, len_l, a8, amx));
+      HIP_TRY(launch_gemm_bf16(EPI_GATE_RES, g, q));
+    }
     RC_TRY(skew_post(ln, q));
     g.ln_out = nullptr; g.xs_out = nullptr;
     g.live_len = live_l;        // FF half
@@ -989,16 +1058,19 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     operands(f8_ff1, hbf, h8, hmx, w.w1, w.w18, w.s1, w.w1q, 0, d);
     g.bias = w.b1; g.N = ffd; g.K = d; g.n_valid = ffd;
     g.out_bf16 = ffb; g.out_f8 = ff8; g.out_mx = ffmx; g.ldc = ffd; g.kv_len = nullptr; g.tile = tile_for(g.N);
+    // FF1 writes what FF2 reads: MXFP8 straight from its epilogue -- except on an outlier checkpoint, where it writes bf16 and FF2's side launch quantises
+    const bool ff1_f8_out = f8_ff2 && !(orows && !f8_ff1);
     if (fold) { g.ln_part = lnpart; g.lnc1_off = fo + 6 * in; g.lnc2_off = fo + 6 * in + ffd; }
     TL_SLOT(g);
     RC_TRY(skew_pre(ln, q));
     GemmParams g_ff1 = g;
-    if (!persist) HIP_TRY(launch_gemm_bf16(f8_ff2 ? EPI_BIAS_GELU_F8 : EPI_BIAS_GELU_BF16, g, q));       // FF1 writes what FF2 reads
+    if (!persist) HIP_TRY(launch_gemm_bf16(ff1_f8_out ? EPI_BIAS_GELU_F8 : EPI_BIAS_GELU_BF16, g, q));
     RC_TRY(skew_post(ln, q));
     g.ln_part = nullptr;
+    if (f8_ff2 && orows) RC_TRY(outlier_rows(ffb, w.w2_side, w.b2_side, ffd, base + 5 * d, nullptr, ff8, ffmx));
     RC_TRY(pkernel(PC_GEMM_FF2, &g.ev_start, &g.ev_stop));
     operands(f8_ff2, ffb, ff8, ffmx, w.w2, w.w28, w.s2, w.w2q, 0, ffd);
-    g.bias = w.b2; g.N = d; g.K = ffd; g.n_valid = d;
+    g.bias = (f8_ff2 && orows) ? w.b2_z.as<float>() : w.b2; g.N = d; g.K = ffd; g.n_valid = d;
     g.out_f32 = xres; g.ldc = d; g.gate_off = base + 5 * d; g.tile = tile_for(g.N);
     if (fuse_ln) {   // the next block's attn_norm (modules.py:314: shift, scale first), or the final norm (:335: scale, shift) after the last
       const int nb = (l + 1) * 6 * d, fb = cfg.depth * 6 * d;
@@ -1316,7 +1388,15 @@ int lemas_dit_set_option(lemas_dit* m, const char* key, int64_t value) {
     return 0;
   }
   if (!strcmp(key, "graph_update")) { m->graph_update = value != 0; return 0; }
-  if (!strcmp(key, "fp8_outlier_guard")) { m->fp8_guard = value != 0; m->drop_graphs(); return 0; }
+  if (!strcmp(key, "fp8_outlier_guard")) {
+    if (m->fp8_guard != (value != 0)) { m->fp8_guard = value != 0; m->fp8_ready = false; m->prepared = false; }     // (the e4m3 images differ: zeroed rows or not)
+    m->drop_graphs();
+    return 0;
+  }
+  if (!strcmp(key, "fp8_outlier_mode")) {       // 1 = mixed-precision decomposition on outlier checkpoints (default), 0 = every block GEMM on bf16 there
+    if (m->fp8_outlier_mode != (value != 0)) { m->fp8_outlier_mode = value != 0; m->fp8_ready = false; m->prepared = false; m->drop_graphs(); }
+    return 0;
+  }
   if (!strcmp(key, "fp8_sites")) {
     if (value < 0 || value > 15) { set_error("lemas_dit_set_option: fp8_sites is a mask of GEMM sites (1 QKV, 2 out-projection, 4 FF1, 8 FF2), 0 .. 15"); return LEMAS_E_ARG; }
     m->fp8_sites_opt = (int)value;

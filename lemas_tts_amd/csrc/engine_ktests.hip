@@ -372,6 +372,33 @@ int lemas_k_ln_mod_f8(const float* x, const float* scale, const float* shift, ui
   return 0;
 }
 
+int lemas_k_outlier_rows(const float* A, const float* Wside, const float* bias_side, const int32_t* chan, int32_t nf, const float* gate,
+                         const int32_t* seq_len, float* x, int32_t batch, int32_t frames, int32_t pitch, int32_t K, int32_t ldx, uint8_t* a8, uint8_t* amx,
+                         void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  Scratch sc;
+  const int M = batch * pitch;
+  bf16_t* a = sc.get<bf16_t>((size_t)M * K);
+  bf16_t* w = sc.get<bf16_t>((size_t)32 * K);
+  float* b = sc.get<float>(32);
+  int* ch = sc.get<int>(32);
+  int* step = sc.get<int>(1);
+  if (!a || !w || !b || !ch || !step) { set_error("lemas_k_outlier_rows: out of memory"); return LEMAS_E_STATE; }
+  if (nf < 1 || nf > 32) { set_error("lemas_k_outlier_rows: nf is 1 .. 32"); return LEMAS_E_ARG; }
+  HIP_TRY(launch_f32_to_bf16(A, a, (size_t)M * K, s));
+  HIP_TRY(launch_f32_to_bf16(Wside, w, (size_t)nf * K, s));      // rows past nf stay zero (Scratch zero-fills)
+  HIP_TRY(hipMemcpyAsync(b, bias_side, (size_t)nf * 4, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipMemsetAsync(ch, 0xff, 32 * 4, s));
+  HIP_TRY(hipMemcpyAsync(ch, chan, (size_t)nf * 4, hipMemcpyDeviceToDevice, s));
+  OutlierRowsParams o{};
+  o.A = a; o.W = w; o.bias = b; o.chan = ch; o.nf = nf; o.x = x; o.ldx = ldx; o.M = M; o.K = K;
+  o.tab = gate; o.tab_stride = 0; o.gate_off = 0; o.step_idx = step; o.kv_len = seq_len; o.seq_pitch = pitch; o.seq_valid = frames; o.batch = batch;
+  o.a8 = a8; o.amx = amx;
+  HIP_TRY(launch_outlier_rows(o, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return 0;
+}
+
 int lemas_k_linear_f8(const float* A, const float* W, const float* bias, float* out, int32_t M, int32_t N, int32_t K, int32_t act,
                       uint8_t* out8, uint8_t* outmx, void* stream) {
   hipStream_t s = (hipStream_t)stream;

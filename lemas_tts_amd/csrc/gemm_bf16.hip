@@ -36,7 +36,7 @@ namespace {
 constexpr int BK = 64;
 constexpr int LN_NP = LN_D / 32;      // ln fold: 32-column statistics slots per row (GemmParams::ln_np)
 
-// Measurement builds only (-DLEMAS_PHASE_TIMESTAMPS, see profiles/r02_kbench_phases.txt): thread 0 of every workgroup stamps the 100 MHz
+// Measurement builds only (-DLEMAS_PHASE_TIMESTAMPS, see profiles/r02/r02_kbench_phases.txt): thread 0 of every workgroup stamps the 100 MHz
 // wall clock at entry, after the prologue, after the K loop and after its last store has drained.  Compiled out of the product.
 #ifdef LEMAS_PHASE_TIMESTAMPS
 // a timeline slot holds 1024 workgroups x 4 stamps (engine_dit.hip TL_SLOT): larger grids stamp their first 1024 workgroups only
@@ -57,7 +57,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 // Step 2: the logical sequence walks the tile grid BLOCK by block, the grid cut into gx x gy blocks (gx * gy = 8), so one XCD's run
 // is (about) one block: it fetches 1/gx of the A panels and 1/gy of the W panels.  With the plain row-major sequence (gx = 8,
-// gy = 1) every XCD streamed ALL of W: PMC FETCH 45.8 MB for the QK GEMM against 15.8 MB algorithmic (profiles/r01o_traffic.json).
+// gy = 1) every XCD streamed ALL of W: PMC FETCH 45.8 MB for the QK GEMM against 15.8 MB algorithmic (profiles/r01/r01o_traffic.json).
 // The host picks (gx, gy) to minimise gy * |A| + gx * |W| (GemmParams::xcd_gx).  Ragged grids: blocks at the edges are smaller.
 // Round 4: the run of an XCD and its block are the SAME thing.  xcd_remap hands every XCD an equal share of the sequence, but the blocks of a
 // ragged grid are not equal (15 x 8 tiles cut 4 x 2: blocks of 16, 16, 16, 16, 16, 16, 12, 12), so an XCD's run started inside one block and
@@ -710,7 +710,7 @@ constexpr int slab_bytes() {
 // ---------------------------------------------------------------- LayerNorm-modulate tail of the gate + residual GEMM
 // The AdaLN-modulated LayerNorm behind every gated residual update (modules.py:635-637, :639 -> the next block's :314, the final
 // :335) needs whole rows of x_res; a 128-column tile holds an eighth of one.  As its own launch it costs a lane's chain 9-13 us per
-// site (5 us of latency-bound kernel between two ~2 us dependent-launch boundaries: profiles/r02_timeline_step.txt) for 0.4 % of the
+// site (5 us of latency-bound kernel between two ~2 us dependent-launch boundaries: profiles/r02/r02_timeline_step.txt) for 0.4 % of the
 // FLOPs.  Here the GEMM launch finishes the job itself: the TILES_N workgroups that share a row panel meet at the panel's arrival
 // counter once their x_res tiles are out (write-through stores, drained by every wave before the one arrival per workgroup), and
 // each then normalises R = BM / TILES_N rows of the panel.  Visibility follows the recipe of the hardware guide (producer: sc1
@@ -1281,7 +1281,7 @@ __device__ __forceinline__ void gemm_body_pp(const GemmParams& p, char* smem, in
     // set of residual rows (and gained nothing from them: at full chip it is bound by the fp32 read-modify-write traffic), and
     // the loop (224-256 VGPRs) none for an early request.  (Round 4, AHEAD 2: the next block's rows requested once a block's
     // accumulators are parked -- 56 B of scratch and SLOWER: 88.2 -> 91.2 us at M = 30720, K = 1024, 141.6 -> 152.5 at K = 2048,
-    // configs[3] -1.1 %; profiles/r04_gate_epilogue_prefetch_256x256.txt)
+    // configs[3] -1.1 %; profiles/r04/r04_gate_epilogue_prefetch_256x256.txt)
     constexpr int LNA = epi_lna<EPI>() ? 2 : 0;
     EpiPre<EPI, 2, EPI != EPI_GATE_RES, LNA> pre;
     pre.load(p, m0 + wm * 128, n0 + wn * 64, lane);
@@ -1554,7 +1554,7 @@ template <> struct TileCfg<T128x128> { static constexpr int BM = 128, BN = 128, 
 template <> struct TileCfg<T128x64>  { static constexpr int BM = 128, BN = 64,  ST = 3, WM = 2, WN = 2; };
 template <> struct TileCfg<T64x64>   { static constexpr int BM = 64,  BN = 64,  ST = 3, WM = 2, WN = 2; };
 template <> struct TileCfg<T128x128W4> { static constexpr int BM = 128, BN = 128, ST = 3, WM = 2, WN = 2; };
-// Tried and dropped in round 3 (profiles/r03_structural_attempts.txt): the 8 waves as 4 x 2 (whole 128-B lines for the ln-fold image:
+// Tried and dropped in round 3 (profiles/r03/r03_structural_attempts.txt): the 8 waves as 4 x 2 (whole 128-B lines for the ln-fold image:
 // +0.7 us plain, -0.7 us as fold producer), a TWO-stage ring (64 KB: two workgroups per CU; -2 ... -8 % end to end), and the K-tile
 // split over two groups of 2 x 2 waves with 64 x 64 outputs that swap halves through LDS before the epilogue (a third less LDS read
 // traffic, parity-green: the K loop is no faster -- 0.43 vs 0.44 us per K-tile, it is the lock-step structure, not LDS bandwidth --
@@ -1574,7 +1574,7 @@ struct Launch {
     const int tiles_m = (p.M + C::BM - 1) / C::BM, tiles_n = p.N / C::BN;
     const dim3 grid(grid_of(tiles_m, tiles_n, p.xcd_gx, p.xcd_runs)), block(64 * C::WM * C::WN);
     // without the ln-fold table the launch keeps the ring's own footprint (128 x 128: exactly 96 KB, which with the attention kernel's
-    // exact 64 KB is a CU's 160 KB -- measured: sharing or not sharing a CU that way changes nothing, profiles/r03_structural_attempts.txt)
+    // exact 64 KB is a CU's 160 KB -- measured: sharing or not sharing a CU that way changes nothing, profiles/r03/r03_structural_attempts.txt)
     const int lds_now = p.ln_part ? lds : lds - C::BM * 8;
     if (p.ev_start)
       hipExtLaunchKernelGGL((gemm_bf16_kernel<EPI, C::BM, C::BN, C::ST, C::WM, C::WN, F8>), grid, block, lds_now, s, p.ev_start, p.ev_stop, 0, p);
@@ -1596,12 +1596,12 @@ int pick_tile(const GemmParams& p) {
   if (tile == T128x64 && p.N <= 1024 && (long)((p.M + 127) / 128) * (p.N / 64) < 130) tile = T64x64;
   // Two lanes in flight and a stand-alone N >= 2048 GEMM (FF1) of at most 256 128 x 128 tiles: the 4-wave form of that tile instead of the
   // 256 x 128 ping-pong tile.  End to end on configs[1] (M = 1875 per lane; tools/e2e_ab.py, ONE engine re-captured per arm, 6 interleaved
-  // rounds, profiles/r02_e2e_ab_w4_tile.txt): 87.1 -> 89.1 audio-s/s (+2.3 %); M = 1152: ties; M = 2304 (288 tiles): -2 %, M = 3456: -5 % (not
+  // rounds, profiles/r02/r02_e2e_ab_w4_tile.txt): 87.1 -> 89.1 audio-s/s (+2.3 %); M = 1152: ties; M = 2304 (288 tiles): -2 %, M = 3456: -5 % (not
   // chosen there).  For the N = 1024 GEMMs it LOSES 1 % against the 8-wave 128 x 128 tile, for the fused QK+V launch 7 %.
   if (!p.f8 && conc >= 2 && p.N >= 2048 && (tile == T256x128 || tile == T128x128) && t128 <= 256) tile = T128x128W4;
   if (!p.f8 && p.N % 256 == 0 && p.N >= 1024) {
     // batched workloads: the ping-pong 256x256 tile once its tiles cover the CUs of this launch 1.5 times (N >= 2048) / 1.1 times
-    // (N = 1024).  Measured end to end with two lanes in flight (tools/e2e_ab.py --batch B, profiles/r02_e2e_ab_pingpong_batch.txt):
+    // (N = 1024).  Measured end to end with two lanes in flight (tools/e2e_ab.py --batch B, profiles/r02/r02_e2e_ab_pingpong_batch.txt):
     // N = 2048 GEMMs: -3 % at M = 2304 per lane, +1 % at 4608, +8 % at 6912 and 9216; adding the N = 1024 GEMMs: -24 %, -3 %, -5 %,
     // +1.3 % (configs[3]'s share: 155 -> 169 audio-s/s).  The tile count, not a round-quantisation model, is what predicts it: with
     // two lanes sharing the chip a partial last round of one lane is filled by the other.
@@ -1730,7 +1730,7 @@ __global__ __launch_bounds__(512) void gemm_group_kernel(const GemmParams* __res
 // barrier (XCD-hierarchical arrival counters, price list row "barrier-xcd" of MI355X_MICROARCH.md) instead of a kernel boundary, no launch
 // ramp / drain per stage, and -- `prefetch` -- the next stage's first WEIGHT tiles already streaming into LDS while the barrier is awaited
 // (weights never depend on the previous stage).  The question it answers: does removing three dependent-launch boundaries and their ramps
-// buy more than three grid barriers cost?  (profiles/r05_block_persist.txt)
+// buy more than three grid barriers cost?  (profiles/r05/r05_block_persist.txt)
 //
 // Visibility follows the recipe of the LayerNorm tail above: every stage publishes with write-through (sc1) stores, each storing wave
 // drains them (vmcnt(0)) before the workgroup's ONE arrival; a released workgroup executes one agent-scope acquire (invalidates this CU's

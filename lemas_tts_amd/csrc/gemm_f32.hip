@@ -14,7 +14,7 @@
 // MFMA j of a 16-k half takes k = 4 lk + j instead of 4 j + lk -- A and W use the same assignment, so every product meets its partner and only
 // the order of the fp32 additions inside a 16-k group differs from the textbook one.  Two LDS buffers and TWO register sets: while tile t is
 // multiplied, tile t+1 sits in the other buffer and the global loads of tiles t+2 and t+3 are in flight (asm loads, exact wait counts), one
-// __syncthreads per K-tile.  Round-4 history of the vocoder decode at L = 938 (profiles/r04_vocoder_f32_gemm.txt): 0.94 ms with every
+// __syncthreads per K-tile.  Round-4 history of the vocoder decode at L = 938 (profiles/r04/r04_vocoder_f32_gemm.txt): 0.94 ms with every
 // load waited for where it was issued (a select behind the load), 0.79 with the loads overlapping the MFMAs, 0.77 with exact wait counts,
 // 0.59 with 32-row tiles on the under-filled grids.
 #include "common.h"
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Params p) {
   const int l15 = lane & 15, lk = lane >> 4;
   // Row-major tile order, NOT the XCD-blocked one of the bf16 GEMMs (common.h xcd_tile_coords): measured on the vocoder (16 of these launches,
   // 938 rows): the blocked order cuts the fabric-side bytes of a decode from 810 to 529 MB (every XCD no longer fetches every panel) and makes
-  // the decode 13 % SLOWER (0.95 -> 1.07 ms), the K = 100 input projection of the step loop 6 % slower (profiles/r04_f32_gemm_xcd_order.txt).
+  // the decode 13 % SLOWER (0.95 -> 1.07 ms), the K = 100 input projection of the step loop 6 % slower (profiles/r04/r04_f32_gemm_xcd_order.txt).
   // These launches are latency-bound chains of K-tiles, the panels come from the die-level cache either way, and eight XCDs asking for the
   // same lines at the same time is the cheaper pattern.
   const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;

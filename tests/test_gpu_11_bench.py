@@ -62,9 +62,9 @@ def test_bench_runs_every_rccl_call_of_the_multi_gpu_path_in_a_world_of_one():
     around the timed region -- and the utterance it times is checked against the reference's own output (full depth, full NFE)."""
     line = _bench(["--steps", "1", "--warmup", "1", "--no-cpu-baseline"], env={"LEMAS_FORCE_DIST": "1", "LEMAS_DIST_BACKEND": "nccl"})
     wb = line["weight_broadcast"]
-    # the DiT blocks' GEMM weights travel in bf16 on the bf16 path (0.98 GB instead of 1.35; bit-identical results: the mel-MSE below is the
+    # the DiT blocks' GEMM weights travel in bf16 on the bf16 path (1.03 GB instead of 1.40 with the vocoder; bit-identical results: the mel-MSE below is the
     # single-process run's to the last digit)
-    assert wb["backend"] == "nccl" and wb["on_device"] is True and wb["world"] == 1 and wb["block_gemm_weights"] == "bf16" and 0.95e9 < wb["bytes"] < 1.0e9
+    assert wb["backend"] == "nccl" and wb["on_device"] is True and wb["world"] == 1 and wb["block_gemm_weights"] == "bf16" and 0.98e9 < wb["bytes"] < 1.08e9
     assert line["n_gpus"] == 1 and line["mel_mse_vs_reference"] is not None and line["mel_mse_vs_reference"] <= 1e-4
     assert line["per_rank_ms"]["min"] > 0 and len(line["per_rank_ms"]["all"]) == 1
     assert line["config"]["utterances_total"] == 1 and line["config"]["utterances_timed"] == 1

@@ -9,6 +9,8 @@ Variants (sites: q = QKV, o = out-projection, 1 = FF1, 2 = FF2; every listed sit
   kside        QKV / FF1: the flagged K columns of the LayerNorm output leave the MXFP8 image (zeroed) and go through a bf16 side product
   nside        out-proj / FF2: the flagged OUTPUT channels (weight rows) are computed from the bf16 activations and bf16 weights instead
   both         kside + nside
+  nside2       out-proj / FF2: the flagged output channels keep their MXFP8 activations but get TWO-TERM e4m3 weights (W = W_hi + W_lo, each e4m3
+               with its own per-row scale: ~bf16 precision from two fp8 MFMA passes over 1 % of the rows) -- what the engine implements
   <v>@<sites>  any of the above restricted to the sites named (e.g. both@q1: only QKV and FF1 on fp8, the others bf16)
   <v>+wbf / <v>+abf   ... with bf16 WEIGHTS (only the activations MXFP8) / bf16 ACTIVATIONS (only the weights e4m3) at the fp8 sites
   attn_qk8     (bf16 GEMMs) attention logits from MXFP8 q and k (one E8M0 scale per 32 of the 64 head dimensions), softmax and P.V unchanged
@@ -95,7 +97,7 @@ class SimDiT(O.OracleDiT):
         if site not in self.sites:                    # this site stays on bf16 operands
             return F.linear(bf(x), bf(w), b)
         kside = self.variant in ("kside", "both") and (".to_q" in name or ".to_k" in name or ".to_v" in name or ".ff.ff.0.0" in name)
-        nside = self.variant in ("nside", "both") and (".to_out.0" in name or ".ff.ff.2" in name)
+        nside = self.variant in ("nside", "both", "nside2") and (".to_out.0" in name or ".ff.ff.2" in name)
         fl = self.flagged
         key = (name, kside, nside)
         if key not in self._cache:
@@ -104,8 +106,12 @@ class SimDiT(O.OracleDiT):
                 wq[:, fl] = 0.0                       # those K columns leave the e4m3 image
             if nside:
                 wq[fl, :] = 0.0                       # those output rows leave it
-            self._cache[key] = (bf(wq) if self.wbf else w_quant(wq)[2], bf(w))
-        w8, wb = self._cache[key]
+            w2 = None
+            if self.variant == "nside2":                # two-term e4m3 image of the flagged rows
+                hi = w_quant(w[fl, :])[2]
+                w2 = hi + w_quant(w[fl, :] - hi)[2]
+            self._cache[key] = (bf(wq) if self.wbf else w_quant(wq)[2], bf(w), w2)
+        w8, wb, w2 = self._cache[key]
         x2 = x.reshape(-1, x.shape[-1])
         xm = x2.clone()
         if kside:
@@ -113,7 +119,9 @@ class SimDiT(O.OracleDiT):
         y = F.linear(bf(xm) if self.abf else mx_quant(xm)[2], w8)
         if kside:                                     # bf16 side product over the flagged K columns
             y = y + F.linear(bf(x2[:, fl]), wb[:, fl])
-        if nside:                                     # flagged output channels from the bf16 operands
+        if nside and w2 is not None:                  # flagged output channels: the same MXFP8 activations, two-term e4m3 weights
+            y[:, fl] = F.linear(mx_quant(x2)[2], w2)
+        elif nside:                                   # flagged output channels from the bf16 operands
             y[:, fl] = F.linear(bf(x2), wb[fl, :])
         return (y + b).reshape(*x.shape[:-1], -1)
 

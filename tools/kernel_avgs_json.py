@@ -2,7 +2,7 @@
 """rocprofv3 kernel-stats text (tools/rocpd_summary.py) of a bench.py run -> the JSON bench.py reads for `avg_launch_us_rocprof`,
 keyed by workload and by the kernel symbol names bench.py uses (out-proj and FF2 are ONE instantiation).
 
-    python tools/kernel_avgs_json.py configs1=profiles/r03_kernel_stats.txt [configs3=...] > profiles/r03_kernel_avgs.json
+    python tools/kernel_avgs_json.py configs1=profiles/r03/r03_kernel_stats.txt [configs3=...] > profiles/r03/r03_kernel_avgs.json
 """
 import json
 import re

@@ -2,7 +2,7 @@
 """K-loop pipe budget of the lock-step 128 x 128 GEMM tile, DERIVED from the raw lines of a committed ablation run (one -DLEMAS_ABLATE build per
 variant: bits 1 = no MFMAs, 2 = no refill LDS-DMA, 4 = no fragment reads) -> the JSON bench.py attaches as `roofline.k_loop_pipes`.
 
-    python tools/kloop_pipes_json.py profiles/r04g_kloop_ablations_128x128.txt > profiles/r04g_kloop_pipes.json
+    python tools/kloop_pipes_json.py profiles/r04/r04g_kloop_ablations_128x128.txt > profiles/r04/r04g_kloop_pipes.json
 
 Per K-tile time of a variant = (loop stamp at K = 2048 - loop stamp at K = 1024) / 16 K-tiles, tile 17 (8 waves); what is outside the loop comes
 from the K = 1024 launch of the unablated build: prologue + loop + epilogue stamps against kbench's launch time."""

@@ -2,7 +2,7 @@
 """Counter-backed bound per big launch: the PMC group passes of tools/gpu_session.sh pmc:<workload> (rocprofv3 --pmc in separate passes over bench.py, summed
 per dispatch by tools/rocpd_pmc.py) -> the JSON bench.py reads for `roofline.limited_by` / `roofline_kernels`.
 
-    python tools/pmc_bounds_json.py configs1=profiles/r04_pmc_groups_configs1.txt [configs3=...] > profiles/r04_kernel_bounds.json
+    python tools/pmc_bounds_json.py configs1=profiles/r04/r04_pmc_groups_configs1.txt [configs3=...] > profiles/r04/r04_kernel_bounds.json
 
 Per kernel symbol (launch averages):
   mfma_busy      SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs the launch's workgroups occupy x kernel cycles): share of the matrix pipes' time, on the CUs the

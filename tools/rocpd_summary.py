@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Summarise a rocprofv3 (ROCm 7.2 'rocpd' sqlite) kernel trace into a --stats style table.
 
-    python tools/rocpd_summary.py gpurun_out/prof_x/x_results.db > profiles/r01_x_kernel_stats.txt
+    python tools/rocpd_summary.py gpurun_out/prof_x/x_results.db > profiles/r01/r01_x_kernel_stats.txt
 """
 import re
 import sqlite3

@@ -2,7 +2,7 @@
 """PMC text of tools/evidence.sh (FETCH_SIZE / WRITE_SIZE sections per workload, made by tools/rocpd_pmc.py) -> the JSON bench.py reads
 for roofline.traffic, keyed by workload and by the kernel symbol names bench.py uses.
 
-    python tools/traffic_json.py profiles/r02_pmc_traffic.txt > profiles/r02_traffic.json
+    python tools/traffic_json.py profiles/r02/r02_pmc_traffic.txt > profiles/r02/r02_traffic.json
 
 gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports half the bytes of wide coalesced reads -> doubled here;
 WRITE_SIZE is taken as reported.  Values are per-launch averages over every launch of the symbol in the profiled run."""
