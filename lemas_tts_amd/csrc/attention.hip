@@ -34,7 +34,7 @@ namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-#ifdef LEMAS_PHASE_TIMESTAMPS      // measurement builds only (tools/kbench_phases.sh); compiled out of the product
+#ifdef LEMAS_PHASE_TIMESTAMPS      // measurement builds only (tools/kbench.py in a -DLEMAS_PHASE_TIMESTAMPS build); compiled out of the product
 #define ATTN_STAMP(k) do { if (p.dbg && threadIdx.x == 0 && blockIdx.x < 1024) p.dbg[blockIdx.x * 4 + (k)] = wall_clock64(); } while (0)
 #else
 #define ATTN_STAMP(k) do { } while (0)

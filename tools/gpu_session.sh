@@ -70,7 +70,7 @@ for step in "$@"; do
         python tools/rocpd_pmc.py "$(find $d -name '*_results.db' | head -1)" $KSUB >> "$O/${TAG}_pmc_groups_$w.txt"
       done; tail -12 "$O/${TAG}_pmc_groups_$w.txt" ;;
     traffic)
-      w=${rest:-configs1}; : > "$O/${TAG}_pmc_traffic_$w.txt"
+      w=${rest:-configs1}; echo "### workload $w" > "$O/${TAG}_pmc_traffic_$w.txt"      # (the header tools/traffic_json.py keys on)
       for c in FETCH_SIZE WRITE_SIZE; do
         d=/tmp/pmc_${w}_$c; rm -rf $d
         (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c -d $d -- python $R/bench.py --workload $w --no-cpu-baseline --no-clock-power --no-phases --steps 1 --warmup 1 > /dev/null 2> /tmp/pmc_err.log) || tail -3 /tmp/pmc_err.log

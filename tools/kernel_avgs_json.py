@@ -29,7 +29,7 @@ def parse(path):
 
 
 def main(args):
-    out = {"_source": "rocprofv3 --kernel-trace --stats over bench.py (tools/evidence.sh): " + ", ".join(a.split("=")[1] for a in args)}
+    out = {"_source": "rocprofv3 --kernel-trace --stats over bench.py (tools/gpu_session.sh rocprof:<workload>): " + ", ".join(a.split("=")[1] for a in args)}
     for a in args:
         wl, path = a.split("=")
         out[wl] = parse(path)

@@ -7,7 +7,7 @@ the buffer holds the LAST step's stamps.  Prints, for one DiT block in the middl
 and ended, and over all blocks the in-situ duration per kernel, the gaps between consecutive launches of a lane and how much of the
 step has 0 / 1 / 2 of the stamped launches in flight.
 
-    /usr/local/graft/bin/gpurun --timeout 900 -- 'bash tools/timeline_step.sh'      (builds the measurement library, runs this, rebuilds the product)
+    /usr/local/graft/bin/gpurun --timeout 900 -- 'bash tools/gpu_session.sh timeline:configs1,configs3'      (builds the measurement library, runs this, rebuilds the product)
 """
 import argparse
 import ctypes as C

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""PMC text of tools/evidence.sh (FETCH_SIZE / WRITE_SIZE sections per workload, made by tools/rocpd_pmc.py) -> the JSON bench.py reads
+"""PMC text of tools/gpu_session.sh traffic:<workload> (FETCH_SIZE / WRITE_SIZE sections per workload, made by tools/rocpd_pmc.py) -> the JSON bench.py reads
 for roofline.traffic, keyed by workload and by the kernel symbol names bench.py uses.
 
     python tools/traffic_json.py profiles/r02/r02_pmc_traffic.txt > profiles/r02/r02_traffic.json
