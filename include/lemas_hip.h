@@ -19,6 +19,10 @@
  *                                              called per sample at lemas_tts/model/cfm.py:248-262
  *   lemas_stft_create/forward/inverse       <- uvr5/multiprocess_cuda_infer.py:206-223 Inference.stft / .istft (the torch.stft /
  *                                              torch.istft pair around the MDX-Net prompt denoiser; tts_multilingual.py:38-86)
+ *   lemas_mdx_create/load_weight/finalize   <- uvr5/multiprocess_cuda_infer.py:225-238 Inference.load_model (the onnxruntime session built
+ *                                              from Kim_Vocal_1.onnx, an export of uvr5/lib_v5/mdxnet.py:36-101 ConvTDFNet)
+ *   lemas_mdx_forward                       <- uvr5/multiprocess_cuda_infer.py:262-272 model_run inside Inference.run_model, i.e.
+ *                                              uvr5/lib_v5/mdxnet.py:103-127 ConvTDFNet.forward
  * Single-kernel entry points for the parity tests and micro-benchmarks (lemas_k_*) are declared in lemas_hip_test.h; they
  * live in a separate library, liblemas_hip_test.so, and are not part of the drop-in surface.
  *
@@ -213,6 +217,38 @@ int32_t lemas_stft_ld(const lemas_stft* m);
 int64_t lemas_stft_frames(const lemas_stft* m, int64_t samples);
 int lemas_stft_forward(lemas_stft* m, const float* wav, int32_t batch, int32_t samples, float* spec, void* stream);
 int lemas_stft_inverse(lemas_stft* m, const float* spec, int32_t batch, int32_t frames, float* wav, void* stream);
+
+/* ---- the MDX-Net separation network of the UVR5 prompt denoiser: ConvTDFNet (uvr5/lib_v5/mdxnet.py:36-127, blocks
+ * uvr5/lib_v5/modules.py:5-74), which the reference runs as an onnxruntime session (uvr5/multiprocess_cuda_infer.py:225-238,262-272).
+ * Configuration = the constructor arguments of ConvTDFNet that shape the network (mdxnet.py:37-49).  Weight names = the state-dict keys of
+ * that module ("first_conv.0.weight", "encoding_blocks.0.tfc.H.0.1.running_var", "ds.0.0.weight", "us.0.0.weight", "final_conv.0.bias"
+ * ...), strict: unknown names are refused, finalize() names the first missing one; `window`, `freq_pad` and `*.num_batches_tracked` are
+ * accepted and ignored (forward never reads them).  Inference only: BatchNorm uses its running statistics (eps 1e-5).
+ *   forward: spek device [batch, dim_c, dim_f, dim_t] fp32 (frames innermost, what Inference.stft returns) -> out, same shape.
+ * All arithmetic is fp32 (f32-input MFMA); workspaces grow to the largest batch seen (~0.75 GB per sample at the Kim_Vocal_1 shape). ---- */
+typedef struct lemas_mdx lemas_mdx;
+typedef struct lemas_mdx_config {
+  int32_t dim_c;        /* 4: (left re, left im, right re, right im) */
+  int32_t dim_f;        /* frequency bins kept (3072); must be divisible by 2^(num_blocks/2), and by 4 after that division if bn >= 0 */
+  int32_t dim_t;        /* frames per chunk (256); divisible by 2^(num_blocks/2) */
+  int32_t num_blocks;   /* 11: n = num_blocks / 2 encoder and decoder stages around the bottleneck */
+  int32_t l;            /* convolutions per TFC (3) */
+  int32_t g;            /* channel growth per stage (48) */
+  int32_t k;            /* TFC kernel size; only 3 is built */
+  int32_t bn;           /* TDF bottleneck factor: f -> f / bn -> f; 0: a single Linear(f, f); -1: no TDF branch (the reference's None) */
+  int32_t bias;         /* TDF linears carry a bias */
+  int32_t norm;         /* 0: BatchNorm2d (optimizer 'rmsprop', folded into the convolutions); 1: GroupNorm(2, c) (optimizer 'adamw') */
+} lemas_mdx_config;
+int lemas_mdx_create(const lemas_mdx_config* cfg, lemas_mdx** out);
+void lemas_mdx_destroy(lemas_mdx* m);
+int lemas_mdx_load_weight(lemas_mdx* m, const char* name, const float* host_data, const int64_t* shape, int32_t ndim);
+int lemas_mdx_finalize(lemas_mdx* m);
+int lemas_mdx_forward(lemas_mdx* m, const float* spek, int32_t batch, float* out, void* stream);
+/* Verification hook: the next forwards also copy the activation after stage `name` ("first", "enc<i>", "ds<i>", "bottleneck", "us<i>",
+ * "dec<i>"; [batch, c, t, f]) to `dev_out` (device, caller-sized); NULL removes the tap. */
+int lemas_mdx_tap(lemas_mdx* m, const char* name, float* dev_out);
+/* multiply-add FLOPs (2 per MAC) of one forward at `batch`: the algorithmic work of the roofline line */
+int64_t lemas_mdx_flops(const lemas_mdx* m, int32_t batch);
 
 /* ---- prosody encoder (ECAPA-TDNN), the prompt's global prosody embedding ----
  * Architecture numbers = the reference's pretssel_cfg.json "model.prosody_*" keys (prosody_encoder.py:390-403). */

@@ -30,6 +30,11 @@ class ProsodyConfig(C.Structure):
                 ("global_context", C.c_int32), ("embed_dim", C.c_int32), ("input_dim", C.c_int32)]
 
 
+class MdxConfig(C.Structure):
+    """lemas_mdx_config (include/lemas_hip.h): the constructor arguments of the reference's ConvTDFNet (uvr5/lib_v5/mdxnet.py:37-49)."""
+    _fields_ = [(n, C.c_int32) for n in ("dim_c", "dim_f", "dim_t", "num_blocks", "l", "g", "k", "bn", "bias", "norm")]
+
+
 class SampleArgs(C.Structure):
     _fields_ = [
         ("struct_size", C.c_uint32),
@@ -116,6 +121,13 @@ def lib():
         "lemas_stft_frames": (C.c_int64, [vp, C.c_int64]),
         "lemas_stft_forward": (C.c_int, [vp, vp, i32, i32, vp, vp]),
         "lemas_stft_inverse": (C.c_int, [vp, vp, i32, i32, vp, vp]),
+        "lemas_mdx_create": (C.c_int, [C.POINTER(MdxConfig), C.POINTER(vp)]),
+        "lemas_mdx_destroy": (None, [vp]),
+        "lemas_mdx_load_weight": (C.c_int, [vp, C.c_char_p, vp, C.POINTER(i64), i32]),
+        "lemas_mdx_finalize": (C.c_int, [vp]),
+        "lemas_mdx_forward": (C.c_int, [vp, vp, i32, vp, vp]),
+        "lemas_mdx_tap": (C.c_int, [vp, C.c_char_p, vp]),
+        "lemas_mdx_flops": (C.c_int64, [vp, i32]),
     }
     _bind(L, sig)
     _lib = L
@@ -177,6 +189,7 @@ EXPORTED = [      # include/lemas_hip.h: the product library
     "lemas_prosody_create", "lemas_prosody_destroy", "lemas_prosody_load_weight", "lemas_prosody_finalize", "lemas_prosody_fbank_frames",
     "lemas_prosody_fbank", "lemas_prosody_encode",
     "lemas_stft_create", "lemas_stft_destroy", "lemas_stft_ld", "lemas_stft_frames", "lemas_stft_forward", "lemas_stft_inverse",
+    "lemas_mdx_create", "lemas_mdx_destroy", "lemas_mdx_load_weight", "lemas_mdx_finalize", "lemas_mdx_forward", "lemas_mdx_tap", "lemas_mdx_flops",
 ]
 EXPORTED_TEST = [  # include/lemas_hip_test.h: the test library
     "lemas_k_linear_bf16", "lemas_k_linear_f32", "lemas_k_attention", "lemas_k_attention_variant", "lemas_k_ln_mod", "lemas_k_convpos", "lemas_k_bench", "lemas_k_gemm_epi",

@@ -376,6 +376,9 @@ enum F32Epi : int {
   F32_BIAS_ADD2 = 4,   // out[m] = acc + bias? + add[m] and out[m + M] = acc + add[m + M]  (input-proj x-part broadcast to cond/uncond)
   F32_BIAS_RELU = 5,   // out = max(acc + bias, 0)         (prosody encoder TDNN / SE)
   F32_BIAS_SIGMOID = 6,  // out = 1 / (1 + exp(-(acc + bias)))  exact expf (SE gate)
+  F32_ROWAFF_RELU = 7,     // out = max(rowscale[ch] * (acc + bias) + rowshift[ch], 0), ch = (m / rows_per_ch) % nch: a Linear over the last axis
+                           // of [b, c, t, f] followed by an inference BatchNorm2d over c (MDX-Net TDF, uvr5/lib_v5/modules.py:61-70)
+  F32_ROWAFF_RELU_RES = 8, // the same + res[m, n]  (x + tdf(x), modules.py:74)
 };
 struct GemmF32Params {
   const float* A; int lda;   // [M, K]
@@ -393,5 +396,31 @@ struct GemmF32Params {
   const float* const* Wv;
   const float* const* biasv;
   size_t out_bstride;
+  // F32_ROWAFF_*: per-row-group affine (null rowscale => 1, 0)
+  const float* rowscale;
+  const float* rowshift;
+  int rows_per_ch, nch;
 };
 hipError_t launch_gemm_f32(int epi, const GemmF32Params& p, hipStream_t s);
+
+// ---- UVR5 MDX-Net (mdx_kernels.hip): planar [b][c][t][f] fp32, implicit-GEMM convolutions on the f32 MFMA --------------------------
+enum MdxConvKind : int { MDX_CONV3 = 0 /* 3x3 s1 p1 */, MDX_DOWN2 = 1 /* 2x2 s2 */, MDX_UP2 = 2 /* transposed 2x2 s2 (+ skip product) */ };
+struct MdxConvParams {
+  const float* x;        // [B][Cin][Ti][Fi]
+  const float* w;        // re-laid weights [ntiles][nchunks][8][mdx_conv_ciw(kind)] (norm folded in)
+  const float* bias;     // [Cout] (norm folded in)
+  float* out;            // CONV3 / DOWN2: [B][Cout][Tg][Fg]; UP2: [B][Cout][2 Tg][2 Fg]
+  const float* skip;     // UP2: multiplied into the result (same shape as out) or null
+  int B, Cin, Cout;
+  int Ti, Fi;            // input image
+  int Tg, Fg;            // GEMM position grid: the output image (CONV3, DOWN2) or the input image (UP2)
+  int nchunks, ntiles;   // ceil(Cin / 8); ceil(columns / 48), columns = Cout (UP2: 4 Cout)
+  int relu;
+};
+hipError_t launch_mdx_conv(int kind, const MdxConvParams& p, hipStream_t s);
+int mdx_conv_ciw(int kind);
+hipError_t launch_mdx_first(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout, int F, int T, int relu,
+                            hipStream_t s);
+hipError_t launch_mdx_final(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout, int F, int T, hipStream_t s);
+hipError_t launch_mdx_groupnorm(const float* x, int ld, int cols, int B, int C, int T, const float* gamma, const float* beta, float eps,
+                                const float* other, int mode, float* out, double* part, float* stats, hipStream_t s);

@@ -155,6 +155,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Params p) {
     if (EPI == F32_BIAS_RES_SCALE) v = p.res[(size_t)m * p.ldres + n] + cs * v;
     return v;
   };
+  (void)finish;
   const bool vec_ok = (p.ldc & 3) == 0 && (reinterpret_cast<size_t>(outz) & 15) == 0 &&
                       (EPI != F32_BIAS_ADD2 || (reinterpret_cast<size_t>(p.add) & 15) == 0);
 #pragma unroll
@@ -162,6 +163,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Params p) {
     const int m = m0 + wm * (TM / 2) + i * 16 + l15;
     if (m >= p.M) continue;
     const bool masked = EPI != F32_BIAS_ADD2 && p.rowmask && p.rowmask[m];
+    constexpr bool ROWAFF = EPI == F32_ROWAFF_RELU || EPI == F32_ROWAFF_RELU_RES;
+    float rs = 1.f, rh = 0.f;
+    if (ROWAFF && p.rowscale) {
+      const int ch = (m / p.rows_per_ch) % p.nch;
+      rs = p.rowscale[ch]; rh = p.rowshift[ch];
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int nb = n0 + wn * 32 + j * 16 + lk * 4;
@@ -173,7 +180,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Params p) {
         const bool in = n < p.N;
         const float bias = (biasz && in) ? biasz[n] : 0.f;
         const float cs = (EPI == F32_BIAS_RES_SCALE && p.colscale && in) ? p.colscale[n] : 1.f;
-        v[r] = in ? finish(acc[i][j][r], m, n, bias, cs) : 0.f;
+        if (ROWAFF) {
+          float t = fmaxf(fmaf(rs, acc[i][j][r] + bias, rh), 0.f);
+          if (EPI == F32_ROWAFF_RELU_RES && in) t += p.res[(size_t)m * p.ldres + n];
+          v[r] = in ? t : 0.f;
+        } else {
+          v[r] = in ? finish(acc[i][j][r], m, n, bias, cs) : 0.f;
+        }
         if (masked) v[r] = 0.f;
       }
       if (vec_ok && nb + 3 < p.N) {
@@ -232,6 +245,8 @@ hipError_t launch_gemm_f32(int epi, const GemmF32Params& p, hipStream_t s) {
     case F32_BIAS_ADD2: return launch<F32_BIAS_ADD2>(p, s);
     case F32_BIAS_RELU: return launch<F32_BIAS_RELU>(p, s);
     case F32_BIAS_SIGMOID: return launch<F32_BIAS_SIGMOID>(p, s);
+    case F32_ROWAFF_RELU: return launch<F32_ROWAFF_RELU>(p, s);
+    case F32_ROWAFF_RELU_RES: return launch<F32_ROWAFF_RELU_RES>(p, s);
   }
   return hipErrorInvalidValue;
 }

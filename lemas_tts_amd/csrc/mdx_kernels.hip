@@ -1,0 +1,410 @@
+// Kernels of the UVR5 MDX-Net separation network (ConvTDFNet), exact fp32 on the f32-input matrix cores (gfx950).
+//
+// Activations are planar [b][c][t][f] fp32 with the frequency axis innermost -- the reference's own layout after its transpose
+// (uvr5/lib_v5/mdxnet.py:107), so the TDF linears over f (modules.py:55-70) are plain row-major GEMMs (gemm_f32.hip) and nothing is ever
+// re-laid out.  The convolutions are implicit GEMMs
+//     D[co][position] = sum over (tap, ci) of  W[co][ci][tap] . x[ci][position + tap]
+// with positions as the MFMA's 16 columns (16 consecutive f of one t: 64-B coalesced stores) and output channels as its 16 rows:
+//   * one workgroup = 4 waves = 4 consecutive t rows x TF = 16 MT consecutive f x 48 output channels (MT x 3 accumulator tiles per wave);
+//   * K runs over chunks of 8 input channels; per chunk the workgroup stages the INPUT HALO ((3 S + KH) rows x ((TF-1) S + KW) columns per
+//     channel) and the 8 x taps x 48 weight slab in LDS once, and all KH x KW taps read their operands from that one halo: activations cross
+//     L2 -> LDS once per chunk, not once per tap (a 3 x 3 im2col GEMM moves 9x the bytes; this kernel's L2 pull is ~4 B/clk/CU against the
+//     ~11 B/clk a CU gets);
+//   * operands are fetched with ds_read_b32 (32 banks, two 32-lane groups): the 16 lanes of a k-group read 16 consecutive words, the second
+//     k-group of a 32-lane group sits one channel plane away, and planes / weight rows are padded to == 16 (mod 32) words, so reads are
+//     conflict-free.  An f32 MFMA 16x16x4 occupies the pipe for 32 cycles: MT + 3 operand reads feed 3 MT of them, LDS is far from a limit;
+//   * two LDS buffers: the global loads of chunk k + 1 are issued before chunk k is multiplied and parked after it, one barrier per chunk.
+// Inference BatchNorm (mdxnet.py:52) is folded into the weights and bias when the engine finalizes; ReLU is the epilogue.  Three geometries
+// share the body: 3 x 3 stride 1 pad 1 (TFC, modules.py:12), 2 x 2 stride 2 (the encoder's down-sampling, mdxnet.py:74) and the transposed
+// 2 x 2 stride 2 (mdxnet.py:90) as a 1 x 1 "convolution" onto 4 Cout columns ordered (co, dt, df): a lane then owns the whole 2 x 2 output
+// patch of one (co, position), multiplies it with the skip tensor (mdxnet.py:117) and stores two float2.
+#include "common.h"
+
+namespace {
+
+constexpr int NTW = 48;        // output columns per workgroup (3 MFMA tiles)
+constexpr int CK = 8;          // input channels per K chunk
+
+template <int KH, int S, int PAD, int MT>
+struct Geom {
+  static constexpr int KW = KH, TAPS = KH * KW, TF = 16 * MT;
+  static constexpr int ROWS = 3 * S + KH;                                  // 4 output rows
+  static constexpr int LEAD = PAD > 0 ? 4 : 0;                             // the halo starts LEAD columns left of the tile: 16-B aligned loads
+  static constexpr int ROWP = ((TF - 1) * S + KW - PAD + LEAD + 3) & ~3;
+  static constexpr int COL0 = LEAD - PAD;
+  static constexpr int PLANE0 = ROWS * ROWP;
+  static constexpr int PLANE = PLANE0 + ((16 - PLANE0 % 32) + 32) % 32;    // == 16 (mod 32): the two k-groups of a lane group on disjoint banks
+  static constexpr int CIW0 = TAPS * NTW;
+  static constexpr int CIW = CIW0 + ((16 - CIW0 % 32) + 32) % 32;
+  static constexpr int Q = ROWP / 4;
+  static constexpr int A_F4 = CK * ROWS * Q, W_F4 = CK * CIW / 4;
+  static constexpr int A_IT = (A_F4 + 255) / 256, W_IT = (W_F4 + 255) / 256;
+};
+
+template <int KH, int S, int PAD, int MT, bool UP>
+__global__ __launch_bounds__(256) void mdx_conv_kernel(const MdxConvParams p) {
+  using G = Geom<KH, S, PAD, MT>;
+  __shared__ __attribute__((aligned(16))) float As[2][CK * G::PLANE];
+  __shared__ __attribute__((aligned(16))) float Ws[2][CK * G::CIW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lk = lane >> 4;
+  const int f0 = blockIdx.x * G::TF, t0 = blockIdx.y * 4;
+  const int b = blockIdx.z / p.ntiles, nt = blockIdx.z % p.ntiles;
+  const float* xb = p.x + (size_t)b * p.Cin * p.Ti * p.Fi;
+  const float* wt = p.w + (size_t)nt * p.nchunks * (CK * G::CIW);
+  const bool vec = (p.Fi & 3) == 0;
+
+  // loader slots: constant over the K loop except for the channel
+  int a_off[G::A_IT];          // element offset inside one channel plane of x (clamped to 0 when outside)
+  int a_lds[G::A_IT];
+  int a_ci[G::A_IT];
+  unsigned a_ok = 0;           // bit it*4 + e: element e of slot it is inside the image (vector path: all four or none)
+#pragma unroll
+  for (int it = 0; it < G::A_IT; ++it) {
+    const int idx = tid + it * 256;
+    const int ci = idx / (G::ROWS * G::Q), rem = idx % (G::ROWS * G::Q), r = rem / G::Q, q = rem % G::Q;
+    const int tin = t0 * S - PAD + r, fin = f0 * S - G::LEAD + 4 * q;
+    const bool in = idx < G::A_F4 && tin >= 0 && tin < p.Ti;
+    a_ci[it] = idx < G::A_F4 ? ci : -1;
+    a_lds[it] = ci * G::PLANE + r * G::ROWP + 4 * q;
+    a_off[it] = 0;
+    if (in) {
+      if (vec) {
+        if (fin >= 0 && fin < p.Fi) { a_ok |= 0xFu << (4 * it); a_off[it] = tin * p.Fi + fin; }
+      } else {
+        a_off[it] = tin * p.Fi + fin;      // per-element tests below
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (fin + e >= 0 && fin + e < p.Fi) a_ok |= 1u << (4 * it + e);
+      }
+    }
+  }
+  const size_t plane = (size_t)p.Ti * p.Fi;
+  f32x4 ra[G::A_IT], rw[G::W_IT];
+  const f32x4 zv = {0.f, 0.f, 0.f, 0.f};
+
+  auto gload = [&](int chunk) {
+#pragma unroll
+    for (int it = 0; it < G::A_IT; ++it) {
+      const int cig = chunk * CK + a_ci[it];
+      const bool cok = a_ci[it] >= 0 && cig < p.Cin;
+      const float* src = xb + (cok ? (size_t)cig * plane : 0);
+      if (vec) {
+        ra[it] = *reinterpret_cast<const f32x4*>(src + a_off[it]);           // always a valid address; zeroed at the park if outside
+        if (!cok) ra[it] = zv;
+      } else {
+        f32x4 v = zv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (cok && (a_ok >> (4 * it + e) & 1)) v[e] = src[a_off[it] + e];
+        ra[it] = v;
+      }
+    }
+    const f32x4* wsrc = reinterpret_cast<const f32x4*>(wt + (size_t)chunk * (CK * G::CIW));
+#pragma unroll
+    for (int it = 0; it < G::W_IT; ++it) {
+      const int idx = tid + it * 256;
+      rw[it] = idx < G::W_F4 ? wsrc[idx] : zv;
+    }
+  };
+  auto park = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < G::A_IT; ++it) {
+      if (a_ci[it] < 0) continue;
+      f32x4 v = ra[it];
+      if (vec && !(a_ok >> (4 * it) & 1)) v = zv;
+      *reinterpret_cast<f32x4*>(&As[buf][a_lds[it]]) = v;
+    }
+#pragma unroll
+    for (int it = 0; it < G::W_IT; ++it) {
+      const int idx = tid + it * 256;
+      if (idx < G::W_F4) *reinterpret_cast<f32x4*>(&Ws[buf][idx * 4]) = rw[it];
+    }
+  };
+
+  f32x4 acc[MT][3];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[i][j] = zv;
+
+  const int a_base = lk * G::PLANE + (wave * S) * G::ROWP + l15 * S + G::COL0;
+  const int w_base = lk * G::CIW + l15;
+
+  gload(0);
+  park(0);
+  __syncthreads();
+  for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+    const int cur = chunk & 1;
+    if (chunk + 1 < p.nchunks) gload(chunk + 1);
+    const float* A = &As[cur][a_base];
+    const float* W = &Ws[cur][w_base];
+#pragma unroll
+    for (int tap = 0; tap < G::TAPS; ++tap) {
+      const int dt = tap / G::KW, df = tap % G::KW;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        float av[MT], bv[3];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) av[i] = A[kk * 4 * G::PLANE + dt * G::ROWP + i * 16 * S + df];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) bv[j] = W[kk * 4 * G::CIW + tap * NTW + j * 16];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[j], av[i], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (chunk + 1 < p.nchunks) park(cur ^ 1);
+    __syncthreads();
+  }
+
+  // D rows = output columns n = nt * 48 + j * 16 + lk * 4 + r, D columns = positions (lane & 15)
+  const int t = t0 + wave;
+  if (t >= p.Tg) return;
+  if (!UP) {
+    float* ob = p.out + (size_t)b * p.Cout * p.Tg * p.Fg;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = nt * NTW + j * 16 + lk * 4 + r;
+        if (co >= p.Cout) continue;
+        const float bias = p.bias[co];
+        float* orow = ob + ((size_t)co * p.Tg + t) * p.Fg;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int f = f0 + i * 16 + l15;
+          if (f >= p.Fg) continue;
+          float v = acc[i][j][r] + bias;
+          if (p.relu) v = fmaxf(v, 0.f);
+          orow[f] = v;
+        }
+      }
+  } else {
+    const int To = 2 * p.Tg, Fo = 2 * p.Fg;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int co = nt * (NTW / 4) + j * 4 + lk;
+      if (co >= p.Cout) continue;
+      const float bias = p.bias[co];
+      const size_t cb = ((size_t)b * p.Cout + co) * To;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int f = f0 + i * 16 + l15;
+        if (f >= p.Fg) continue;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const size_t o = (cb + 2 * t + dt) * Fo + 2 * f;
+          float v0 = acc[i][j][dt * 2] + bias, v1 = acc[i][j][dt * 2 + 1] + bias;
+          if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+          if (p.skip) {
+            const float2 s = *reinterpret_cast<const float2*>(p.skip + o);
+            v0 *= s.x; v1 *= s.y;
+          }
+          *reinterpret_cast<float2*>(p.out + o) = make_float2(v0, v1);
+        }
+      }
+    }
+  }
+}
+
+template <int KH, int S, int PAD, bool UP>
+hipError_t launch_geom(const MdxConvParams& p, hipStream_t s) {
+  // wider position tiles while they still give the chip ~2 workgroups per CU; the narrow ones for the deep, small levels
+  auto wgs = [&](int mt) { return (long)((p.Fg + 16 * mt - 1) / (16 * mt)) * ((p.Tg + 3) / 4) * p.B * p.ntiles; };
+  constexpr int MAXMT = (S == 2) ? 2 : 4;        // the stride-2 halo of a 64-wide tile would not fit the static 64 KB of LDS
+  int mt = MAXMT;
+  while (mt > 1 && wgs(mt) < 512) mt >>= 1;
+  const dim3 grid((p.Fg + 16 * mt - 1) / (16 * mt), (p.Tg + 3) / 4, p.B * p.ntiles);
+  if (grid.y > 65535 || grid.z > 65535) return hipErrorInvalidValue;
+  if (mt == 4) {
+    if constexpr (MAXMT >= 4) hipLaunchKernelGGL((mdx_conv_kernel<KH, S, PAD, 4, UP>), grid, dim3(256), 0, s, p);
+  } else if (mt == 2) {
+    hipLaunchKernelGGL((mdx_conv_kernel<KH, S, PAD, 2, UP>), grid, dim3(256), 0, s, p);
+  } else {
+    hipLaunchKernelGGL((mdx_conv_kernel<KH, S, PAD, 1, UP>), grid, dim3(256), 0, s, p);
+  }
+  return hipGetLastError();
+}
+
+// ---- first 1x1 convolution (+ folded norm, ReLU) with the transpose of mdxnet.py:105-107: [b][ci][f][t] -> [b][co][t][f] ----------------
+constexpr int XT = 32;     // 32 x 32 (f, t) positions per workgroup
+
+__global__ __launch_bounds__(256) void mdx_first_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                        float* __restrict__ out, int Cin, int Cout, int F, int T, int relu) {
+  extern __shared__ float sm[];                    // [Cin][XT f][XT + 1 t] then the weights [Cout][Cin] and bias [Cout]
+  float* tile = sm;
+  float* wl = sm + Cin * XT * (XT + 1);
+  float* bl = wl + Cout * Cin;
+  const int f0 = blockIdx.x * XT, t0 = blockIdx.y * XT, b = blockIdx.z;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = threadIdx.x; i < Cout * Cin; i += 256) wl[i] = w[i];
+  for (int i = threadIdx.x; i < Cout; i += 256) bl[i] = bias[i];
+  const float* xb = x + (size_t)b * Cin * F * T;
+  for (int c = 0; c < Cin; ++c)
+    for (int r = ty; r < XT; r += 8) {             // row = f, lanes along t (contiguous in the input)
+      const int f = f0 + r, t = t0 + tx;
+      tile[(c * XT + r) * (XT + 1) + tx] = (f < F && t < T) ? xb[((size_t)c * F + f) * T + t] : 0.f;
+    }
+  __syncthreads();
+  float* ob = out + (size_t)b * Cout * T * F;
+  for (int r = ty; r < XT; r += 8) {               // row = t, lanes along f (contiguous in the output)
+    const int t = t0 + r, f = f0 + tx;
+    if (t >= T || f >= F) continue;
+    float xv[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) xv[c] = c < Cin ? tile[(c * XT + tx) * (XT + 1) + r] : 0.f;
+    for (int co = 0; co < Cout; ++co) {
+      float v = bl[co];
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        if (c < Cin) v = fmaf(wl[co * Cin + c], xv[c], v);
+      if (relu) v = fmaxf(v, 0.f);
+      ob[((size_t)co * T + t) * F + f] = v;
+    }
+  }
+}
+
+// ---- last 1x1 convolution with the transpose back (mdxnet.py:121-125): [b][ci][t][f] -> [b][co][f][t], co <= 8 ---------------------------
+__global__ __launch_bounds__(256) void mdx_final_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                        float* __restrict__ out, int Cin, int Cout, int F, int T) {
+  extern __shared__ float sm[];                    // [Cout][XT t][XT + 1 f] then the weights [Cout][Cin]
+  float* tile = sm;
+  float* wl = sm + Cout * XT * (XT + 1);
+  const int f0 = blockIdx.x * XT, t0 = blockIdx.y * XT, b = blockIdx.z;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = threadIdx.x; i < Cout * Cin; i += 256) wl[i] = w[i];
+  __syncthreads();
+  const float* xb = x + (size_t)b * Cin * T * F;
+  for (int r = ty; r < XT; r += 8) {               // row = t, lanes along f
+    const int t = t0 + r, f = f0 + tx;
+    float v[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) v[o] = o < Cout ? bias[o] : 0.f;
+    if (t < T && f < F)
+      for (int c = 0; c < Cin; ++c) {
+        const float xv = xb[((size_t)c * T + t) * F + f];
+#pragma unroll
+        for (int o = 0; o < 8; ++o)
+          if (o < Cout) v[o] = fmaf(wl[o * Cin + c], xv, v[o]);
+      }
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+      if (o < Cout) tile[(o * XT + r) * (XT + 1) + tx] = v[o];
+  }
+  __syncthreads();
+  float* ob = out + (size_t)b * Cout * F * T;
+  for (int o = 0; o < Cout; ++o)
+    for (int r = ty; r < XT; r += 8) {             // row = f, lanes along t
+      const int f = f0 + r, t = t0 + tx;
+      if (f < F && t < T) ob[((size_t)o * F + f) * T + t] = tile[(o * XT + tx) * (XT + 1) + r];
+    }
+}
+
+// ---- GroupNorm(2, c) (the 'adamw' variant, mdxnet.py:54-55): statistics, then normalise + ReLU (+ skip product / residual sum) -----------
+// x is a row matrix [b * c * t rows][ld] with `cols` valid columns; the rows of one (sample, group) are contiguous.
+constexpr int GN_SPLIT = 64;
+
+__global__ __launch_bounds__(256) void mdx_gn_partial_kernel(const float* __restrict__ x, int ld, int cols, long rows_per_group, double* __restrict__ part) {
+  const int grp = blockIdx.y, sp = blockIdx.x;
+  const long r0 = rows_per_group * sp / GN_SPLIT, r1 = rows_per_group * (sp + 1) / GN_SPLIT;
+  const float* base = x + (size_t)grp * rows_per_group * ld;
+  double s = 0.0, q = 0.0;
+  for (long r = r0 + (threadIdx.x >> 6); r < r1; r += 4) {
+    float fs = 0.f, fq = 0.f;                      // one row segment per wave pass in fp32, rows combined in double
+    for (int c = threadIdx.x & 63; c < cols; c += 64) {
+      const float v = base[(size_t)r * ld + c];
+      fs += v; fq = fmaf(v, v, fq);
+    }
+    s += fs; q += fq;
+  }
+  __shared__ double ss[256], sq[256];
+  ss[threadIdx.x] = s; sq[threadIdx.x] = q;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) { ss[threadIdx.x] += ss[threadIdx.x + o]; sq[threadIdx.x] += sq[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { part[((size_t)grp * GN_SPLIT + sp) * 2] = ss[0]; part[((size_t)grp * GN_SPLIT + sp) * 2 + 1] = sq[0]; }
+}
+
+__global__ void mdx_gn_final_kernel(const double* __restrict__ part, int ngroups, double count, float eps, float* __restrict__ stats) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= ngroups) return;
+  double s = 0.0, q = 0.0;
+  for (int i = 0; i < GN_SPLIT; ++i) { s += part[((size_t)g * GN_SPLIT + i) * 2]; q += part[((size_t)g * GN_SPLIT + i) * 2 + 1]; }
+  const double mean = s / count, var = fmax(q / count - mean * mean, 0.0);
+  stats[2 * g] = (float)mean;
+  stats[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// mode 0: y = relu(norm(x)); 1: y = relu(norm(x)) * other; 2: y = relu(norm(x)) + other.  `other` / `out` share x's [rows][ld] shape.
+__global__ __launch_bounds__(256) void mdx_gn_apply_kernel(const float* __restrict__ x, int ld, int cols, long rows, int C, int T,
+                                                           const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ other, int mode,
+                                                           float* __restrict__ out) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const long chan_row = row / T;                   // (b * C + c)
+  const int c = (int)(chan_row % C), bi = (int)(chan_row / C);
+  const int g = bi * 2 + (c >= C / 2 ? 1 : 0);
+  const float mean = stats[2 * g], rstd = stats[2 * g + 1], ga = gamma[c], be = beta[c];
+  for (int col = threadIdx.x & 63; col < cols; col += 64) {
+    const size_t o = (size_t)row * ld + col;
+    float v = fmaxf((x[o] - mean) * rstd * ga + be, 0.f);
+    if (mode == 1) v *= other[o];
+    if (mode == 2) v += other[o];
+    out[o] = v;
+  }
+}
+
+}  // namespace
+
+hipError_t launch_mdx_conv(int kind, const MdxConvParams& p, hipStream_t s) {
+  if (p.B <= 0 || p.Cin <= 0 || p.Cout <= 0 || p.Tg <= 0 || p.Fg <= 0 || p.nchunks <= 0 || p.ntiles <= 0) return hipErrorInvalidValue;
+  switch (kind) {
+    case MDX_CONV3: return launch_geom<3, 1, 1, false>(p, s);
+    case MDX_DOWN2: return launch_geom<2, 2, 0, false>(p, s);
+    case MDX_UP2: return launch_geom<1, 1, 0, true>(p, s);
+  }
+  return hipErrorInvalidValue;
+}
+
+// padded K-slab row length of the re-laid weights (floats per input channel): the engine builds [ntile][chunk][8][mdx_conv_ciw(kind)]
+int mdx_conv_ciw(int kind) {
+  switch (kind) {
+    case MDX_CONV3: return Geom<3, 1, 1, 1>::CIW;
+    case MDX_DOWN2: return Geom<2, 2, 0, 1>::CIW;
+    case MDX_UP2: return Geom<1, 1, 0, 1>::CIW;
+  }
+  return 0;
+}
+
+hipError_t launch_mdx_first(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout, int F, int T, int relu,
+                            hipStream_t s) {
+  if (Cin > 8 || Cin <= 0 || Cout <= 0) return hipErrorInvalidValue;
+  const size_t sm = ((size_t)Cin * XT * (XT + 1) + (size_t)Cout * Cin + Cout) * sizeof(float);
+  if (sm > 64 * 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(mdx_first_kernel, dim3((F + XT - 1) / XT, (T + XT - 1) / XT, B), dim3(256), sm, s, x, w, bias, out, Cin, Cout, F, T, relu);
+  return hipGetLastError();
+}
+
+hipError_t launch_mdx_final(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout, int F, int T, hipStream_t s) {
+  if (Cout > 8 || Cout <= 0 || Cin <= 0) return hipErrorInvalidValue;
+  const size_t sm = ((size_t)Cout * XT * (XT + 1) + (size_t)Cout * Cin) * sizeof(float);
+  if (sm > 64 * 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(mdx_final_kernel, dim3((F + XT - 1) / XT, (T + XT - 1) / XT, B), dim3(256), sm, s, x, w, bias, out, Cin, Cout, F, T);
+  return hipGetLastError();
+}
+
+hipError_t launch_mdx_groupnorm(const float* x, int ld, int cols, int B, int C, int T, const float* gamma, const float* beta, float eps,
+                                const float* other, int mode, float* out, double* part /* [B * 2 * 64 * 2] */, float* stats /* [B * 2 * 2] */,
+                                hipStream_t s) {
+  if ((C & 1) || B <= 0 || cols <= 0) return hipErrorInvalidValue;
+  const long rpg = (long)(C / 2) * T, rows = (long)B * C * T;
+  hipLaunchKernelGGL(mdx_gn_partial_kernel, dim3(GN_SPLIT, B * 2), dim3(256), 0, s, x, ld, cols, rpg, part);
+  hipLaunchKernelGGL(mdx_gn_final_kernel, dim3((B * 2 + 63) / 64), dim3(64), 0, s, part, B * 2, (double)rpg * cols, eps, stats);
+  hipLaunchKernelGGL(mdx_gn_apply_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, ld, cols, rows, C, T, stats, gamma, beta, other, mode, out);
+  return hipGetLastError();
+}

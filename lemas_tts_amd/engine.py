@@ -406,6 +406,67 @@ class StftEngine(_Streamed):
 _RESAMPLERS: dict = {}
 
 
+class MdxEngine(_Streamed):
+    """Owns one ``lemas_mdx``: the MDX-Net separation network of the UVR5 prompt denoiser (the reference's onnxruntime session,
+    ``uvr5/multiprocess_cuda_infer.py:225-238``; architecture ``uvr5/lib_v5/mdxnet.py:36-127``).
+
+    ``arch``: any object / mapping with the ConvTDFNet constructor arguments ``dim_c, dim_f, dim_t, num_blocks, l, g, k, bn, bias,
+    optimizer`` (``bn`` None = no TDF branch; ``optimizer`` 'rmsprop' -> BatchNorm2d, 'adamw' -> GroupNorm(2, c)).
+    ``state_dict``: the module's state dict (key names of the reference class; strict)."""
+
+    def __init__(self, arch, state_dict: dict, device="cuda:0"):
+        super().__init__(device)
+        get = (lambda k: arch[k]) if isinstance(arch, dict) else (lambda k: getattr(arch, k))
+        opt = get("optimizer")
+        if opt not in ("rmsprop", "adamw"):
+            raise ValueError(f"optimizer {opt!r}: the reference defines a norm only for 'rmsprop' and 'adamw' (mdxnet.py:51-55)")
+        bn = get("bn")
+        self.dim_c, self.dim_f, self.dim_t = int(get("dim_c")), int(get("dim_f")), int(get("dim_t"))
+        cfg = _lib.MdxConfig(self.dim_c, self.dim_f, self.dim_t, int(get("num_blocks")), int(get("l")), int(get("g")), int(get("k")),
+                             -1 if bn is None else int(bn), int(bool(get("bias"))), 1 if opt == "adamw" else 0)
+        L = _lib.lib()
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(L.lemas_mdx_create(C.byref(cfg), C.byref(self._h)), "lemas_mdx_create")
+            for name, v in state_dict.items():
+                _load(L.lemas_mdx_load_weight, self._h, name, v)
+            _lib.check(L.lemas_mdx_finalize(self._h), "lemas_mdx_finalize")
+        self._taps = {}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().lemas_mdx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def flops(self, batch: int = 1) -> int:
+        return int(_lib.lib().lemas_mdx_flops(self._h, batch))
+
+    def tap(self, name: str, buf: Optional[torch.Tensor]) -> None:
+        """Verification hook: copy the activation after stage ``name`` into ``buf`` on every following forward (None removes it)."""
+        self._taps[name] = buf
+        _lib.check(_lib.lib().lemas_mdx_tap(self._h, name.encode(), C.c_void_p(buf.data_ptr()) if buf is not None else None), "lemas_mdx_tap")
+
+    def forward(self, spek: torch.Tensor) -> torch.Tensor:
+        """[b, dim_c, dim_f, dim_t] fp32 -> the same shape (ConvTDFNet.forward, mdxnet.py:103-127)."""
+        if spek.ndim != 4 or tuple(spek.shape[1:]) != (self.dim_c, self.dim_f, self.dim_t):
+            raise ValueError(f"expected [b, {self.dim_c}, {self.dim_f}, {self.dim_t}], got {tuple(spek.shape)}")
+        with torch.cuda.device(self.device):
+            x = spek.to(self.device, torch.float32).contiguous()
+            out = torch.empty_like(x)
+            s = self._enter(x, out, *[t for t in self._taps.values() if t is not None])
+            _lib.check(_lib.lib().lemas_mdx_forward(self._h, x.data_ptr(), x.shape[0], out.data_ptr(), s), "lemas_mdx_forward")
+            self._exit()
+        return out
+
+    __call__ = forward
+
+
 def resampler(orig_freq: int, new_freq: int = 24000, device="cuda:0") -> "ResampleEngine":
     """One ResampleEngine per (orig, new, device): building one costs a fp64 kernel bank on the host, a hipMalloc and an
     H2D copy, which does not belong on the per-utterance latency path."""

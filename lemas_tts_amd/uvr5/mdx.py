@@ -95,20 +95,36 @@ class Inference:
         return wav.reshape(b, 2, self.chunk_size)
 
     # ---- the network ---------------------------------------------------------------------------------------------
-    def load_model(self, model_run, threads: int = 1, device=None):
-        """The reference builds an onnxruntime session from a path here (:226-240); this mirror takes the network as a callable."""
-        if isinstance(model_run, (str, os.PathLike)):
-            raise NotImplementedError(f"{model_run}: the MDX-Net is an ONNX file and there is no ONNX runtime for MI355X in this tree; "
-                                      "pass a callable model_run(spek[b, 4, dim_f, dim_t]) -> spec_pred")
-        if not callable(model_run):
-            raise TypeError("model_run must be callable")
-
-        def run(spek: torch.Tensor) -> torch.Tensor:
-            out = model_run(spek)
-            if isinstance(out, np.ndarray):
-                out = torch.from_numpy(out)
-            return out.to(self.device, torch.float32)
-        self.model_run = run
+    def load_model(self, model, threads: int = 1, device=None):
+        """The reference builds an onnxruntime session from ``model_path`` here (:225-240).  This mirror runs the network the ONNX file
+        was exported from -- ConvTDFNet, uvr5/lib_v5/mdxnet.py:36-127 -- on the HIP engine (``lemas_mdx_*``).  ``model`` is
+          * a path: ``*.onnx`` (initializers read by ``onnx_weights.load_onnx``, no onnx / onnxruntime package involved), or a state dict
+            of the module as ``*.safetensors`` / ``*.pt`` / ``*.ckpt`` / ``*.npz`` (hyper-parameters inferred from the tensor shapes);
+          * ``(arch, state_dict)``: the ConvTDFNet constructor arguments (object or dict, see ``MdxEngine``) and its state dict;
+          * a callable ``model_run(spek[b, 4, dim_f, dim_t]) -> spec_pred`` (tensor or numpy), used as is.
+        ``threads`` is the reference's onnxruntime intra-op thread count: meaningless here, accepted."""
+        if callable(model):
+            def run(spek: torch.Tensor) -> torch.Tensor:
+                out = model(spek)
+                if isinstance(out, np.ndarray):
+                    out = torch.from_numpy(out)
+                return out.to(self.device, torch.float32)
+            self.model_run = run
+            return
+        from ..engine import MdxEngine
+        from . import onnx_weights
+        if isinstance(model, (str, os.PathLike)):
+            arch, sd = onnx_weights.load_network_file(os.fspath(model), dim_t=self.dim_t)
+        elif isinstance(model, (tuple, list)) and len(model) == 2:
+            arch, sd = model
+        else:
+            raise TypeError("load_model: a path, an (arch, state_dict) pair or a callable")
+        get = (lambda k: arch[k]) if isinstance(arch, dict) else (lambda k: getattr(arch, k))
+        if (int(get("dim_c")), int(get("dim_f")), int(get("dim_t"))) != (self.dim_c, self.dim_f, self.dim_t):
+            raise ValueError(f"the network is built for [b, {get('dim_c')}, {get('dim_f')}, {get('dim_t')}] but the configuration cuts "
+                             f"[b, {self.dim_c}, {self.dim_f}, {self.dim_t}] spectrograms")
+        self.network = MdxEngine(arch, sd, device=self.device)
+        self.model_run = self.network.forward
 
     # ---- chunking (multiprocess_cuda_infer.py:243-258) -------------------------------------------------------------
     def initialize_mix(self, mix: torch.Tensor):
@@ -130,7 +146,11 @@ class Inference:
         else:
             if self.model_run is None:
                 raise RuntimeError("load_model() has not been given a network")
-            pred = (self.model_run(spek) - self.model_run(-spek)) * 0.5 if self.is_denoise else self.model_run(spek)
+            if self.is_denoise and getattr(self, "network", None) is not None:
+                both = self.model_run(torch.cat((spek, -spek), dim=0))          # the +- pair of :269 as one batch of the engine
+                pred = (both[:spek.shape[0]] - both[spek.shape[0]:]) * 0.5
+            else:
+                pred = (self.model_run(spek) - self.model_run(-spek)) * 0.5 if self.is_denoise else self.model_run(spek)
         wav = self.istft(pred)[:, :, self.trim:-self.trim]
         return wav.transpose(0, 1).reshape(2, -1)
 
