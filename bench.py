@@ -483,7 +483,7 @@ def main():
     ap.add_argument("--outlier-weights", type=int, default=0, help="1 = synthetic weights WITH outlier residual channels (1 %% of the channels x30 in every block's "
                     "residual-writing projections, synth.synth_cfm_state_dict(outlier=(0.01, 30))): what the fp8 path's outlier decomposition costs / buys; "
                     "the reference fixture does not apply to these weights (no parity check in the line)")
-    ap.add_argument("--fp8-outlier-mode", type=int, default=-1, help="engine option fp8_outlier_mode (-1 = default 1: mixed-precision decomposition; 0 = bf16)")
+    ap.add_argument("--fp8-outlier-mode", type=int, default=-1, help="engine option fp8_outlier_mode (-1 = leave the default, 0: every block GEMM on bf16 operands when the guard trips; 1 = the mixed-precision decomposition, measurement builds only)")
     ap.add_argument("--skip-dead", type=int, default=-1, help="engine option skip_dead (-1 = engine default 0: every sample of a ragged batch runs at "
                     "the batch's pitch, as in the reference; 1 = the 128-row blocks that lie wholly in a sample's padding are left uncomputed: "
                     "+12.6 %% on configs2, the last ~30 frames of a sample then differ from the reference's by 5e-6 instead of 2e-6 mel-MSE)")
@@ -760,11 +760,11 @@ def main():
                     continue
             return None, None
         wkey = a.workload + ("_fp8" if a.fp8 and a.workload != "configs4" else "")
-        traffic_e, traffic_src = committed(("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json"), wkey, dom)
+        traffic_e, traffic_src = committed(("r06_traffic.json", "r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json"), wkey, dom)
         traffic = traffic_e.get("hbm_bytes_per_launch") if traffic_e else None
-        rocprof_e, rocprof_src = committed(("r05_kernel_avgs.json", "r04_kernel_avgs.json", "r03_kernel_avgs.json"), wkey, dom)
+        rocprof_e, rocprof_src = committed(("r06_kernel_avgs.json", "r05_kernel_avgs.json", "r04_kernel_avgs.json", "r03_kernel_avgs.json"), wkey, dom)
         rocprof_us = rocprof_e.get("avg_us") if rocprof_e else None
-        bounds_all, bounds_src = committed(("r05_kernel_bounds.json", "r04_kernel_bounds.json"), wkey)
+        bounds_all, bounds_src = committed(("r06_kernel_bounds.json", "r05_kernel_bounds.json", "r04_kernel_bounds.json"), wkey)
         is_gemm = dom != "attn_fwd_splitkv_kernel"
         peak = MFMA_FP8_PEAK_TFLOPS if (a.fp8 and is_gemm) else MFMA_BF16_PEAK_TFLOPS   # attention stays bf16
         dom_bound = (bounds_all or {}).get(dom)
@@ -875,7 +875,7 @@ def main():
         L1 = e0 - s0                                                          # frames of the decode timed alone above
         nb1 = one_mel.shape[0]
         voc_bytes = nb1 * (400.0 * L1 + 1024.0 * (L1 - 1)) + wbytes           # weights + mel in + wav out
-        voc_traffic, voc_traffic_src = committed(("r05_traffic.json", "r04_traffic.json"), a.workload, "vocoder")
+        voc_traffic, voc_traffic_src = committed(("r06_traffic.json", "r05_traffic.json", "r04_traffic.json"), a.workload, "vocoder")
         voc_hbm = voc_traffic.get("hbm_bytes_per_decode") if voc_traffic else None
         # the decode is fp32 GEMM work (exact fp32 MFMA, 157.3 TFLOP/s dense: MI355X_MICROARCH.md "Peak FP32 (matrix)"), not a byte stream:
         # every weight matrix is applied once per frame, plus the windowed inverse rDFT as a GEMM against its (n_fft + 2) x n_fft basis

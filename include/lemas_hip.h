@@ -146,14 +146,12 @@ int lemas_dit_set_option(lemas_dit* m, const char* key, int64_t value);
  * whose residual-writing projections (attn.to_out, ff.2) show outlier output channels -- per-channel weight scale > 8x the median --
  * runs every block GEMM on its bf16 operands after all: such channels make the solve five to seven times more sensitive to e4m3 noise at
  * EVERY GEMM site (2.9e-4 mel-MSE at full depth / NFE 32 against the 1e-4 target; no single site stays under it with margin), so fp8 does
- * not ship for such weights.  0 = run fp8 regardless), "fp8_outlier_mode" (what a tripped guard does: 0 (default) = every block GEMM on bf16
- * operands; 1 = the mixed-precision decomposition: QKV, out-projection and FF2 stay on fp8 operands, FF1 runs on bf16, and the flagged output
- * channels (at most 32) of out-projection / FF2 are computed from bf16 operands by a side launch -- meets the 1e-4 target on the outlier
- * fixtures (8.4e-5 / 9.6e-5) with fp8 on three of the four sites, but is slower than 0 at the shapes measured), "fp8_sites" (mask of the GEMM sites of a block that take fp8 operands when
+ * not ship for such weights.  0 = run fp8 regardless; round 5's mixed-precision decomposition, option "fp8_outlier_mode", met the target
+ * but ran slower than this fallback and lives in measurement builds only since round 6), "fp8_sites" (mask of the GEMM sites of a block that take fp8 operands when
  * "fp8" = 1: 1 QKV, 2 out-projection, 4 FF1, 8 FF2; default 15).
  * counters since creation, for tools and tests: "graph_captures", "graph_instantiates", "graph_updates", "graph_update_failures",
  * "graph_evictions", "graph_buckets", "fp8_outlier_channels" (residual channels flagged by the guard; -1 before the first fp8 prepare),
- * "fp8_gemms_kept_bf16" (GEMMs per DiT block that run on bf16 operands while "fp8" = 1: 0; 4 when the guard tripped; 1 with "fp8_outlier_mode" 1) */
+ * "fp8_gemms_kept_bf16" (GEMMs per DiT block that run on bf16 operands while "fp8" = 1: 0; 4 when the guard tripped) */
 int lemas_dit_get_stat(lemas_dit* m, const char* key, int64_t* value);
 /* synchronises the device and returns 0, or LEMAS_E_STATE when a device-side wait of this engine gave up (fused LayerNorm tail):
  * every result since then is invalid and prepare() / solve() refuse to run */

@@ -70,7 +70,8 @@ struct lemas_dit {
   // text embedding) are not seen -- a first-contact item for real checkpoints.
   bool fp8_guard = true, fp8_guard_tripped = false;
   int fp8_outlier_channels = 0;
-  // option "fp8_outlier_mode" (round 5; default 0): 1 = when the guard trips on at most 32 channels, fp8 is NOT given up: QKV, out-projection and FF2
+  // option "fp8_outlier_mode" (round 5; default 0; MEASUREMENT BUILDS ONLY since round 6 -- slower than the bf16 fallback it replaces, 125 vs 136
+  // audio-s/s at configs[4], so the product does not carry it): 1 = when the guard trips on at most 32 channels, fp8 is NOT given up: QKV, out-projection and FF2
   // keep their fp8 operands (three of the four sites), FF1 runs on bf16 operands, and the flagged OUTPUT channels of out-projection / FF2 are
   // computed from bf16 operands by outlier_rows.hip (their rows of the e4m3 images and their biases are zeroed), which also writes the MXFP8 image
   // of its input rows for the fp8 GEMM of the site.  Accuracy against the reference's own outputs: 8.4e-5 at NFE 32 and 9.6e-5 on the 8-step
@@ -193,10 +194,11 @@ struct lemas_dit {
             &d_rope_sin, &d_len, &d_live, &d_sin, &d_h1, &d_temb, &d_st, &d_cond_eff, &d_step_cond, &d_pm, &d_pt, &d_te,
             &d_rowmask, &d_t1, &d_t2, &d_t3, &d_gx, &d_ct, &d_pconst, &d_y, &d_xres, &d_hbf, &d_q, &d_k, &d_vt,
             &d_abf, &d_ff, &d_cmid, &d_pred, &d_h8, &d_hmx, &d_a8, &d_amx, &d_ff8, &d_ffmx, &d_lncnt, &d_lnpart,
-            &d_foldA, &d_foldtmp, &d_foldsites, &d_foldparams, &d_zero};
+            &d_foldA, &d_foldtmp, &d_foldsites, &d_foldparams, &d_zero, &d_flagged};
   }
   static std::vector<DevBuf*> block_bufs(BlockW& b) {
-    return {&b.wqkv, &b.wo, &b.w1, &b.w2, &b.bqkv, &b.wqkv8, &b.wo8, &b.w18, &b.w28, &b.sqkv, &b.so, &b.s1, &b.s2, &b.wqkvq, &b.woq, &b.w1q, &b.w2q};
+    return {&b.wqkv, &b.wo, &b.w1, &b.w2, &b.bqkv, &b.wqkv8, &b.wo8, &b.w18, &b.w28, &b.sqkv, &b.so, &b.s1, &b.s2, &b.wqkvq, &b.woq, &b.w1q, &b.w2q,
+            &b.wo_side, &b.w2_side, &b.bo_side, &b.b2_side, &b.bo_z, &b.b2_z};
   }
   static void drop_bucket(GraphBucket& b) {
     for (auto& g : b.g) {
@@ -392,7 +394,10 @@ int lemas_dit::quantize_fp8() {
   }
   // mixed-precision decomposition for outlier checkpoints: side operands of the flagged channels, zeroed rows / biases for the fp8 GEMMs
   fp8_outlier_split = false;
-  if (fp8_guard && fp8_guard_tripped && fp8_outlier_mode && fp8_outlier_channels <= 32) {
+#ifdef LEMAS_MEASUREMENT_BUILD
+  // (outlier_rows.hip is built for K = 1024 and 2048 only: any other inner / FF width keeps the all-bf16 guard behaviour, decided BEFORE a row is zeroed)
+  const bool side_ok = (in == 1024 || in == 2048) && (ffd == 1024 || ffd == 2048);
+  if (fp8_guard && fp8_guard_tripped && fp8_outlier_mode && fp8_outlier_channels <= 32 && side_ok) {
     const int nf = fp8_outlier_channels;
     std::vector<int> pad(32, -1);
     for (int j = 0; j < nf; ++j) pad[j] = h_flagged[j];
@@ -419,6 +424,7 @@ int lemas_dit::quantize_fp8() {
     HIP_TRY(hipDeviceSynchronize());
     fp8_outlier_split = true;
   }
+#endif
   fp8_ready = true;
   return 0;
 }
@@ -528,6 +534,11 @@ int lemas_dit::finalize() {
     HIP_TRY(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    // the extra lanes of "lane_split" too: created here, never inside enqueue_forward(), which also runs under stream capture
+    for (int i = 0; i < MAX_LANES - 2; ++i) {
+      HIP_TRY(hipStreamCreateWithFlags(&sx[i], hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&ev_joinx[i], hipEventDisableTiming));
+    }
   }
   HIP_TRY(hipStreamSynchronize(s));
   tab_stride = fold_off(cfg.depth);
@@ -828,10 +839,7 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
   const bool fork = lanes >= 2 && !profile;
   hipStream_t st[MAX_LANES];
   for (int ln = 0; ln < lanes; ++ln) {
-    if (fork && ln >= 2 && !sx[ln - 2]) {
-      HIP_TRY(hipStreamCreateWithFlags(&sx[ln - 2], hipStreamNonBlocking));
-      HIP_TRY(hipEventCreateWithFlags(&ev_joinx[ln - 2], hipEventDisableTiming));
-    }
+    if (fork && ln >= 2 && !sx[ln - 2]) { set_error("lane streams are created by finalize(): call order"); return LEMAS_E_STATE; }
     st[ln] = !fork || ln == 0 ? s : ln == 1 ? s2 : sx[ln - 2];
   }
   const int bh = BB / lanes;                 // samples (branch-rows) per lane
@@ -1021,8 +1029,14 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
       o.A = A; o.W = wside.as<bf16_t>(); o.bias = bside.as<float>(); o.chan = d_flagged.as<int>(); o.nf = fp8_outlier_channels;
       o.x = xres; o.ldx = d; o.M = rows; o.K = K; o.tab = tab; o.tab_stride = tab_stride; o.gate_off = gate_off; o.step_idx = step;
       o.kv_len = kvl; o.seq_pitch = pitch; o.seq_valid = N; o.batch = len_batch; o.a8 = q8; o.amx = qmx;
+#ifdef LEMAS_MEASUREMENT_BUILD
       HIP_TRY(launch_outlier_rows(o, q));
       return 0;
+#else
+      (void)o;
+      set_error("the fp8 outlier decomposition exists in measurement builds only");
+      return LEMAS_E_STATE;
+#endif
     };
     TL_SLOT(at);
     RC_TRY(skew_pre(ln, q));
@@ -1341,7 +1355,7 @@ int lemas_dit_set_option(lemas_dit* m, const char* key, int64_t value) {
   }
 #endif
 #ifndef LEMAS_MEASUREMENT_BUILD
-  if (!strcmp(key, "ln_fused") || !strcmp(key, "lane_skew") || !strcmp(key, "xcd_runs") || !strcmp(key, "block_persist")) {
+  if (!strcmp(key, "ln_fused") || !strcmp(key, "lane_skew") || !strcmp(key, "xcd_runs") || !strcmp(key, "block_persist") || !strcmp(key, "fp8_outlier_mode")) {
     if (value == 0) return 0;       // "off" is what the product does anyway
     set_error("lemas_dit_set_option: '%s' is a measurement option -- its code exists only in builds of the library with -DLEMAS_MEASUREMENT_BUILD "
               "(LEMAS_EXTRA_HIPCC_FLAGS, lemas_tts_amd/build.py); the product library does not carry it", key);
@@ -1393,10 +1407,12 @@ int lemas_dit_set_option(lemas_dit* m, const char* key, int64_t value) {
     m->drop_graphs();
     return 0;
   }
-  if (!strcmp(key, "fp8_outlier_mode")) {       // 1 = mixed-precision decomposition on outlier checkpoints (default), 0 = every block GEMM on bf16 there
+#ifdef LEMAS_MEASUREMENT_BUILD
+  if (!strcmp(key, "fp8_outlier_mode")) {       // 0 (default) = every block GEMM on bf16 operands when the guard trips; 1 = the mixed-precision decomposition
     if (m->fp8_outlier_mode != (value != 0)) { m->fp8_outlier_mode = value != 0; m->fp8_ready = false; m->prepared = false; m->drop_graphs(); }
     return 0;
   }
+#endif
   if (!strcmp(key, "fp8_sites")) {
     if (value < 0 || value > 15) { set_error("lemas_dit_set_option: fp8_sites is a mask of GEMM sites (1 QKV, 2 out-projection, 4 FF1, 8 FF2), 0 .. 15"); return LEMAS_E_ARG; }
     m->fp8_sites_opt = (int)value;

@@ -375,6 +375,10 @@ int lemas_k_ln_mod_f8(const float* x, const float* scale, const float* shift, ui
 int lemas_k_outlier_rows(const float* A, const float* Wside, const float* bias_side, const int32_t* chan, int32_t nf, const float* gate,
                          const int32_t* seq_len, float* x, int32_t batch, int32_t frames, int32_t pitch, int32_t K, int32_t ldx, uint8_t* a8, uint8_t* amx,
                          void* stream) {
+#ifndef LEMAS_MEASUREMENT_BUILD
+  set_error("lemas_k_outlier_rows: csrc/outlier_rows.hip is compiled into measurement builds only (-DLEMAS_MEASUREMENT_BUILD)");
+  return LEMAS_E_STATE;
+#else
   hipStream_t s = (hipStream_t)stream;
   Scratch sc;
   const int M = batch * pitch;
@@ -397,6 +401,7 @@ int lemas_k_outlier_rows(const float* A, const float* Wside, const float* bias_s
   HIP_TRY(launch_outlier_rows(o, s));
   HIP_TRY(hipStreamSynchronize(s));
   return 0;
+#endif
 }
 
 int lemas_k_linear_f8(const float* A, const float* W, const float* bias, float* out, int32_t M, int32_t N, int32_t K, int32_t act,

@@ -707,98 +707,10 @@ constexpr int slab_bytes() {
                                                       : SlabBf16<WTM, WTN>::BYTES;
 }
 
-// ---------------------------------------------------------------- LayerNorm-modulate tail of the gate + residual GEMM
-// The AdaLN-modulated LayerNorm behind every gated residual update (modules.py:635-637, :639 -> the next block's :314, the final
-// :335) needs whole rows of x_res; a 128-column tile holds an eighth of one.  As its own launch it costs a lane's chain 9-13 us per
-// site (5 us of latency-bound kernel between two ~2 us dependent-launch boundaries: profiles/r02/r02_timeline_step.txt) for 0.4 % of the
-// FLOPs.  Here the GEMM launch finishes the job itself: the TILES_N workgroups that share a row panel meet at the panel's arrival
-// counter once their x_res tiles are out (write-through stores, drained by every wave before the one arrival per workgroup), and
-// each then normalises R = BM / TILES_N rows of the panel.  Visibility follows the recipe of the hardware guide (producer: sc1
-// payload stores -> s_waitcnt vmcnt(0) in every storing wave -> barrier -> relaxed agent-scope arrival; consumer: relaxed poll by
-// one lane -> barrier -> sc1 loads, which bypass this CU's L1; no XCD's L2 holds a line of x_res that another workgroup wrote in
-// this launch, because a workgroup only ever read the columns it then overwrote and sc1 stores drop the line).
-// Progress: a waiting workgroup depends only on workgroups of the SAME launch; the caller fuses only when all of them (and the
-// other lane's) fit the chip at once (gemm_bf16_ln_fusable), kernels that do not wait always drain, and the wait gives up after
-// ~50 ms with the sticky error word set instead of hanging the queue.
-typedef __attribute__((address_space(1))) unsigned int gu32;
-
-__device__ __forceinline__ void ln_load_row_sc1(const float* row, int lane, u32x4 (&v)[LN_PER][2]) {
-  static_assert(LN_PER == 2, "row image");
-  const char* p0 = reinterpret_cast<const char*>(row) + lane * 32;   // float4 index (lane + 64 i) * 2 + h -> byte lane * 32 + i * 2048 + h * 16
-  const char* p1 = p0 + 2048;
-  asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
-               "global_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
-               "global_load_dwordx4 %2, %5, off sc1\n\t"
-               "global_load_dwordx4 %3, %5, off offset:16 sc1"
-               : "=&v"(v[0][0]), "=&v"(v[0][1]), "=&v"(v[1][0]), "=&v"(v[1][1]) : "v"(p0), "v"(p1) : "memory");
-}
-// retire the asm loads above: the wait names every destination, so no consumer can be scheduled ahead of it
-__device__ __forceinline__ void ln_wait_row(u32x4 (&v)[LN_PER][2]) {
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0][0]), "+v"(v[0][1]), "+v"(v[1][0]), "+v"(v[1][1]) : : "memory");
-}
-
-// The option needs the device to itself: the co-residency estimate that enables it (engine_dit.hip: lanes x workgroups <= CUs x workgroups
-// per CU) knows nothing of other tenants (a second process sharing the GPU, CU masks, a side-stream kernel holding CUs).  It is off by default.
-template <int TBM, int TBN, int NW>
-__device__ __forceinline__ void ln_tail(const GemmParams& p, int m0, int n0, char* ln_lds) {
-  constexpr int TILES_N = LN_D / TBN, R = TBM / TILES_N, RW = R / NW;
-  static_assert(TILES_N * TBN == LN_D && R * TILES_N == TBM && RW * NW == R && RW >= 1, "rows of a panel must divide over its workgroups and waves");
-  constexpr int ROWS = RW >= 2 ? 2 : 1;     // rows in flight per wave (as the stand-alone kernel)
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tm = m0 / TBM, tn = n0 / TBN;
-  // publish this workgroup's x_res tile
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  gu32* cnt = (gu32*)(p.ln_cnt + tm);
-  if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  // the modulation vectors do not depend on the panel: in flight while the other tiles arrive
-  const float* base = p.tab + (size_t)p.step_idx[0] * p.tab_stride;
-  float4 a[LN_PER][2], b[LN_PER][2];
-  ln_load_vec(base + p.ln_scale_off, lane, a);
-  ln_load_vec(base + p.ln_shift_off, lane, b);
-  // `gave_up` travels through LDS (the ring is free by now): a workgroup whose wait timed out must NOT normalise rows of a panel that is
-  // incomplete -- it flags the engine (sticky, host-visible) and leaves ln_out alone
-  int* gave_up = reinterpret_cast<int*>(ln_lds);
-  if (tid == 0) {
-    unsigned spins = 0;
-    int fail = 0;
-    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)TILES_N) {
-      __builtin_amdgcn_s_sleep(8);
-      if (++spins > (1u << 16)) {
-        __hip_atomic_store((gu32*)p.ln_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        fail = 1;
-        break;
-      }
-    }
-    *gave_up = fail;
-  }
-  __syncthreads();
-  if (*gave_up) return;
-  const int row0 = m0 + tn * R + wave * RW;
-#pragma unroll
-  for (int r = 0; r < RW; r += ROWS) {
-    u32x4 raw[ROWS][LN_PER][2];
-#pragma unroll
-    for (int q = 0; q < ROWS; ++q) {
-      int row = row0 + r + q;
-      row = row < p.M ? row : p.M - 1;
-      ln_load_row_sc1(p.out_f32 + (size_t)row * LN_D, lane, raw[q]);
-    }
-#pragma unroll
-    for (int q = 0; q < ROWS; ++q) ln_wait_row(raw[q]);
-#pragma unroll
-    for (int q = 0; q < ROWS; ++q) {
-      float4 v[LN_PER][2];
-#pragma unroll
-      for (int i = 0; i < LN_PER; ++i)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) v[i][h] = __builtin_bit_cast(float4, raw[q][i][h]);
-      const int row = row0 + r + q;
-      ln_row_store(v, a, b, p.ln_out + (size_t)row * LN_D, lane, row < p.M);
-    }
-  }
-}
+// (measurement builds only: the LayerNorm-modulate tail of the gate + residual launch, engine option "ln_fused")
+#ifdef LEMAS_MEASUREMENT_BUILD
+#include "gemm_bf16_exp_ln_tail.h"
+#endif
 
 // ---------------------------------------------------------------- ln fold: row statistics on both sides of a GEMM (GemmParams)
 // consumer: the first TBM * TPR threads turn the LN_NP partial (sum, sum of squares) pairs of the tile's rows into (r, -r mu) in LDS.
@@ -1722,141 +1634,10 @@ __global__ __launch_bounds__(512) void gemm_group_kernel(const GemmParams* __res
 }
 
 
+// (measurement builds only: the persistent FF-half kernel, engine option "block_persist")
 #ifdef LEMAS_MEASUREMENT_BUILD
-// ================================================================================================================
-// MEASUREMENT (round 5; engine option "block_persist", measurement builds only): the FF half of a DiT block -- out-projection -> ff_norm ->
-// FF1 -> FF2 (modules.py:635-639) -- as ONE persistent launch per CFG lane.  The four stages are the very bodies of the separate launches
-// (gemm_body 128 x 128 with eight waves, ln_core.h rows), so results are bit-identical; what changes is what sits BETWEEN the stages: a grid
-// barrier (XCD-hierarchical arrival counters, price list row "barrier-xcd" of MI355X_MICROARCH.md) instead of a kernel boundary, no launch
-// ramp / drain per stage, and -- `prefetch` -- the next stage's first WEIGHT tiles already streaming into LDS while the barrier is awaited
-// (weights never depend on the previous stage).  The question it answers: does removing three dependent-launch boundaries and their ramps
-// buy more than three grid barriers cost?  (profiles/r05/r05_block_persist.txt)
-//
-// Visibility follows the recipe of the LayerNorm tail above: every stage publishes with write-through (sc1) stores, each storing wave
-// drains them (vmcnt(0)) before the workgroup's ONE arrival; a released workgroup executes one agent-scope acquire (invalidates this CU's
-// vector L1) before it reads what other workgroups wrote.  Progress: all workgroups of the launch (<= 136) wait for each other, so the
-// launch needs them co-resident -- the other lane's kernels never wait on anything and always drain, a second persistent launch (the other
-// lane) brings <= 136 more workgroups of 96 KB: 272 > 256 CUs do NOT fit, so the engine runs the lanes' persistent launches on 120 + 8
-// surplus workgroups each only when 2 x grid <= CUs.  Every wait is bounded and flags the engine instead of hanging the queue.
-struct ChainParams {
-  GemmParams out, ff1, ff2;        // out-projection (EPI_GATE_RES), FF1 (EPI_BIAS_GELU_BF16), FF2 (EPI_GATE_RES): as for the separate launches
-  int ln_scale_off, ln_shift_off;  // ff_norm's modulation vectors inside the AdaLN table row (its input is out.out_f32, its output ff1.A)
-  unsigned int* sync;              // [16] zeroed before the launch: [0..7] group arrivals, [8] top arrivals, [9] generation
-  unsigned int* err;               // sticky error word (host-visible)
-  int prefetch;                    // 1 = request the next stage's first two weight K-tiles before waiting at the barrier
-};
-
-// one arrival per workgroup; returns false when the wait gave up (the caller must not touch data of the incomplete stage)
-template <typename PRE>
-__device__ __forceinline__ bool chain_barrier(const ChainParams& c, int phase, int* lds_flag, PRE&& prefetch) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's write-through stores have reached memory
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned nwg = gridDim.x, g = blockIdx.x & 7;
-    const unsigned members = (nwg >> 3) + (g < (nwg & 7) ? 1u : 0u), groups = nwg < 8 ? nwg : 8u;
-    gu32* grp = (gu32*)(c.sync + g);
-    gu32* top = (gu32*)(c.sync + 8);
-    gu32* gen = (gu32*)(c.sync + 9);
-    const unsigned want = (unsigned)phase + 1u;
-    if (__hip_atomic_fetch_add(grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == members * want) {
-      if (__hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == groups * want)
-        __hip_atomic_store(gen, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-  prefetch();      // every wave: the next stage's first weight K-tiles, requested between this workgroup's arrival and its wait
-  if (threadIdx.x == 0) {
-    gu32* gen = (gu32*)(c.sync + 9);
-    const unsigned want = (unsigned)phase + 1u;
-    unsigned spins = 0;
-    int fail = 0;
-    while (__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-      __builtin_amdgcn_s_sleep(2);
-      if (++spins > (1u << 18)) {
-        __hip_atomic_store((gu32*)c.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        fail = 1;
-        break;
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // buffer_inv sc1: this CU's L1 forgets what other workgroups have since rewritten
-    *lds_flag = fail;
-  }
-  __syncthreads();
-  return *lds_flag == 0;
-}
-
-__global__ __launch_bounds__(512) void gemm_chain_ffhalf_kernel(const ChainParams c) {
-  using C = TileCfg<T128x128>;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int RING = body_lds_base<EPI_GATE_RES, C::BM, C::BN, C::ST, C::WM, C::WN, false>();
-  float* rs = reinterpret_cast<float*>(smem + RING);
-  int* flag = reinterpret_cast<int*>(smem + RING + C::BM * 8);
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // first tile of this workgroup in a stage (false: none)
-  auto first_tile = [&](const GemmParams& p, int& tm, int& tn) {
-    return xcd_tile_coords(blockIdx.x, (p.M + C::BM - 1) / C::BM, p.N / C::BN, p.xcd_gx, tm, tn);
-  };
-  auto stage = [&](auto epi_tag, const GemmParams& p, bool wpre) {
-    constexpr int EPI = decltype(epi_tag)::value;
-    const int tiles_m = (p.M + C::BM - 1) / C::BM, tiles_n = p.N / C::BN;
-    const int grid = xcd_grid(tiles_m, tiles_n, p.xcd_gx);
-    for (int b = blockIdx.x; b < grid; b += gridDim.x) {
-      int tm, tn;
-      if (!xcd_tile_coords(b, tiles_m, tiles_n, p.xcd_gx, tm, tn)) continue;
-      if (wpre && b == (int)blockIdx.x) gemm_body<EPI, C::BM, C::BN, C::ST, C::WM, C::WN, true, false, true>(p, smem, tm * C::BM, tn * C::BN, rs);
-      else gemm_body<EPI, C::BM, C::BN, C::ST, C::WM, C::WN, true, false>(p, smem, tm * C::BM, tn * C::BN, rs);
-      __syncthreads();      // the epilogue slabs are retired before the next tile's ring stages land
-    }
-  };
-  const bool pre = c.prefetch != 0;
-  auto none = []() {};
-  auto pre_w = [&](const GemmParams& p) {
-    int tm, tn;
-    if (first_tile(p, tm, tn)) gemm_prefetch_w<C::BM, C::BN, C::ST, C::WM, C::WN>(p, smem, tn * C::BN);
-  };
-  // ---- stage 0: x += gate_msa * (attn . Wo^T + bo)
-  stage(std::integral_constant<int, EPI_GATE_RES>{}, c.out, false);
-  // (FF1's first weight tiles go out HERE, ahead of the LayerNorm stage, which does not touch LDS: they land under it)
-  if (pre) { if (!chain_barrier(c, 0, flag, [&]() { pre_w(c.ff1); })) return; }
-  else if (!chain_barrier(c, 0, flag, none)) return;
-  // ---- stage 1: h = LayerNorm(x) (1 + scale_mlp) + shift_mlp, two rows per wave
-  {
-    const GemmParams& p = c.out;
-    const float* base = p.tab + (size_t)p.step_idx[0] * p.tab_stride;
-    float4 a[LN_PER][2], b[LN_PER][2];
-    ln_load_vec(base + c.ln_scale_off, lane, a);
-    ln_load_vec(base + c.ln_shift_off, lane, b);
-    bf16_t* hout = const_cast<bf16_t*>(c.ff1.A);
-    for (int r0 = (blockIdx.x * 8 + wave) * 2; r0 < p.M; r0 += gridDim.x * 16) {
-      u32x4 raw[2][LN_PER][2];
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        int row = r0 + q;
-        row = row < p.M ? row : p.M - 1;
-        ln_load_row_sc1(p.out_f32 + (size_t)row * LN_D, lane, raw[q]);
-      }
-#pragma unroll
-      for (int q = 0; q < 2; ++q) ln_wait_row(raw[q]);
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        float4 v[LN_PER][2];
-#pragma unroll
-        for (int i = 0; i < LN_PER; ++i)
-#pragma unroll
-          for (int h = 0; h < 2; ++h) v[i][h] = __builtin_bit_cast(float4, raw[q][i][h]);
-        ln_row_store(v, a, b, hout + (size_t)(r0 + q) * LN_D, lane, r0 + q < p.M);
-      }
-    }
-  }
-  if (!chain_barrier(c, 1, flag, none)) return;
-  // ---- stage 2: ff = gelu_tanh(h . W1^T + b1)
-  stage(std::integral_constant<int, EPI_BIAS_GELU_BF16>{}, c.ff1, pre);
-  if (pre) { if (!chain_barrier(c, 2, flag, [&]() { pre_w(c.ff2); })) return; }
-  else if (!chain_barrier(c, 2, flag, none)) return;
-  // ---- stage 3: x += gate_mlp * (ff . W2^T + b2)
-  stage(std::integral_constant<int, EPI_GATE_RES>{}, c.ff2, pre);
-}
-#endif  // LEMAS_MEASUREMENT_BUILD
+#include "gemm_bf16_exp_chain.h"
+#endif
 
 // tile of the fused QK+V launch: the largest whose QK part alone still gives ~100 workgroups per lane (two lanes share the chip)
 int pick_qkv_tile(const GemmParams& pq) {

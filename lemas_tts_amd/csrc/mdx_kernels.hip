@@ -41,8 +41,8 @@ struct Geom {
   static constexpr int A_IT = (A_F4 + 255) / 256, W_IT = (W_F4 + 255) / 256;
 };
 
-template <int KH, int S, int PAD, int MT, bool UP>
-__global__ __launch_bounds__(256) void mdx_conv_kernel(const MdxConvParams p) {
+template <int KH, int S, int PAD, int MT, bool UP, bool VEC>
+__global__ __launch_bounds__(256, 2) void mdx_conv_kernel(const MdxConvParams p) {
   using G = Geom<KH, S, PAD, MT>;
   __shared__ __attribute__((aligned(16))) float As[2][CK * G::PLANE];
   __shared__ __attribute__((aligned(16))) float Ws[2][CK * G::CIW];
@@ -52,67 +52,65 @@ __global__ __launch_bounds__(256) void mdx_conv_kernel(const MdxConvParams p) {
   const int b = blockIdx.z / p.ntiles, nt = blockIdx.z % p.ntiles;
   const float* xb = p.x + (size_t)b * p.Cin * p.Ti * p.Fi;
   const float* wt = p.w + (size_t)nt * p.nchunks * (CK * G::CIW);
-  const bool vec = (p.Fi & 3) == 0;
+  const size_t plane = (size_t)p.Ti * p.Fi;
 
-  // loader slots: constant over the K loop except for the channel
-  int a_off[G::A_IT];          // element offset inside one channel plane of x (clamped to 0 when outside)
-  int a_lds[G::A_IT];
-  int a_ci[G::A_IT];
-  unsigned a_ok = 0;           // bit it*4 + e: element e of slot it is inside the image (vector path: all four or none)
+  // Loader slots: a thread owns A_IT float4 slots of the halo (channel ci, halo row r, 4 columns from 4 q) and W_IT float4 of the weight slab;
+  // everything but the channel base is constant over the K loop.  Loads are UNCONDITIONAL from clamped (always valid) addresses and the
+  // halo's zero padding is applied when a slot is parked in LDS: a load under a branch made the compiler wait for every load in flight
+  // before issuing the next one (s_waitcnt vmcnt(0) in front of each global_load), i.e. eight serial L2 round trips per chunk.
+  const float* a_ptr[G::A_IT];   // address of the slot in channel `ci` of chunk 0 (or xb when the slot is outside the image)
+  int a_lds[G::A_IT];            // LDS word offset, -1: no slot
+  int a_lim[G::A_IT];            // the slot's channel is inside the tensor while chunk * CK < a_lim
+  unsigned a_ok = 0;             // bit 4 it + e: element e of slot it is inside the image (VEC: all four or none)
 #pragma unroll
   for (int it = 0; it < G::A_IT; ++it) {
     const int idx = tid + it * 256;
     const int ci = idx / (G::ROWS * G::Q), rem = idx % (G::ROWS * G::Q), r = rem / G::Q, q = rem % G::Q;
     const int tin = t0 * S - PAD + r, fin = f0 * S - G::LEAD + 4 * q;
-    const bool in = idx < G::A_F4 && tin >= 0 && tin < p.Ti;
-    a_ci[it] = idx < G::A_F4 ? ci : -1;
-    a_lds[it] = ci * G::PLANE + r * G::ROWP + 4 * q;
-    a_off[it] = 0;
-    if (in) {
-      if (vec) {
-        if (fin >= 0 && fin < p.Fi) { a_ok |= 0xFu << (4 * it); a_off[it] = tin * p.Fi + fin; }
-      } else {
-        a_off[it] = tin * p.Fi + fin;      // per-element tests below
+    const bool slot = idx < G::A_F4, rowin = slot && tin >= 0 && tin < p.Ti;
+    a_lds[it] = slot ? ci * G::PLANE + r * G::ROWP + 4 * q : -1;
+    a_lim[it] = slot ? p.Cin - ci : 0;
+    a_ptr[it] = xb;
+    if (VEC) {
+      if (rowin && fin >= 0 && fin < p.Fi) { a_ok |= 0xFu << (4 * it); a_ptr[it] = xb + (size_t)ci * plane + (size_t)tin * p.Fi + fin; }
+    } else if (rowin) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (fin + e >= 0 && fin + e < p.Fi) a_ok |= 1u << (4 * it + e);
-      }
+      for (int e = 0; e < 4; ++e)
+        if (fin + e >= 0 && fin + e < p.Fi) a_ok |= 1u << (4 * it + e);
+      a_ptr[it] = xb + (size_t)ci * plane + (size_t)tin * p.Fi + fin;      // element e is read only where its bit is set
     }
   }
-  const size_t plane = (size_t)p.Ti * p.Fi;
-  f32x4 ra[G::A_IT], rw[G::W_IT];
   const f32x4 zv = {0.f, 0.f, 0.f, 0.f};
+  f32x4 ra[G::A_IT], rw[G::W_IT];
+  const f32x4* wsrc = reinterpret_cast<const f32x4*>(wt);
 
   auto gload = [&](int chunk) {
 #pragma unroll
     for (int it = 0; it < G::A_IT; ++it) {
-      const int cig = chunk * CK + a_ci[it];
-      const bool cok = a_ci[it] >= 0 && cig < p.Cin;
-      const float* src = xb + (cok ? (size_t)cig * plane : 0);
-      if (vec) {
-        ra[it] = *reinterpret_cast<const f32x4*>(src + a_off[it]);           // always a valid address; zeroed at the park if outside
-        if (!cok) ra[it] = zv;
+      const bool cok = chunk * CK < a_lim[it];
+      const float* src = cok ? a_ptr[it] + (size_t)chunk * CK * plane : xb;
+      if (VEC) {
+        ra[it] = *reinterpret_cast<const f32x4*>(src);
       } else {
         f32x4 v = zv;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          if (cok && (a_ok >> (4 * it + e) & 1)) v[e] = src[a_off[it] + e];
+          if (cok && (a_ok >> (4 * it + e) & 1)) v[e] = src[e];
         ra[it] = v;
       }
     }
-    const f32x4* wsrc = reinterpret_cast<const f32x4*>(wt + (size_t)chunk * (CK * G::CIW));
 #pragma unroll
     for (int it = 0; it < G::W_IT; ++it) {
       const int idx = tid + it * 256;
-      rw[it] = idx < G::W_F4 ? wsrc[idx] : zv;
+      rw[it] = wsrc[(size_t)chunk * (CK * G::CIW / 4) + (idx < G::W_F4 ? idx : 0)];
     }
   };
-  auto park = [&](int buf) {
+  auto park = [&](int buf, int chunk) {
 #pragma unroll
     for (int it = 0; it < G::A_IT; ++it) {
-      if (a_ci[it] < 0) continue;
+      if (a_lds[it] < 0) continue;
       f32x4 v = ra[it];
-      if (vec && !(a_ok >> (4 * it) & 1)) v = zv;
+      if (VEC && !((a_ok >> (4 * it) & 1) && chunk * CK < a_lim[it])) v = zv;
       *reinterpret_cast<f32x4*>(&As[buf][a_lds[it]]) = v;
     }
 #pragma unroll
@@ -132,7 +130,7 @@ __global__ __launch_bounds__(256) void mdx_conv_kernel(const MdxConvParams p) {
   const int w_base = lk * G::CIW + l15;
 
   gload(0);
-  park(0);
+  park(0, 0);
   __syncthreads();
   for (int chunk = 0; chunk < p.nchunks; ++chunk) {
     const int cur = chunk & 1;
@@ -155,7 +153,7 @@ __global__ __launch_bounds__(256) void mdx_conv_kernel(const MdxConvParams p) {
           for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[j], av[i], acc[i][j], 0, 0, 0);
       }
     }
-    if (chunk + 1 < p.nchunks) park(cur ^ 1);
+    if (chunk + 1 < p.nchunks) park(cur ^ 1, chunk + 1);
     __syncthreads();
   }
 
@@ -209,7 +207,7 @@ __global__ __launch_bounds__(256) void mdx_conv_kernel(const MdxConvParams p) {
   }
 }
 
-template <int KH, int S, int PAD, bool UP>
+template <int KH, int S, int PAD, bool UP, bool VEC>
 hipError_t launch_geom(const MdxConvParams& p, hipStream_t s) {
   // wider position tiles while they still give the chip ~2 workgroups per CU; the narrow ones for the deep, small levels
   auto wgs = [&](int mt) { return (long)((p.Fg + 16 * mt - 1) / (16 * mt)) * ((p.Tg + 3) / 4) * p.B * p.ntiles; };
@@ -219,13 +217,20 @@ hipError_t launch_geom(const MdxConvParams& p, hipStream_t s) {
   const dim3 grid((p.Fg + 16 * mt - 1) / (16 * mt), (p.Tg + 3) / 4, p.B * p.ntiles);
   if (grid.y > 65535 || grid.z > 65535) return hipErrorInvalidValue;
   if (mt == 4) {
-    if constexpr (MAXMT >= 4) hipLaunchKernelGGL((mdx_conv_kernel<KH, S, PAD, 4, UP>), grid, dim3(256), 0, s, p);
+    if constexpr (MAXMT >= 4) hipLaunchKernelGGL((mdx_conv_kernel<KH, S, PAD, 4, UP, VEC>), grid, dim3(256), 0, s, p);
   } else if (mt == 2) {
-    hipLaunchKernelGGL((mdx_conv_kernel<KH, S, PAD, 2, UP>), grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((mdx_conv_kernel<KH, S, PAD, 2, UP, VEC>), grid, dim3(256), 0, s, p);
   } else {
-    hipLaunchKernelGGL((mdx_conv_kernel<KH, S, PAD, 1, UP>), grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((mdx_conv_kernel<KH, S, PAD, 1, UP, VEC>), grid, dim3(256), 0, s, p);
   }
   return hipGetLastError();
+}
+
+template <int KH, int S, int PAD, bool UP>
+hipError_t launch_geom(const MdxConvParams& p, hipStream_t s) {
+  // 16-B loads need whole float4 groups inside or outside the image: a row length that is a multiple of 4 (tiles start at multiples of 16)
+  const bool vec = (p.Fi & 3) == 0 && (reinterpret_cast<size_t>(p.x) & 15) == 0;
+  return vec ? launch_geom<KH, S, PAD, UP, true>(p, s) : launch_geom<KH, S, PAD, UP, false>(p, s);
 }
 
 // ---- first 1x1 convolution (+ folded norm, ReLU) with the transpose of mdxnet.py:105-107: [b][ci][f][t] -> [b][co][t][f] ----------------
@@ -283,6 +288,7 @@ __global__ __launch_bounds__(256) void mdx_final_kernel(const float* __restrict_
 #pragma unroll
     for (int o = 0; o < 8; ++o) v[o] = o < Cout ? bias[o] : 0.f;
     if (t < T && f < F)
+#pragma unroll 8
       for (int c = 0; c < Cin; ++c) {
         const float xv = xb[((size_t)c * T + t) * F + f];
 #pragma unroll

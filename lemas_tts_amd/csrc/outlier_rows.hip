@@ -18,6 +18,9 @@
 // row, so the permutation cancels.  A lane's run is whole 32-value MX blocks, so the MXFP8 image needs no cross-lane maximum.  Partial tiles
 // are summed through LDS in a fixed order by wave 0, which also does the gated read-modify-write.  Swapped operands as in gemm_bf16.hip: a
 // lane owns ONE row m and 16 of the 32 channel slots.
+// MEASUREMENT BUILDS ONLY since round 6 (-DLEMAS_MEASUREMENT_BUILD): the decomposition holds the 1e-4 target but is slower than the all-bf16
+// fallback it replaces (profiles/r05/r05h_outlier_throughput.txt), so the product library does not carry this kernel or its engine option.
+#ifdef LEMAS_MEASUREMENT_BUILD
 #include "common.h"
 
 namespace {
@@ -120,3 +123,5 @@ hipError_t launch_outlier_rows(const OutlierRowsParams& p, hipStream_t s) {
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }
+
+#endif  // LEMAS_MEASUREMENT_BUILD

@@ -6,11 +6,11 @@ with the sampler and vocoder behind it running on the MI355X engines.
 
 What differs from the reference script, and why:
 
-* ``--denoise`` (UVR5 MDX-Net through onnxruntime, ``tts_multilingual.py:38-86``): the shell around the network -- resample to
-  44.1 kHz, stereo chunking, STFT, inverse STFT, 24-bit temporary wav -- is built (``lemas_tts_amd/uvr5``); the network
-  is an ONNX file that is not part of the tree and there is no ONNX runtime for this device, so it has to be supplied:
-  ``--denoise_model_factory package.module:callable`` names a function that returns ``model_run(spek) -> spec_pred`` (and
-  ``--denoise_config`` the reference's json files).  Without it ``--denoise`` is refused.
+* ``--denoise`` (UVR5 MDX-Net, ``tts_multilingual.py:38-86,303-314``): the reference runs ``pretrained_models/uvr5/Kim_Vocal_1.onnx``
+  through onnxruntime on the CPU; here the same directory (``--denoise_model``, default ``PRETRAINED_ROOT/uvr5``) feeds the HIP
+  implementation of the network the ONNX file was exported from (``lemas_tts_amd/uvr5``, ``lemas_mdx_*``).
+  ``--denoise_model`` may also name a network file directly (``.onnx`` or a state dict of the module), ``--denoise_config`` the reference's
+  json files, and ``--denoise_model_factory package.module:callable`` a function returning ``model_run(spek) -> spec_pred`` to use instead;
 * there is no CPU retry (``:332-336``): this build has no CPU path, a missing GPU is an error;
 * checkpoints resolve locally only (``:89-119`` falls back to a Hugging Face download; no network here);
 * the text frontend comes from the factory registered with ``lemas_tts_amd.api.set_frontend_factory``; ``--ref_phones`` / ``--phones``
@@ -100,6 +100,10 @@ def build_parser() -> argparse.ArgumentParser:
                    help="'package.module:callable' building the text frontend for --frontend phone|char, called as callable(dtype=...): "
                         "e.g. lemas_tts.infer.frontend:TextNorm.  Default: the LEMAS_FRONTEND_FACTORY environment variable.  The text "
                         "frontend (espeak / jieba / langid) is host Python outside this package")
+    p.add_argument("--denoise_model", type=str, default=None,
+                   help="--denoise: directory laid out like the reference's pretrained_models/uvr5 (Kim_Vocal_1.onnx + MDX-Net-Kim-Vocal1.json "
+                        "[+ model_data.json]) or a network file (.onnx, or a ConvTDFNet state dict as .safetensors/.pt/.ckpt/.npz); "
+                        "default PRETRAINED_ROOT/uvr5")
     p.add_argument("--denoise_model_factory", type=str, default=None,
                    help="'package.module:callable' returning the MDX-Net as model_run(spek[b, 4, dim_f, dim_t]) -> spec_pred for --denoise")
     p.add_argument("--denoise_config", type=str, nargs="*", default=None,
@@ -113,10 +117,6 @@ def _phone_lines(s: str) -> List[List[str]]:
 
 def main(argv=None) -> int:
     args = build_parser().parse_args(argv)
-    if args.denoise and not args.denoise_model_factory:
-        raise NotImplementedError("--denoise: the UVR5 MDX-Net is an ONNX model outside this tree and there is no ONNX runtime for "
-                                  "MI355X here; supply it with --denoise_model_factory package.module:callable, or denoise the prompt "
-                                  "beforehand (SURVEY.md 8f-4)")
     phones_given = args.ref_phones is not None or args.phones is not None
     if phones_given and (args.ref_phones is None or args.phones is None):
         raise SystemExit("--ref_phones and --phones go together")
@@ -133,10 +133,16 @@ def main(argv=None) -> int:
         set_frontend_factory(resolve_frontend_factory(args.frontend_factory))
     ref_audio, tmp_denoised = args.ref_audio, None
     if args.denoise:             # :303-314: the prompt goes through UVR5 first, the temporary file is removed at the end
-        from ..api import resolve_callable
         from ..uvr5 import MDXConfig, UVR5
-        cfg = MDXConfig.from_json(*args.denoise_config) if args.denoise_config else MDXConfig()
-        network = resolve_callable(args.denoise_model_factory, "denoise model factory")()
+        cfg = MDXConfig.from_json(*args.denoise_config) if args.denoise_config else None
+        if args.denoise_model_factory:
+            from ..api import resolve_callable
+            network = resolve_callable(args.denoise_model_factory, "denoise model factory")()
+        else:
+            network = args.denoise_model or str(PRETRAINED_ROOT / "uvr5")
+            if not os.path.exists(network):
+                raise FileNotFoundError(f"--denoise: {network} does not exist (the reference keeps Kim_Vocal_1.onnx and its json files "
+                                        "there); point --denoise_model at the directory or at a network file")
         tmp_denoised = UVR5(network, cfg, device=args.device or "cuda:0").denoise_file(ref_audio)
         ref_audio = tmp_denoised
     try:                         # everything after the temporary file exists runs under the finally that removes it

@@ -1,12 +1,14 @@
-"""MI355X mirror of the reference's UVR5 MDX-Net denoising shell (``uvr5/multiprocess_cuda_infer.py:181-301`` ``Inference``; wrapper
-``lemas_tts/scripts/tts_multilingual.py:38-86`` ``UVR5``): everything AROUND the separation network -- stereo chunking with trimmed
-overlaps, STFT to the network's [batch, 4, dim_f, dim_t] layout, the +-input averaging ("denoise") trick, inverse STFT, margin
-handling -- with the same method names and argument meaning.
+"""MI355X mirror of the reference's UVR5 MDX-Net prompt denoiser (``uvr5/multiprocess_cuda_infer.py:181-301`` ``Inference``; wrapper
+``lemas_tts/scripts/tts_multilingual.py:38-86`` ``UVR5``), same method names and argument meaning:
 
-The network itself is an ONNX file (``Kim_Vocal_1.onnx``) that is neither in the reference tree nor runnable here (no onnxruntime for
-MI355X), so it is a CALLABLE handed to ``load_model``: ``model_run(spek) -> spec_pred`` on ``[b, 4, dim_f, dim_t]`` float32, device
-tensor in, tensor or numpy array out.  The two transforms run in ``liblemas_hip.so`` (``lemas_stft_*``: fp32 MFMA GEMMs against
-precomputed bases); slicing, padding and concatenation are tensor plumbing.  Resampling to 44.1 kHz uses ``lemas_resample_*``.
+* the shell AROUND the separation network -- stereo chunking with trimmed overlaps, STFT to the network's [batch, 4, dim_f, dim_t] layout,
+  the +-input averaging ("denoise") trick, inverse STFT, margin handling.  The two transforms run in ``liblemas_hip.so`` (``lemas_stft_*``:
+  fp32 MFMA GEMMs against precomputed bases); slicing, padding and concatenation are tensor plumbing; resampling to 44.1 kHz uses
+  ``lemas_resample_*``;
+* the network itself.  The reference runs ``Kim_Vocal_1.onnx`` through onnxruntime (:225-238); that file is an export of ``ConvTDFNet``
+  (``uvr5/lib_v5/mdxnet.py:36-127``), and ``Inference.load_model`` here builds that architecture on the HIP engine (``lemas_mdx_*``,
+  csrc/engine_mdx.hip) from the ONNX file's initializers or from the module's state dict -- no onnxruntime involved.  A callable is still
+  accepted in its place (tests use it to exercise the shell alone).
 """
 from __future__ import annotations
 
@@ -179,13 +181,54 @@ def normalize_two_stem(wave: torch.Tensor, mix: torch.Tensor, is_normalize: bool
     return wave, mix
 
 
-class UVR5:
-    """``tts_multilingual.py:38-86``: denoise a prompt file.  ``model_run`` is the separation network (see ``Inference.load_model``)."""
+MODEL_STEM, UI_CONFIG = "Kim_Vocal_1", "MDX-Net-Kim-Vocal1.json"      # tts_multilingual.py:55-56
+MODEL_EXTS = (".onnx", ".safetensors", ".pt", ".ckpt", ".npz")
 
-    def __init__(self, model_run: Callable, config: Optional[MDXConfig] = None, device: str = "cuda:0") -> None:
+
+def model_hash(model_path: str) -> str:
+    """``ModelData.get_model_hash`` (multiprocess_cuda_infer.py:165-178): md5 of the file's last 10 000 KiB, of the whole file if shorter."""
+    import hashlib
+    with open(model_path, "rb") as f:
+        try:
+            f.seek(-10000 * 1024, 2)
+        except OSError:
+            f.seek(0)
+        return hashlib.md5(f.read()).hexdigest()
+
+
+def resolve_model_dir(model_dir: str):
+    """The reference's ``pretrained_models/uvr5`` layout (tts_multilingual.py:55-69) -> (network file, MDXConfig): ``Kim_Vocal_1.onnx`` (or
+    the same stem as a state-dict file), the UI options in ``MDX-Net-Kim-Vocal1.json`` and the model's entry of ``model_data.json``
+    (keyed by ``model_hash``; ModelData :108-121), each optional -- absent files leave the published Kim_Vocal_1 defaults."""
+    import json
+    path = next((os.path.join(model_dir, MODEL_STEM + e) for e in MODEL_EXTS if os.path.isfile(os.path.join(model_dir, MODEL_STEM + e))), None)
+    if path is None:
+        raise FileNotFoundError(f"{model_dir}: no {MODEL_STEM}{{{','.join(MODEL_EXTS)}}} (the UVR5 MDX-Net weights the reference keeps in "
+                                "pretrained_models/uvr5)")
+    ui = os.path.join(model_dir, UI_CONFIG)
+    cfg = MDXConfig.from_json(ui) if os.path.isfile(ui) else MDXConfig()
+    table = os.path.join(model_dir, "model_data.json")
+    if os.path.isfile(table):
+        with open(table, "r", encoding="utf-8") as f:
+            entry = json.load(f).get(model_hash(path))
+        if entry:
+            for k in ("compensate", "mdx_dim_f_set", "mdx_dim_t_set", "mdx_n_fft_scale_set"):
+                if k in entry:
+                    setattr(cfg, k, type(getattr(cfg, k))(entry[k]))
+    return path, cfg
+
+
+class UVR5:
+    """``tts_multilingual.py:38-86``: denoise a prompt file.  ``model``: a directory laid out like the reference's ``pretrained_models/uvr5``
+    (``resolve_model_dir``), or anything ``Inference.load_model`` takes (a network file, an ``(arch, state_dict)`` pair, a callable)."""
+
+    def __init__(self, model, config: Optional[MDXConfig] = None, device: str = "cuda:0") -> None:
         self.device = device
+        if isinstance(model, (str, os.PathLike)) and os.path.isdir(model):
+            model, dir_config = resolve_model_dir(os.fspath(model))
+            config = config or dir_config
         self.model = Inference(config or MDXConfig(), device)
-        self.model.load_model(model_run, 1)
+        self.model.load_model(model, 1)
 
     def denoise(self, wav: torch.Tensor, sr: int) -> torch.Tensor:
         """wav [channels, n] at `sr` -> vocal stem [2, n'] at 44.1 kHz."""

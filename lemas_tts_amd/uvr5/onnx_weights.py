@@ -115,7 +115,7 @@ def _tensor(buf: memoryview) -> Tuple[str, np.ndarray]:
         arr = np.asarray(int32s, dtype=np.int32)
     else:
         arr = np.zeros(0, dtype=dt)
-    return name, arr.astype(dt, copy=False).reshape(dims)
+    return name, arr.astype(dt, copy=True).reshape(dims)          # own, writable memory (frombuffer views are read-only)
 
 
 class Node:

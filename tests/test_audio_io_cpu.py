@@ -114,8 +114,15 @@ def test_cli_resolution_and_refusals(tmp_path, monkeypatch):
     assert M._resolve_vocab("multilingual_grl", None) == str(root / "data" / "multilingual_grl" / "vocab.txt")
     (root / "ckpts" / "multilingual_prosody.safetensors").write_bytes(b"")           # fallback: directly under ckpts/
     assert M._resolve_ckpt("multilingual_prosody", None).endswith("multilingual_prosody.safetensors")
-    with pytest.raises(NotImplementedError, match="UVR5"):
-        M.main(["--ref_audio", "r.wav", "--ref_text", "a", "--text", "b", "--denoise"])
+    # --denoise needs the reference's pretrained_models/uvr5 directory (or --denoise_model): a missing one is named, not worked around
+    (root / "data" / "multilingual_prosody").mkdir(parents=True)
+    (root / "data" / "multilingual_prosody" / "vocab.txt").write_text("a\n")
+    (tmp_path / "r.wav").write_bytes(b"")
+    with pytest.raises(FileNotFoundError, match="--denoise: .*uvr5 does not exist"):
+        M.main(["--model", "multilingual_prosody", "--ref_audio", str(tmp_path / "r.wav"), "--ref_text", "a", "--text", "b", "--denoise"])
+    (root / "uvr5").mkdir()
+    with pytest.raises(FileNotFoundError, match="no Kim_Vocal_1"):
+        M.main(["--model", "multilingual_prosody", "--ref_audio", str(tmp_path / "r.wav"), "--ref_text", "a", "--text", "b", "--denoise"])
     with pytest.raises(SystemExit, match="go together"):
         M.main(["--ref_audio", "r.wav", "--ref_phones", "a|b"])
     with pytest.raises(FileNotFoundError, match="Prosody encoder assets"):

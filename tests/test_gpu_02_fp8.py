@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import needs_measurement_build
 from oracle.mxfp8 import mx_dequant, mx_quant, w_quant
 
 pytestmark = pytest.mark.gpu
@@ -194,6 +195,7 @@ def test_fp8_cost_of_quantising_activations_and_outlier_stress(golden_dir, name,
     assert got[0] < got[2] < got[1], got          # each step of quantisation costs accuracy: bf16 < weights-only < weights + activations
 
 
+@needs_measurement_build
 def test_outlier_rows_kernel():
     """csrc/outlier_rows.hip: the flagged output channels of a residual-writing projection from bf16 operands, gated and added in place --
     against fp64 on the bf16-rounded operands; ragged lengths (rows at or past a sample's length and padding rows must not be touched)."""
@@ -255,34 +257,29 @@ def _outlier_case(golden_dir, name):
 def test_fp8_outlier_guard(golden_dir):
     """Activation outliers at a PRODUCTION step count (tests/golden/configs0_outlier_nfe32.npz: the reference's own output at full depth,
     NFE 32, on weights whose residual-writing projections scale 1 % of the channels x30 -- oracle/gen_golden.py --full-size).  Unguarded,
-    the fp8 path misses the 1e-4 target there (2.9e-4).  The guard (default) sees the outlier channels in the per-channel weight scales, and
-    since round 5 the engine then runs the MIXED-PRECISION DECOMPOSITION (option fp8_outlier_mode, default 1) instead of giving fp8 up: QKV,
-    out-projection and FF2 stay on fp8 operands -- three of the four GEMM sites -- FF1 runs on bf16 operands and the flagged OUTPUT channels of
-    out-projection / FF2 are computed from bf16 operands by csrc/outlier_rows.hip.  THE tolerance (1e-4) is asserted on that path; mode 0 is
-    round 4's behaviour (every block GEMM on bf16: the bf16 path's bits).  On weights without such channels nothing changes."""
+    the fp8 path misses the 1e-4 target there (2.9e-4).  The guard (default) sees the outlier channels in the per-channel weight scales and
+    runs every block GEMM on its bf16 operands: the bf16 path's bits.  (The mixed-precision decomposition of round 5, engine option
+    fp8_outlier_mode = 1, lives in measurement builds only since round 6 -- it met 1e-4 but ran slower than this fallback:
+    test_fp8_outlier_decomposition below.)  On weights without such channels nothing changes."""
     m, fx, run = _outlier_case(golden_dir, "configs0_outlier_nfe32")
-    out_u, unguarded = run(1, guard=0)
+    out_u, unguarded = run(1, guard=0, mode=0)
     assert m.engine.stat("fp8_gemms_kept_bf16") == 0
-    out_s, split = run(1, guard=1, mode=1)
-    assert m.engine.stat("fp8_gemms_kept_bf16") == 1          # FF1 only: fp8 on 3 of the 4 sites
     n_out = m.engine.stat("fp8_outlier_channels")
     out_g, legacy = run(1, guard=1, mode=0)
     assert m.engine.stat("fp8_gemms_kept_bf16") == 4
-    out_b, bf16 = run(0)
+    out_b, bf16 = run(0, mode=0)
     print(f"\n[fp8 on outlier weights, NFE 32, {n_out} outlier channels] mel-MSE vs reference: bf16 {bf16:.3e}  fp8 unguarded {unguarded:.3e}  "
-          f"fp8 decomposition (3 of 4 sites) {split:.3e}  guard with every GEMM on bf16 {legacy:.3e}")
+          f"guard with every GEMM on bf16 {legacy:.3e}")
     assert 5 <= n_out <= 20                   # 1 % of 1024 channels
-    assert bf16 <= 1e-4 and split <= 1e-4 and legacy <= 1e-4, (bf16, split, legacy)      # THE tolerance (BASELINE.json), not a multiple of what was measured
+    assert bf16 <= 1e-4 and legacy <= 1e-4, (bf16, legacy)      # THE tolerance (BASELINE.json), not a multiple of what was measured
     assert unguarded > 1e-4                   # what the guard is there for (if this ever passes unguarded, the guard can go)
-    assert bf16 < split < unguarded
     np.testing.assert_array_equal(out_g, out_b)
-    # the decomposition replays bit for bit (graph vs eager) and switching modes re-quantises the zeroed rows
-    m.engine.set_option("graph", 0)
-    out_s2, _ = run(1, guard=1, mode=1)
-    m.engine.set_option("graph", 1)
-    np.testing.assert_array_equal(out_s, out_s2)
-    out_u2, _ = run(1, guard=0)
+    out_u2, _ = run(1, guard=0, mode=0)
     np.testing.assert_array_equal(out_u, out_u2)
+    if not __import__("conftest").measurement_build():          # the product refuses the measurement option by name
+        from lemas_tts_amd import _lib as L
+        with pytest.raises(L.LemasError, match="measurement option"):
+            m.engine.set_option("fp8_outlier_mode", 1)
     del m
     # no outlier channels: the guard does not trip and the fp8 path is bit-for-bit what it was
     import test_gpu_00_sample as T
@@ -299,9 +296,28 @@ def test_fp8_outlier_guard(golden_dir):
     m2.engine.set_option("fp8_outlier_guard", 1)
 
 
+@needs_measurement_build
+def test_fp8_outlier_decomposition(golden_dir):
+    """MEASUREMENT BUILDS ONLY: engine option fp8_outlier_mode = 1 -- QKV, out-projection and FF2 stay on fp8 operands (three of the four
+    GEMM sites), FF1 runs on bf16 operands and the flagged OUTPUT channels of out-projection / FF2 are computed from bf16 operands by
+    csrc/outlier_rows.hip.  Measured 8.4e-5 / 9.6e-5 against the 1e-4 target (a 4 % margin on the eight-step fixture: a different reduction
+    order or lease can flip it, which is one more reason it is not product code); -8 % throughput against the bf16 fallback."""
+    m, fx, run = _outlier_case(golden_dir, "configs0_outlier_nfe32")
+    _, unguarded = run(1, guard=0, mode=0)
+    out_s, split = run(1, guard=1, mode=1)
+    assert m.engine.stat("fp8_gemms_kept_bf16") == 1          # FF1 only: fp8 on 3 of the 4 sites
+    _, bf16 = run(0, mode=0)
+    assert split <= 1e-4 and bf16 < split < unguarded, (bf16, split, unguarded)
+    m.engine.set_option("graph", 0)
+    out_s2, _ = run(1, guard=1, mode=1)
+    m.engine.set_option("graph", 1)
+    np.testing.assert_array_equal(out_s, out_s2)
+
+
+@needs_measurement_build
 def test_fp8_outlier_decomposition_on_the_eight_step_fixture(golden_dir):
     """tests/golden/full_outlier.npz: the same stress on an EIGHT-step solve (F = 150, N = 400), whose coarse steps integrate any flow error
-    almost undamped: fp8 unguarded 6.9e-4.  The decomposition meets the 1e-4 target here too."""
+    almost undamped: fp8 unguarded 6.9e-4.  The decomposition meets the 1e-4 target here too -- at 9.6e-5, a 4 % margin (see above)."""
     m, fx, run = _outlier_case(golden_dir, "full_outlier")
     _, unguarded = run(1, guard=0)
     _, split = run(1, guard=1, mode=1)

@@ -175,3 +175,68 @@ def test_denoiser_shell_with_the_hip_network(denoise):
     e = _rel(out, ref)
     print(f"\n[uvr5 shell + hip network, denoise {denoise}] rel err {e:.2e}")
     assert e < REL
+
+
+@pytest.mark.gpu
+def test_cli_denoise_runs_from_the_reference_directory_layout(tmp_path, monkeypatch):
+    """``tts_multilingual --denoise`` (tts_multilingual.py:303-314) with no user-supplied callable: pretrained_models/uvr5 holds
+    Kim_Vocal_1.onnx + MDX-Net-Kim-Vocal1.json + model_data.json (keyed by the reference's model hash), the prompt goes through the HIP
+    denoiser, and the synthesis that follows reads the denoised temporary file (removed afterwards)."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from onnx_writer import convtdfnet_onnx
+    from test_gpu_08_cli import _assets
+    import lemas_tts_amd.api as A
+    import lemas_tts_amd.scripts.tts_multilingual as M
+    from lemas_tts_amd import synth
+    from lemas_tts_amd.infer.audio_io import load_wav, save_wav
+    from lemas_tts_amd.uvr5 import UVR5, mdx
+    root = _assets(tmp_path, 1)
+    monkeypatch.setattr(M, "PRETRAINED_ROOT", root)
+    monkeypatch.setattr(M, "CKPTS_ROOT", root / "ckpts")
+    real_cfg = A.load_arch_config
+    monkeypatch.setattr(A, "load_arch_config", lambda m: {**real_cfg(m), "arch": {**real_cfg(m)["arch"], "depth": 1}})
+    arch = MO.MdxArch(dim_f=64, dim_t=16, num_blocks=5, l=2, g=8, k=3, bn=4, bias=False)
+    sd = MO.seeded_state_dict(arch, 3)
+    uv = root / "uvr5"
+    uv.mkdir()
+    convtdfnet_onnx(str(uv / "Kim_Vocal_1.onnx"), arch, sd)
+    (uv / "MDX-Net-Kim-Vocal1.json").write_text(json.dumps({"is_denoise": True, "mdx_batch_size": 2, "margin": 441, "chunks": 0, "model_name": "Kim_Vocal_1"}))
+    (uv / "model_data.json").write_text(json.dumps({mdx.model_hash(str(uv / "Kim_Vocal_1.onnx")): {
+        "compensate": 1.0, "mdx_dim_f_set": 64, "mdx_dim_t_set": 4, "mdx_n_fft_scale_set": 2048, "primary_stem": "Vocals"}}))
+    t = np.arange(int(1.2 * 16000)) / 16000.0
+    prompt = 0.05 * np.sin(2 * np.pi * 220 * t)[:, None] + 0.004 * np.random.default_rng(7).standard_normal((t.size, 1))
+    save_wav(tmp_path / "ref.wav", prompt, 16000, "PCM_16")
+
+    # the wrapper alone: resolves the directory, is_denoise on, output = shell oracle around the oracle network on the same 44.1 kHz input
+    u = UVR5(str(uv), device="cuda:0")
+    assert (u.model.dim_f, u.model.dim_t, u.model.n_fft, u.model.is_denoise, u.model.mdx_batch_size) == (64, 16, 2048, True, 2)
+    wav, sr = load_wav(tmp_path / "ref.wav")
+    from lemas_tts_amd.engine import resampler
+    stereo = resampler(sr, 44100)(torch.cat((wav, wav)).to("cuda:0"))
+    got = u.denoise(wav, sr).cpu().numpy()
+    from oracle.uvr5_oracle import ShellOracle
+    net = MO.MdxOracle(arch, sd)
+    o = ShellOracle(2048, 64, 4, is_denoise=True, mdx_batch_size=2, margin=441)
+    o.model_run = lambda spek: net.forward(spek).numpy()
+    ref = o.demix_base({0: stereo.cpu()}).numpy()
+    assert got.shape == ref.shape and _rel(got, ref) < REL
+
+    seen = {}
+    real_infer = A.TTS.infer
+
+    def spy(self, **kw):
+        seen["ref"] = kw["ref_file"]
+        seen["audio"] = load_wav(kw["ref_file"])
+        return real_infer(self, **kw)
+    monkeypatch.setattr(A.TTS, "infer", spy)
+    ref_ph = "|".join(f"p{i}" for i in synth.synth_tokens(74, 9, 60))
+    out = tmp_path / "out.wav"
+    rc = M.main(["--ref_audio", str(tmp_path / "ref.wav"), "--ref_phones", ref_ph, "--phones", ref_ph, "--output_wave", str(out), "--nfe_step", "2",
+                 "--seed", "1", "--use_ema", "--denoise"])
+    assert rc == 0 and out.is_file()
+    assert seen["ref"] != str(tmp_path / "ref.wav") and not os.path.exists(seen["ref"])          # a temporary file, gone again
+    den, dsr = seen["audio"]
+    assert dsr == 44100 and den.shape == (2, got.shape[1])
+    assert np.abs(den.numpy() - np.clip(got, -1, 1)).max() < 2.0 ** -22                           # the 24-bit file of the denoiser's output

@@ -17,6 +17,9 @@
 #   kbench[:<args, '+' for spaces>]   tools/kbench.py
 #   scale:<n>                    bench.py with n ranks sharing the one GPU over gloo (weak-scaling line + the sharded job)
 #   py:<script, '+' for spaces>  python <script> (experiments under tools/exp or tools/)
+#   pyprof:<name>:<script, '+' for spaces>   rocprofv3 --kernel-trace --stats over `python <script>` -> <TAG>_kernel_stats_<name>.txt
+#                                (SEQ=<n> in the environment: also the last n dispatches in launch order -> <TAG>_sequence_<name>.txt)
+#   pypmc:<name>:<script, '+' for spaces>    the PMC group passes + FETCH_SIZE / WRITE_SIZE over `python <script>` -> <TAG>_pmc_<name>.txt (all kernels)
 set -u
 TAG=${TAG:-r05}
 cd /tmp && export TMPDIR=/tmp
@@ -91,6 +94,20 @@ for step in "$@"; do
       cut -c1-260 "$O/${TAG}_bench_${n}ranks_shared_gpu.json"
       LEMAS_SHARE_GPU=1 LEMAS_DIST_BACKEND=gloo timeout 900 python bench.py --gpus $n --job configs3_full --steps 1 --warmup 1 > "$O/${TAG}_job_${n}ranks_shared_gpu.json" 2>> "$O/${TAG}_bench.err"
       cut -c1-260 "$O/${TAG}_job_${n}ranks_shared_gpu.json" ;;
+    pyprof)
+      name=${rest%%:*}; cmd=$(sp "${rest#*:}"); rm -rf /tmp/pyprof_$name
+      (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/pyprof_$name -- python $R/$cmd > /tmp/pyprof_$name.out 2> /tmp/pyprof_$name.log)
+      python tools/rocpd_summary.py "$(find /tmp/pyprof_$name -name '*_results.db' | head -1)" > "$O/${TAG}_kernel_stats_$name.txt"
+      [ -n "${SEQ:-}" ] && python tools/rocpd_sequence.py "$(find /tmp/pyprof_$name -name '*_results.db' | head -1)" $SEQ > "$O/${TAG}_sequence_$name.txt"
+      grep -v amdgpu.ids /tmp/pyprof_$name.out | tail -1 > "$O/${TAG}_under_rocprof_$name.json"; head -24 "$O/${TAG}_kernel_stats_$name.txt" | cut -c1-150 ;;
+    pypmc)
+      name=${rest%%:*}; cmd=$(sp "${rest#*:}"); : > "$O/${TAG}_pmc_$name.txt"
+      for grp in "${PMC_GROUPS[@]}" "FETCH_SIZE" "WRITE_SIZE"; do
+        d=/tmp/pypmc_${name}_$(echo $grp | tr ' ' '_' | cut -c1-40); rm -rf $d
+        (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $grp -d $d -- python $R/$cmd > /dev/null 2> /tmp/pmc_err.log) || tail -3 /tmp/pmc_err.log
+        echo "## $grp" >> "$O/${TAG}_pmc_$name.txt"
+        python tools/rocpd_pmc.py "$(find $d -name '*_results.db' | head -1)" mdx_ gemm_f32 >> "$O/${TAG}_pmc_$name.txt"
+      done; tail -12 "$O/${TAG}_pmc_$name.txt" ;;
     py)
       timeout 1500 python $(sp "$rest") 2>&1 | grep -v amdgpu.ids | tee -a "$O/${TAG}_py.txt" ;;
     *) echo "unknown step $step" ;;
