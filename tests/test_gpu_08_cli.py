@@ -155,7 +155,8 @@ def test_cli_default_usage_reaches_the_string_frontend_through_a_named_factory(t
 
 def test_cli_denoise_runs_the_uvr5_shell_with_a_named_network(tmp_path, monkeypatch):
     """--denoise (tts_multilingual.py:303-314): the prompt goes through the UVR5 shell (lemas_tts_amd/uvr5) before TTS.infer; the network
-    is named with --denoise_model_factory.  With an identity network the shell only band-limits and resamples the prompt, so the output
+    here is a user-supplied callable named with --denoise_model_factory (the built-in HIP network from the reference's directory layout:
+    tests/test_mdxnet.py::test_cli_denoise_runs_from_the_reference_directory_layout).  With an identity network the shell only band-limits and resamples the prompt, so the output
     exists and differs from the undenoised run only through that; the temporary file is removed."""
     import glob
     import tempfile
@@ -178,7 +179,7 @@ def test_cli_denoise_runs_the_uvr5_shell_with_a_named_network(tmp_path, monkeypa
     before = set(glob.glob(os.path.join(tempfile.gettempdir(), "*.wav")))
     common = ["--ref_audio", str(tmp_path / "ref.wav"), "--ref_phones", ref_ph, "--phones", gen_ph, "--nfe_step", "2", "--cfg_strength", "2.0",
               "--sway_sampling_coef", "5", "--seed", "7", "--use_ema"]
-    with pytest.raises(NotImplementedError, match="denoise_model_factory"):
+    with pytest.raises(FileNotFoundError, match="--denoise: .*uvr5 does not exist"):      # no pretrained_models/uvr5, no --denoise_model: named, not worked around
         M.main(common + ["--denoise", "--output_wave", str(tmp_path / "x.wav")])
     assert M.main(common + ["--denoise", "--denoise_model_factory", "fake_mdx:build", "--denoise_config", str(tmp_path / "mdx.json"),
                             "--output_wave", str(tmp_path / "den.wav")]) == 0

@@ -79,7 +79,7 @@ def main():
         line["denoise"] = {"prompt_seconds": args.prompt_seconds, "ms": dd * 1e3, "audio_seconds_per_second": args.prompt_seconds / dd,
                            "chunks": int(-(-out.shape[1] // uv.model.gen_size)), "is_denoise": True, "out_samples_44k1": int(out.shape[1])}
     if args.cpu_baseline:
-        torch.set_num_threads(os.cpu_count() or 1)
+        torch.set_num_threads(min(16, os.cpu_count() or 1))       # (256 threads on the GPU box's host: 50 s per forward, 20x slower than 8 in the build container)
         net = MO.MdxOracle(arch, sd)
         xc = MO.seeded_input(arch, 1, 21)
         net.forward(xc)
