@@ -810,6 +810,29 @@ def main():
                                                   "outside_the_loop_us": t17["outside_the_loop_us"], "source": pipes_src}
         if bounds_all:
             result["roofline_kernels"] = {k: v for k, v in bounds_all.items() if not k.startswith("_")}
+        # energy: the package sits on its 1.4 kW cap in every workload, so step time follows joules per utterance.  tools/energy_table.py
+        # loops each block kernel alone (two lanes) under a rocm-smi sampler; its committed table is read here, nothing is typed in.
+        energy_e, energy_src = committed(("r06_energy.json",), a.workload)
+        if energy_e and not a.fp8:
+            cls = energy_e["classes"]
+
+            def cflops(r):
+                return 4.0 * r["M"] * r["M"] * 64 * r["N"] if r["kernel"] == "attention" else 2.0 * r["M"] * r["N"] * r["K"]
+            tot_fl = sum(cflops(r) * r["launches_per_step_batch"] for r in cls)
+            tot_j = energy_e["sum_j_block_kernels"]
+            result["roofline"]["energy"] = {
+                "j_per_utterance_measured": energy_e.get("workload", {}).get("j_per_utterance"),
+                "package_w": energy_e.get("workload", {}).get("package_w"), "sclk_mhz": energy_e.get("workload", {}).get("sclk_mhz"),
+                "table_over_measured": energy_e.get("check", {}).get("ratio"),
+                "pj_per_flop_block_kernels": tot_j / tot_fl * 1e12,
+                "power_capped_tflops": 1400.0 / (tot_j / tot_fl) / 1e12,      # what 1.4 kW buys at this path's energy per flop
+                "by_kernel": {r["class"]: {"j_per_launch": r["j_per_launch"], "package_w": r["package_w"], "sclk_mhz": r["sclk_mhz"],
+                                           "us_per_launch_alone_two_lanes": r["us_per_launch"], "pj_per_flop": (r["j_per_launch"] / cflops(r) * 1e12) if cflops(r) else None,
+                                           "energy_share": r["share_of_table_j"],
+                                           "flop_share": cflops(r) * r["launches_per_step_batch"] / tot_fl} for r in cls},
+                "note": "each block kernel looped alone in two concurrent lanes for 3 s under a rocm-smi sampler; J per launch = W x us / lanes; "
+                        "the sum over a step batch is checked against W x ms of the workload itself on the same lease (table_over_measured)",
+                "source": energy_src}
         g_ms = sum(v["ms"] for s, v in by_sym.items() if s != "attn_fwd_splitkv_kernel")
         g_fl = sum(v["flops"] for s, v in by_sym.items() if s != "attn_fwd_splitkv_kernel")
         gpeak = MFMA_FP8_PEAK_TFLOPS if a.fp8 else MFMA_BF16_PEAK_TFLOPS

@@ -667,6 +667,37 @@ extern "C" int lemas_k_bench(const char* what, int32_t M, int32_t N, int32_t K, 
               n, bh, grid, (t3 - t0) * 0.01, st / grid, sp / grid, sl / grid, se / grid);
     }
 #endif
+  } else if (w == "ln_mod") {
+    // M rows of D = N fp32 -> bf16 (the AdaLN-modulated LayerNorm in front of QKV and FF1)
+    float* x = sc.get<float>((size_t)M * N);
+    bf16_t* o = sc.get<bf16_t>((size_t)M * N);
+    float* tab = sc.get<float>((size_t)2 * N);
+    int* step = sc.get<int>(16);
+    if (!x || !o || !tab || !step) { set_error("bench: out of memory"); return LEMAS_E_STATE; }
+    hipLaunchKernelGGL(fill_pattern_kernel, dim3(1024), dim3(256), 0, s, reinterpret_cast<bf16_t*>(x), (size_t)M * N * 2, 6u);
+    rc = time_it([&]() { return launch_ln_mod(x, o, M, N, tab, 0, 0, N, step, s); });
+  } else if (w == "gemm_qkv") {
+    // the fused QK (N = 2048, RoPE epilogue) + V (N = 1024, transposed store) launch of a lane; K = 1024
+    const int in = 1024, npad = (M + 127) & ~127;
+    bf16_t* a = sc.get<bf16_t>((size_t)M * K);
+    bf16_t* wt = sc.get<bf16_t>((size_t)3 * in * K);
+    float* b = sc.get<float>(3 * in);
+    bf16_t* q = sc.get<bf16_t>((size_t)M * in);
+    bf16_t* k = sc.get<bf16_t>((size_t)M * in);
+    bf16_t* vt = sc.get<bf16_t>((size_t)16 * 64 * npad);
+    float* rc_ = sc.get<float>((size_t)M * 32);
+    float* rs_ = sc.get<float>((size_t)M * 32);
+    int* step = sc.get<int>(16);
+    if (!a || !wt || !b || !q || !k || !vt || !rc_ || !rs_ || !step) { set_error("bench: out of memory"); return LEMAS_E_STATE; }
+    hipLaunchKernelGGL(fill_pattern_kernel, dim3(1024), dim3(256), 0, s, a, (size_t)M * K, 1u);
+    hipLaunchKernelGGL(fill_pattern_kernel, dim3(1024), dim3(256), 0, s, wt, (size_t)3 * in * K, 2u);
+    GemmParams gq{};
+    gq.A = a; gq.W = wt; gq.bias = b; gq.M = M; gq.N = 2 * in; gq.K = K; gq.n_valid = 2 * in; gq.ldc = 2 * in; gq.step_idx = step;
+    gq.seq_pitch = M; gq.seq_valid = M; gq.batch = 1; gq.heads = 16; gq.npad = npad; gq.q = q; gq.k = k; gq.vt = vt; gq.rope_cos = rc_; gq.rope_sin = rs_;
+    GemmParams gv = gq;
+    gv.W = wt + (size_t)2 * in * K; gv.bias = b + 2 * in; gv.N = in; gv.n_valid = in; gv.ldc = in;
+    gq.tile = gv.tile = variant;
+    rc = time_it([&]() { return launch_gemm_qkv_fused(gq, gv, s); });
   } else {
     set_error("bench: unknown kernel '%s'", what);
     rc = LEMAS_E_ARG;

@@ -12,7 +12,7 @@
 * ``cpu_baseline`` (--cpu-baseline): the fp32 restatement (oracle/mdx_oracle.py, test infrastructure; torch CPU kernels) on one sample
   of the same shape on this box's host cores -- the reference itself ran 2.3 s per forward on 8 threads in the build container
   (tests/golden/mdxnet_kim.npz ref_seconds).
-Synthetic seeded weights (oracle/mdx_oracle.seeded_state_dict)."""
+Synthetic seeded weights (lemas_tts_amd/synth.py synth_mdx_state_dict)."""
 import argparse
 import json
 import os
@@ -24,8 +24,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from oracle import mdx_oracle as MO   # noqa: E402
+from lemas_tts_amd import synth   # noqa: E402
 from lemas_tts_amd.engine import MdxEngine   # noqa: E402
+from lemas_tts_amd.uvr5.arch import KIM_VOCAL_1, MdxArch, flops   # noqa: E402
 
 F32_MFMA_PEAK = 157.3e12
 
@@ -38,10 +39,10 @@ def main():
     ap.add_argument("--cpu-baseline", action="store_true")
     ap.add_argument("--small", action="store_true", help="dim_f 768, dim_t 64 (a quick run under a profiler)")
     args = ap.parse_args()
-    arch = MO.MdxArch(dim_f=768, dim_t=64) if args.small else MO.KIM_VOCAL_1
-    sd = MO.seeded_state_dict(arch, 20)
+    arch = MdxArch(dim_f=768, dim_t=64) if args.small else KIM_VOCAL_1
+    sd = synth.synth_mdx_state_dict(arch, 20)
     eng = MdxEngine(arch, sd)
-    x = torch.from_numpy(MO.seeded_input(arch, args.batch, 21)).to("cuda:0")
+    x = torch.from_numpy(synth.synth_mdx_input(arch, args.batch, 21)).to("cuda:0")
     for _ in range(2):
         eng.forward(x)
     torch.cuda.synchronize()
@@ -80,13 +81,14 @@ def main():
                            "chunks": int(-(-out.shape[1] // uv.model.gen_size)), "is_denoise": True, "out_samples_44k1": int(out.shape[1])}
     if args.cpu_baseline:
         torch.set_num_threads(min(16, os.cpu_count() or 1))       # (256 threads on the GPU box's host: 50 s per forward, 20x slower than 8 in the build container)
+        from oracle import mdx_oracle as MO            # the CPU baseline IS the oracle (test infrastructure), timed, never shipped
         net = MO.MdxOracle(arch, sd)
-        xc = MO.seeded_input(arch, 1, 21)
+        xc = synth.synth_mdx_input(arch, 1, 21)
         net.forward(xc)
         t0 = time.perf_counter()
         net.forward(xc)
         dc = time.perf_counter() - t0
-        line["cpu_baseline"] = {"value": MO.flops(arch) / dc / 1e12, "unit": "TFLOP/s", "seconds_per_forward": dc, "cores": torch.get_num_threads(),
+        line["cpu_baseline"] = {"value": flops(arch) / dc / 1e12, "unit": "TFLOP/s", "seconds_per_forward": dc, "cores": torch.get_num_threads(),
                                 "kind": "port", "sample": "one forward of one sample, the same shape and weights (torch CPU fp32)"}
     print(json.dumps(line))
 
