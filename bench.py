@@ -842,7 +842,17 @@ def main():
         result["kernel_time_share"] = {k: round(v[0] / total_ms, 4) for k, v in prof.items() if v[1] > 0}
         result["kernel_avg_us"] = {k: round(1e3 * v[0] / v[1], 2) for k, v in prof.items() if v[1] > 0}
 
+        # batched shapes: the in-situ timeline of one ODE step (measurement build, tools/timeline_step.py --json), committed -- per block the sum of
+        # the launches' in-situ spans, the gaps between consecutive launches of a lane by site, how much of the step has one / two launches in
+        # flight, and which launch is the one that is alone
+        tl_e, tl_src = committed((f"r06_timeline_{a.workload}.json",))
+        if tl_e and B > 1 and a.dual and not a.fp8:
+            result["roofline"]["latency_batched"] = dict({k: v for k, v in tl_e.items() if not k.startswith("_")}, source=tl_src,
+                                                         block_us_this_run=None)
+
         def add_latency_roofline(step_loop_ms, clock_ghz):
+            if "latency_batched" in result["roofline"] and a.depth > 0:
+                result["roofline"]["latency_batched"]["block_us_this_run"] = 1e3 * step_loop_ms / nfe / a.depth
             # batch 1, two lanes, bf16: the block is a dependent chain per lane, priced against its latency floor next to the MFMA figure
             if pipes and B == 1 and a.dual and not a.fp8 and a.depth > 0:
                 result["latency_roofline"] = latency_roofline(result["kernel_avg_us"], pipes, int(rows), 1e3 * step_loop_ms / nfe / a.depth, lanes, clock_ghz)

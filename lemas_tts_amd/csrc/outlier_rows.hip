@@ -20,6 +20,7 @@
 // lane owns ONE row m and 16 of the 32 channel slots.
 // MEASUREMENT BUILDS ONLY since round 6 (-DLEMAS_MEASUREMENT_BUILD): the decomposition holds the 1e-4 target but is slower than the all-bf16
 // fallback it replaces (profiles/r05/r05h_outlier_throughput.txt), so the product library does not carry this kernel or its engine option.
+#include "common.h"      // (defines LEMAS_MEASUREMENT_BUILD for -DLEMAS_PHASE_TIMESTAMPS builds too)
 #ifdef LEMAS_MEASUREMENT_BUILD
 #include "common.h"
 

@@ -33,6 +33,9 @@ def test_header_symbols_are_exported():
         assert hasattr(T, name), f"{name} declared in lemas_hip_test.h but not exported by liblemas_hip_test.so"
     exported = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
     assert "lemas_k_" not in exported and "force_tiles" not in exported, "the product library must not carry test hooks"
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    own = [l for l in undefined.splitlines() if "launch_" in l or "lemas" in l]
+    assert not own, f"the product library references its own symbols without defining them (a source compiled out by a build flag?): {own}"
     assert set(_lib.EXPORTED) == product, (set(_lib.EXPORTED) ^ product)
     assert set(_lib.EXPORTED_TEST) == tests, (set(_lib.EXPORTED_TEST) ^ tests)
 

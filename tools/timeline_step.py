@@ -31,6 +31,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="configs1")
     ap.add_argument("--opt", nargs="*", default=[], help="engine options key=value (e.g. ln_fold=1)")
+    ap.add_argument("--json", default=None, help="also write the per-block figures as JSON (what bench.py's roofline.latency_batched reads)")
     a = ap.parse_args()
     global NAMES
     w = dict(Bn.WORKLOADS[a.workload])
@@ -98,6 +99,49 @@ def main():
         last, depth = tt, depth + dlt
     tot = t1 - t0
     print(f"# of the step: no stamped launch in flight {100 * busy[0] / tot:.1f} %, one {100 * busy[1] / tot:.1f} %, two or more {100 * busy[2] / tot:.1f} %")
+    # WHICH launch is alone when exactly one is in flight (and what the other lane is doing then: it sits in a gap between two of ITS launches --
+    # the LayerNorm launches, which are not stamped, or a launch boundary)
+    alone = {n: 0.0 for n in NAMES}
+    other_gap = {}
+    spans = sorted(rec, key=lambda r: r[3])
+    edges = sorted({r[3] for r in rec} | {r[4] for r in rec})
+    lane_seq = {ln: sorted((r for r in rec if r[1] == ln), key=lambda r: r[3]) for ln in (0, 1)}
+    for x0, x1 in zip(edges, edges[1:]):
+        mid_t = 0.5 * (x0 + x1)
+        live = [r for r in spans if r[3] <= mid_t < r[4]]
+        if len(live) != 1:
+            continue
+        r = live[0]
+        alone[r[2]] += x1 - x0
+        oseq = lane_seq[1 - r[1]]
+        prev = [q for q in oseq if q[4] <= mid_t]
+        nxt = [q for q in oseq if q[3] > mid_t]
+        key = f"{prev[-1][2] if prev else 'start'}->{nxt[0][2] if nxt else 'end'}"
+        other_gap[key] = other_gap.get(key, 0.0) + (x1 - x0)
+    print("# alone in flight, us per block by launch: " + "  ".join(f"{k} {v / arch.depth:.1f}" for k, v in alone.items()))
+    print("# ... while the other lane sits between: " + "  ".join(f"{k} {v / arch.depth:.1f}" for k, v in sorted(other_gap.items(), key=lambda kv: -kv[1])))
+    if a.json:
+        import json
+        per_lane_gaps = {}
+        for ln in (0, 1):
+            seq = lane_seq[ln]
+            for x, y in zip(seq, seq[1:]):
+                per_lane_gaps.setdefault(f"{x[2]}->{y[2]}", []).append(y[3] - x[4])
+        out = {"_source": f"tools/timeline_step.py --workload {a.workload} (measurement build, -DLEMAS_PHASE_TIMESTAMPS): per-workgroup wall-clock stamps of every "
+                          "block GEMM / attention launch of the LAST ODE step, replayed from the captured graph",
+               "workload": a.workload, "options": a.opt, "blocks": arch.depth, "lanes": 2, "stamped_launches": len(rec),
+               "us_per_block": (t1 - t0) / arch.depth,
+               "in_situ_span_us": {n: float(np.mean([r[4] - r[3] for r in rec if r[2] == n])) for n in NAMES},
+               "sum_in_situ_spans_us_per_block_per_lane": float(sum(np.mean([r[4] - r[3] for r in rec if r[2] == n]) for n in NAMES)),
+               "gaps_us_by_site": {k: float(np.mean(v)) for k, v in per_lane_gaps.items()},
+               "sum_gaps_us_per_block_per_lane": float(sum(np.mean(v) for v in per_lane_gaps.values())),
+               "share_in_flight": {"none": busy[0] / tot, "one": busy[1] / tot, "two_or_more": busy[2] / tot},
+               "alone_in_flight_us_per_block": {k: v / arch.depth for k, v in alone.items()},
+               "alone_while_other_lane_between_us_per_block": {k: v / arch.depth for k, v in sorted(other_gap.items(), key=lambda kv: -kv[1])},
+               "workgroups": {n: int(np.median([r[5] for r in rec if r[2] == n])) for n in NAMES}}
+        with open(a.json, "w") as f:
+            json.dump(out, f, indent=1)
+        print("wrote", a.json)
 
 
 if __name__ == "__main__":
