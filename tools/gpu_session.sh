@@ -83,7 +83,7 @@ for step in "$@"; do
     timeline)
       LEMAS_EXTRA_HIPCC_FLAGS=-DLEMAS_PHASE_TIMESTAMPS timeout 900 python -c "from lemas_tts_amd import build; build.build_library(force=True)"
       for w in $(echo "${rest:-configs1}" | tr ',' ' '); do
-        timeout 600 python tools/timeline_step.py --workload $w --json "$O/${TAG}_timeline_$w.json" ${TLOPT:+--opt $TLOPT} 2>&1 | grep -v amdgpu.ids > "$O/${TAG}_timeline_step_$w${TLOPT:+_$(echo $TLOPT | tr -d ' =')}.txt"; head -40 "$O/${TAG}_timeline_step_$w${TLOPT:+_$(echo $TLOPT | tr -d ' =')}.txt"
+        timeout 600 python tools/timeline_step.py --workload $w --json "$O/${TAG}_timeline_$w${TLOPT:+_$(echo $TLOPT | tr -d ' =')}.json" ${TLOPT:+--opt $TLOPT} 2>&1 | grep -v amdgpu.ids > "$O/${TAG}_timeline_step_$w${TLOPT:+_$(echo $TLOPT | tr -d ' =')}.txt"; head -40 "$O/${TAG}_timeline_step_$w${TLOPT:+_$(echo $TLOPT | tr -d ' =')}.txt"
       done
       timeout 900 python -c "from lemas_tts_amd import build; build.build_library(force=True)" ;;
     kbench)
