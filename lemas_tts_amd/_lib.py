@@ -125,6 +125,7 @@ def lib():
         "lemas_mdx_destroy": (None, [vp]),
         "lemas_mdx_load_weight": (C.c_int, [vp, C.c_char_p, vp, C.POINTER(i64), i32]),
         "lemas_mdx_finalize": (C.c_int, [vp]),
+        "lemas_mdx_set_option": (C.c_int, [vp, C.c_char_p, i64]),
         "lemas_mdx_forward": (C.c_int, [vp, vp, i32, vp, vp]),
         "lemas_mdx_tap": (C.c_int, [vp, C.c_char_p, vp]),
         "lemas_mdx_flops": (C.c_int64, [vp, i32]),
@@ -189,7 +190,7 @@ EXPORTED = [      # include/lemas_hip.h: the product library
     "lemas_prosody_create", "lemas_prosody_destroy", "lemas_prosody_load_weight", "lemas_prosody_finalize", "lemas_prosody_fbank_frames",
     "lemas_prosody_fbank", "lemas_prosody_encode",
     "lemas_stft_create", "lemas_stft_destroy", "lemas_stft_ld", "lemas_stft_frames", "lemas_stft_forward", "lemas_stft_inverse",
-    "lemas_mdx_create", "lemas_mdx_destroy", "lemas_mdx_load_weight", "lemas_mdx_finalize", "lemas_mdx_forward", "lemas_mdx_tap", "lemas_mdx_flops",
+    "lemas_mdx_create", "lemas_mdx_destroy", "lemas_mdx_load_weight", "lemas_mdx_finalize", "lemas_mdx_set_option", "lemas_mdx_forward", "lemas_mdx_tap", "lemas_mdx_flops",
 ]
 EXPORTED_TEST = [  # include/lemas_hip_test.h: the test library
     "lemas_k_linear_bf16", "lemas_k_linear_f32", "lemas_k_attention", "lemas_k_attention_variant", "lemas_k_ln_mod", "lemas_k_convpos", "lemas_k_bench", "lemas_k_gemm_epi",

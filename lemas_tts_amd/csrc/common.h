@@ -404,7 +404,8 @@ struct GemmF32Params {
 hipError_t launch_gemm_f32(int epi, const GemmF32Params& p, hipStream_t s);
 
 // ---- UVR5 MDX-Net (mdx_kernels.hip): planar [b][c][t][f] fp32, implicit-GEMM convolutions on the f32 MFMA --------------------------
-enum MdxConvKind : int { MDX_CONV3 = 0 /* 3x3 s1 p1 */, MDX_DOWN2 = 1 /* 2x2 s2 */, MDX_UP2 = 2 /* transposed 2x2 s2 (+ skip product) */ };
+enum MdxConvKind : int { MDX_CONV3 = 0 /* 3x3 s1 p1 */, MDX_DOWN2 = 1 /* 2x2 s2 */, MDX_UP2 = 2 /* transposed 2x2 s2 (+ skip product) */,
+                          MDX_CONV3_BX = 3 /* 3x3 s1 p1 on split-bf16 operands: weights [ntiles][ceil(Cin / 16)][10 taps][2][48][8] packed (hi << 16 | lo) */ };
 struct MdxConvParams {
   const float* x;        // [B][Cin][Ti][Fi]
   const float* w;        // re-laid weights [ntiles][nchunks][8][mdx_conv_ciw(kind)] (norm folded in)

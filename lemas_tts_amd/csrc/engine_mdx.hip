@@ -37,6 +37,19 @@ struct NormP {            // GroupNorm affine (device) -- BatchNorm lives folded
   DevVec gamma, beta, scale, shift;
 };
 
+// fp32 -> (bf16(x) << 16) | bf16(x - bf16(x)), both round-to-nearest-even: the split-operand format of mdx_conv3_bx_kernel
+inline uint32_t bf16_rne(float x) {
+  uint32_t u;
+  std::memcpy(&u, &x, 4);
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+inline uint32_t split_pack(float x) {
+  const uint32_t h = bf16_rne(x), hb = h << 16;
+  float hf;
+  std::memcpy(&hf, &hb, 4);
+  return hb | (bf16_rne(x - hf) & 0xFFFFu);
+}
+
 struct ConvP {
   int kind = 0, cin = 0, cout = 0, nchunks = 0, ntiles = 0;
   DevVec w, bias;
@@ -63,6 +76,7 @@ struct lemas_mdx {
   lemas_mdx_config cfg{};
   int n = 0;
   bool finalized = false;
+  bool bf16x3 = false;      // option "bf16x3": the 3x3 convolutions on split-bf16 operands (mdx_kernels.hip), set before finalize()
   std::map<std::string, std::vector<int64_t>> schema;
   std::map<std::string, std::vector<float>> host;
   std::map<std::string, float*> taps;
@@ -175,6 +189,7 @@ struct lemas_mdx {
   // conv weight `wname` ([co][ci][k][k], or [ci][co][2][2] for the transposed one) + norm at `nname` -> the kernel's K-slab layout
   int conv_build(ConvP& c, int kind, int cin, int cout, const std::string& wname, const std::string& bname, const std::string& nname) const {
     c.kind = kind; c.cin = cin; c.cout = cout;
+    if (kind == MDX_CONV3 && bf16x3 && !group_norm()) return conv_build_bx(c, cin, cout, wname, bname, nname);
     const int taps = kind == MDX_CONV3 ? 9 : kind == MDX_DOWN2 ? 4 : 1;
     const int cols = kind == MDX_UP2 ? 4 * cout : cout;
     const int ciw = mdx_conv_ciw(kind);
@@ -202,6 +217,29 @@ struct lemas_mdx {
     RC_TRY(c.w.upload(slab));
     RC_TRY(c.bias.upload(bias));
     RC_TRY(norm_upload(nname, cout, c.norm, false));
+    return 0;
+  }
+
+  // the split-bf16 slab: [ntile][chunk of 16 ci][10 taps][2 channel blocks][48 co][8 ci] packed dwords, tap 9 zero
+  int conv_build_bx(ConvP& c, int cin, int cout, const std::string& wname, const std::string& bname, const std::string& nname) const {
+    c.kind = MDX_CONV3_BX;
+    c.nchunks = (cin + 15) / 16; c.ntiles = (cout + 47) / 48;
+    std::vector<float> sc, sh;
+    norm_fold(nname, cout, sc, sh);
+    const std::vector<float>&w = H(wname), &b = H(bname);
+    const size_t per_chunk = (size_t)10 * 2 * 48 * 8;
+    std::vector<float> slab((size_t)c.ntiles * c.nchunks * per_chunk, 0.f), bias(cout);
+    uint32_t* bits = reinterpret_cast<uint32_t*>(slab.data());
+    for (int co = 0; co < cout; ++co) bias[co] = sc[co] * b[co] + sh[co];
+    for (int co = 0; co < cout; ++co)
+      for (int ci = 0; ci < cin; ++ci)
+        for (int tap = 0; tap < 9; ++tap) {
+          const float v = w[((size_t)co * cin + ci) * 9 + tap] * sc[co];
+          const int nt = co / 48, nn = co % 48, ch = ci / 16, cb = (ci % 16) / 8, k = ci % 8;
+          bits[((size_t)nt * c.nchunks + ch) * per_chunk + (((size_t)tap * 2 + cb) * 48 + nn) * 8 + k] = split_pack(v);
+        }
+    RC_TRY(c.w.upload(slab));
+    RC_TRY(c.bias.upload(bias));
     return 0;
   }
 
@@ -476,6 +514,17 @@ int lemas_mdx_forward(lemas_mdx* m, const float* spek, int32_t batch, float* out
   if (!m || !spek || !out || batch <= 0) { set_error("lemas_mdx_forward: bad arguments"); return LEMAS_E_ARG; }
   if (!m->finalized) { set_error("lemas_mdx_forward: finalize() first"); return LEMAS_E_STATE; }
   return m->forward(spek, batch, out, (hipStream_t)stream);
+}
+
+int lemas_mdx_set_option(lemas_mdx* m, const char* key, int64_t value) {
+  if (!m || !key) { set_error("lemas_mdx_set_option: null argument"); return LEMAS_E_ARG; }
+  if (!std::strcmp(key, "bf16x3")) {
+    if (m->finalized) { set_error("lemas_mdx_set_option: 'bf16x3' decides the weight layout and must be set before finalize()"); return LEMAS_E_STATE; }
+    m->bf16x3 = value != 0;
+    return 0;
+  }
+  set_error("lemas_mdx_set_option: unknown option '%s'", key);
+  return LEMAS_E_ARG;
 }
 
 int lemas_mdx_tap(lemas_mdx* m, const char* name, float* dev_out) {

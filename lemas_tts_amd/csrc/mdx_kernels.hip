@@ -207,6 +207,215 @@ __global__ __launch_bounds__(256, 2) void mdx_conv_kernel(const MdxConvParams p)
   }
 }
 
+// ---- split-bf16 ("bf16x3") form of the 3x3 convolution -------------------------------------------------------------------------------
+// Engine option "bf16x3" (lemas_mdx_set_option, default 0 = the exact kernel above).  Every fp32 operand x is carried as TWO bf16 numbers,
+// hi = bf16(x) and lo = bf16(x - hi) (x = hi + lo to 2^-17 relative), packed in one dword (hi << 16 | lo) -- the bytes of an fp32, so nothing
+// grows in memory or LDS -- and each product is three bf16 MFMAs: W_hi A_hi + W_hi A_lo + W_lo A_hi (the dropped W_lo A_lo is 2^-16 of the
+// product).  v_mfma_f32_16x16x32_bf16 does 16 x 16 x 32 in 16 cycles where the f32-input MFMA does 16 x 16 x 4 in 32: 16x the rate, 5.3x after
+// the three-way split, at ~2^-16 relative precision per product (fp32 accumulation as before) -- between TF32 (2^-11, what the reference's
+// onnxruntime CUDA provider uses for convolutions by default) and fp32 (2^-24).  Weights are split on the host at finalize(); activations stay
+// fp32 in global memory and are split when a halo is parked in LDS, once per element, not once per use.
+// K = 32 of one MFMA = 2 taps x 16 input channels: lane group g = lane >> 4 takes tap 2 tp + (g >> 1), channels 8 (g & 1) .. + 7 (its 8
+// consecutive k); taps run in 5 pairs, the 10th tap has zero weights.  The halo stays planar ([ci][row][col], planes == 2 (mod 4) words so that
+// the two channel blocks of a 32-lane read group sit on disjoint banks): a fragment is 8 ds_read_b32 + 8 v_perm_b32 (hi halves / lo halves of
+// dword pairs); the weight slab is laid out on the host so that a lane's 8 dwords are contiguous (2 ds_read_b128).  One LDS buffer of 58 KB,
+// two workgroups per CU: while one parks (converts) the other multiplies.
+constexpr int CKB = 16;        // input channels per K chunk of the split-bf16 kernel
+constexpr int BX_TAPS = 10;    // 9 taps + 1 of zero weights: 5 MFMA steps of 2 taps
+
+template <int MT>
+struct GeomBx {
+  static constexpr int TF = 16 * MT, ROWS = 6, ROWP = TF + 8, COL0 = 3;
+  static constexpr int PLANE0 = ROWS * ROWP;
+  static constexpr int PLANE = PLANE0 + ((2 - PLANE0 % 4) + 4) % 4;          // == 2 (mod 4): 8 planes == 16 (mod 32)
+  static constexpr int Q = ROWP / 4;
+  static constexpr int A_F4 = CKB * ROWS * Q, W_WORDS = BX_TAPS * 2 * NTW * 8, W_F4 = W_WORDS / 4;
+  static constexpr int A_IT = (A_F4 + 255) / 256, W_IT = (W_F4 + 255) / 256;
+};
+
+__device__ __forceinline__ void split_pack2(float x0, float x1, unsigned& p0, unsigned& p1) {
+  unsigned h, l;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(h) : "v"(x0), "v"(x1));          // round to nearest even: {bf16(x0), bf16(x1)}
+  const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xFFFF0000u);   // exact
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(l) : "v"(r0), "v"(r1));
+  p0 = (h << 16) | (l & 0xFFFFu);
+  p1 = (h & 0xFFFF0000u) | (l >> 16);
+}
+
+template <int MT, bool VEC, int NPROD>
+__global__ __launch_bounds__(256, 2) void mdx_conv3_bx_kernel(const MdxConvParams p) {
+  using G = GeomBx<MT>;
+  __shared__ __attribute__((aligned(16))) unsigned As[CKB * G::PLANE];
+  __shared__ __attribute__((aligned(16))) unsigned Ws[G::W_WORDS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int f0 = blockIdx.x * G::TF, t0 = blockIdx.y * 4;
+  const int b = blockIdx.z / p.ntiles, nt = blockIdx.z % p.ntiles;
+  const float* xb = p.x + (size_t)b * p.Cin * p.Ti * p.Fi;
+  const u32x4* wsrc = reinterpret_cast<const u32x4*>(p.w) + (size_t)nt * p.nchunks * G::W_F4;
+  const size_t plane = (size_t)p.Ti * p.Fi;
+
+  const float* a_ptr[G::A_IT];
+  int a_lds[G::A_IT], a_lim[G::A_IT];
+  unsigned a_ok = 0;
+#pragma unroll
+  for (int it = 0; it < G::A_IT; ++it) {
+    const int idx = tid + it * 256;
+    const int ci = idx / (G::ROWS * G::Q), rem = idx % (G::ROWS * G::Q), r = rem / G::Q, q = rem % G::Q;
+    const int tin = t0 - 1 + r, fin = f0 - 4 + 4 * q;
+    const bool slot = idx < G::A_F4, rowin = slot && tin >= 0 && tin < p.Ti;
+    a_lds[it] = slot ? ci * G::PLANE + r * G::ROWP + 4 * q : -1;
+    a_lim[it] = slot ? p.Cin - ci : 0;
+    a_ptr[it] = xb;
+    if (VEC) {
+      if (rowin && fin >= 0 && fin < p.Fi) { a_ok |= 0xFu << (4 * it); a_ptr[it] = xb + (size_t)ci * plane + (size_t)tin * p.Fi + fin; }
+    } else if (rowin) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (fin + e >= 0 && fin + e < p.Fi) a_ok |= 1u << (4 * it + e);
+      a_ptr[it] = xb + (size_t)ci * plane + (size_t)tin * p.Fi + fin;
+    }
+  }
+  const f32x4 zv = {0.f, 0.f, 0.f, 0.f};
+  f32x4 ra[G::A_IT];
+  u32x4 rw[G::W_IT];
+
+  auto gload = [&](int chunk) {
+#pragma unroll
+    for (int it = 0; it < G::A_IT; ++it) {
+      const bool cok = chunk * CKB < a_lim[it];
+      const float* src = cok ? a_ptr[it] + (size_t)chunk * CKB * plane : xb;
+      if (VEC) {
+        ra[it] = *reinterpret_cast<const f32x4*>(src);
+      } else {
+        f32x4 v = zv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (cok && (a_ok >> (4 * it + e) & 1)) v[e] = src[e];
+        ra[it] = v;
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < G::W_IT; ++it) {
+      const int idx = tid + it * 256;
+      rw[it] = wsrc[(size_t)chunk * G::W_F4 + (idx < G::W_F4 ? idx : 0)];
+    }
+  };
+  auto park = [&](int chunk) {
+#pragma unroll
+    for (int it = 0; it < G::A_IT; ++it) {
+      if (a_lds[it] < 0) continue;
+      f32x4 v = ra[it];
+      if (VEC && !((a_ok >> (4 * it) & 1) && chunk * CKB < a_lim[it])) v = zv;
+      unsigned p0, p1, p2, p3;
+      split_pack2(v[0], v[1], p0, p1);
+      split_pack2(v[2], v[3], p2, p3);
+      uint2* dst = reinterpret_cast<uint2*>(&As[a_lds[it]]);                   // planes are == 2 (mod 4) words: 8-B aligned, not 16
+      dst[0] = make_uint2(p0, p1);
+      dst[1] = make_uint2(p2, p3);
+    }
+#pragma unroll
+    for (int it = 0; it < G::W_IT; ++it) {
+      const int idx = tid + it * 256;
+      if (idx < G::W_F4) *reinterpret_cast<u32x4*>(&Ws[idx * 4]) = rw[it];
+    }
+  };
+
+  f32x4 acc[MT][3];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[i][j] = zv;
+
+  // this lane's operand bases: channel block g & 1, tap 2 tp + (g >> 1) (tap 9 has zero weights: it reads tap 8's, valid, halo)
+  const int a_base = (g & 1) * 8 * G::PLANE + wave * G::ROWP + l15 + G::COL0;
+  int toff[5];
+#pragma unroll
+  for (int tp = 0; tp < 5; ++tp) {
+    const int tap = min(2 * tp + (g >> 1), 8);
+    toff[tp] = (tap / 3) * G::ROWP + tap % 3;
+  }
+  const int w_base = ((g >> 1) * 2 + (g & 1)) * NTW * 8 + l15 * 8;
+
+  gload(0);
+  for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+    park(chunk);
+    __syncthreads();
+    if (chunk + 1 < p.nchunks) gload(chunk + 1);
+#pragma unroll
+    for (int tp = 0; tp < 5; ++tp) {
+      bf16x8 bh[3], bl[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const u32x4 w0 = *reinterpret_cast<const u32x4*>(&Ws[w_base + tp * 4 * NTW * 8 + j * 16 * 8]);
+        const u32x4 w1 = *reinterpret_cast<const u32x4*>(&Ws[w_base + tp * 4 * NTW * 8 + j * 16 * 8 + 4]);
+        u32x4 h, l;
+        h[0] = __builtin_amdgcn_perm(w0[1], w0[0], 0x07060302u); l[0] = __builtin_amdgcn_perm(w0[1], w0[0], 0x05040100u);
+        h[1] = __builtin_amdgcn_perm(w0[3], w0[2], 0x07060302u); l[1] = __builtin_amdgcn_perm(w0[3], w0[2], 0x05040100u);
+        h[2] = __builtin_amdgcn_perm(w1[1], w1[0], 0x07060302u); l[2] = __builtin_amdgcn_perm(w1[1], w1[0], 0x05040100u);
+        h[3] = __builtin_amdgcn_perm(w1[3], w1[2], 0x07060302u); l[3] = __builtin_amdgcn_perm(w1[3], w1[2], 0x05040100u);
+        bh[j] = __builtin_bit_cast(bf16x8, h); bl[j] = __builtin_bit_cast(bf16x8, l);
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const unsigned* A = &As[a_base + toff[tp] + i * 16];
+        unsigned d[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d[k] = A[k * G::PLANE];
+        u32x4 h, l;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          h[k] = __builtin_amdgcn_perm(d[2 * k + 1], d[2 * k], 0x07060302u);
+          l[k] = __builtin_amdgcn_perm(d[2 * k + 1], d[2 * k], 0x05040100u);
+        }
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, h), al = __builtin_bit_cast(bf16x8, l);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          if (NPROD >= 4) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], al, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah, acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  const int t = t0 + wave;
+  if (t >= p.Tg) return;
+  float* ob = p.out + (size_t)b * p.Cout * p.Tg * p.Fg;
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = nt * NTW + j * 16 + (lane >> 4) * 4 + r;
+      if (co >= p.Cout) continue;
+      const float bias = p.bias[co];
+      float* orow = ob + ((size_t)co * p.Tg + t) * p.Fg;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int f = f0 + i * 16 + l15;
+        if (f >= p.Fg) continue;
+        float v = acc[i][j][r] + bias;
+        if (p.relu) v = fmaxf(v, 0.f);
+        orow[f] = v;
+      }
+    }
+}
+
+template <bool VEC>
+hipError_t launch_bx(const MdxConvParams& p, hipStream_t s) {
+  auto wgs = [&](int mt) { return (long)((p.Fg + 16 * mt - 1) / (16 * mt)) * ((p.Tg + 3) / 4) * p.B * p.ntiles; };
+  int mt = 4;
+  while (mt > 1 && wgs(mt) < 512) mt >>= 1;
+  const dim3 grid((p.Fg + 16 * mt - 1) / (16 * mt), (p.Tg + 3) / 4, p.B * p.ntiles);
+  if (grid.y > 65535 || grid.z > 65535) return hipErrorInvalidValue;
+  if (mt == 4) hipLaunchKernelGGL((mdx_conv3_bx_kernel<4, VEC, 3>), grid, dim3(256), 0, s, p);
+  else if (mt == 2) hipLaunchKernelGGL((mdx_conv3_bx_kernel<2, VEC, 3>), grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((mdx_conv3_bx_kernel<1, VEC, 3>), grid, dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
 template <int KH, int S, int PAD, bool UP, bool VEC>
 hipError_t launch_geom(const MdxConvParams& p, hipStream_t s) {
   // wider position tiles while they still give the chip ~2 workgroups per CU; the narrow ones for the deep, small levels
@@ -369,6 +578,10 @@ __global__ __launch_bounds__(256) void mdx_gn_apply_kernel(const float* __restri
 
 hipError_t launch_mdx_conv(int kind, const MdxConvParams& p, hipStream_t s) {
   if (p.B <= 0 || p.Cin <= 0 || p.Cout <= 0 || p.Tg <= 0 || p.Fg <= 0 || p.nchunks <= 0 || p.ntiles <= 0) return hipErrorInvalidValue;
+  if (kind == MDX_CONV3_BX) {
+    const bool vec = (p.Fi & 3) == 0 && (reinterpret_cast<size_t>(p.x) & 15) == 0;
+    return vec ? launch_bx<true>(p, s) : launch_bx<false>(p, s);
+  }
   switch (kind) {
     case MDX_CONV3: return launch_geom<3, 1, 1, false>(p, s);
     case MDX_DOWN2: return launch_geom<2, 2, 0, false>(p, s);
@@ -380,6 +593,7 @@ hipError_t launch_mdx_conv(int kind, const MdxConvParams& p, hipStream_t s) {
 // padded K-slab row length of the re-laid weights (floats per input channel): the engine builds [ntile][chunk][8][mdx_conv_ciw(kind)]
 int mdx_conv_ciw(int kind) {
   switch (kind) {
+    case MDX_CONV3_BX: return BX_TAPS * 2 * NTW * 8 / CKB;     // words per input channel of a 16-channel chunk slab (layout: see the kernel)
     case MDX_CONV3: return Geom<3, 1, 1, 1>::CIW;
     case MDX_DOWN2: return Geom<2, 2, 0, 1>::CIW;
     case MDX_UP2: return Geom<1, 1, 0, 1>::CIW;

@@ -414,7 +414,9 @@ class MdxEngine(_Streamed):
     optimizer`` (``bn`` None = no TDF branch; ``optimizer`` 'rmsprop' -> BatchNorm2d, 'adamw' -> GroupNorm(2, c)).
     ``state_dict``: the module's state dict (key names of the reference class; strict)."""
 
-    def __init__(self, arch, state_dict: dict, device="cuda:0"):
+    def __init__(self, arch, state_dict: dict, device="cuda:0", bf16x3: bool = False):
+        """``bf16x3``: the 3x3 convolutions on split-bf16 operands (three bf16 MFMAs per product, ~2^-16 relative precision, 5.3x the f32
+        matrix rate) instead of the exact f32-input MFMA."""
         super().__init__(device)
         get = (lambda k: arch[k]) if isinstance(arch, dict) else (lambda k: getattr(arch, k))
         opt = get("optimizer")
@@ -428,6 +430,8 @@ class MdxEngine(_Streamed):
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(L.lemas_mdx_create(C.byref(cfg), C.byref(self._h)), "lemas_mdx_create")
+            if bf16x3:
+                _lib.check(L.lemas_mdx_set_option(self._h, b"bf16x3", 1), "lemas_mdx_set_option")
             for name, v in state_dict.items():
                 _load(L.lemas_mdx_load_weight, self._h, name, v)
             _lib.check(L.lemas_mdx_finalize(self._h), "lemas_mdx_finalize")

@@ -135,6 +135,50 @@ def test_hip_network_edge_shapes_vs_oracle(arch, batch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["mini", "mini_wide", "mini_notdf"])
+def test_hip_network_split_bf16_matches_the_reference_class(golden_dir, name):
+    """Engine option bf16x3: the 3x3 convolutions on split-bf16 operands (x = hi + lo, three bf16 MFMAs per product; ~2^-16 relative per
+    product, fp32 accumulation).  Same vectors, same bar (1e-4 of the rms); measured ~2e-5."""
+    from lemas_tts_amd.engine import MdxEngine
+    fx, arch = _fx(golden_dir, name), MINIS[name]
+    eng = MdxEngine(arch, MO.seeded_state_dict(arch, int(fx["seed_weights"][0])), bf16x3=True)
+    bufs = {k[4:]: torch.zeros(fx[k].shape, device="cuda:0") for k in fx if k.startswith("tap_")}
+    for k, b in bufs.items():
+        eng.tap(k, b)
+    y = eng.forward(torch.from_numpy(fx["input"]).to("cuda:0"))
+    torch.cuda.synchronize()
+    worst = max(_rel(b.cpu().numpy(), fx[f"tap_{k}"]) for k, b in bufs.items())
+    e = _rel(y.cpu().numpy(), fx["output"])
+    print(f"\n[mdxnet {name}, bf16x3] output rel err {e:.2e}, worst stage {worst:.2e}")
+    assert e < REL and worst < REL
+
+
+@pytest.mark.gpu
+def test_hip_network_split_bf16_kim_shape_and_edges(golden_dir):
+    from lemas_tts_amd import _lib
+    from lemas_tts_amd.engine import MdxEngine
+    fx, arch = _fx(golden_dir, "kim"), MO.KIM_VOCAL_1
+    eng = MdxEngine(arch, MO.seeded_state_dict(arch, int(fx["seed_weights"][0])), bf16x3=True)
+    x = torch.from_numpy(MO.seeded_input(arch, 1, int(fx["seed_input"][0]))).to("cuda:0")
+    y = eng.forward(x).cpu().numpy()
+    rms = float(fx["rms"][0])
+    print(f"\n[mdxnet kim, bf16x3] sample max err / rms {np.abs(y[MO.KIM_SAMPLE] - fx['sample']).max() / rms:.2e}")
+    _check_kim(y, fx, REL)
+    with pytest.raises(_lib.LemasError, match="before finalize"):          # the option decides the weight layout
+        _lib.check(_lib.lib().lemas_mdx_set_option(eng._h, b"bf16x3", 0), "set_option")
+    del eng
+    for a2, batch in [(MO.MdxArch(dim_f=12, dim_t=6, num_blocks=3, l=2, g=20, bn=None), 2),       # scalar loads, ragged tiles, 20 -> 32 channel padding
+                      (MO.MdxArch(dim_f=200, dim_t=20, num_blocks=3, l=1, g=52, bn=5, bias=True), 1),
+                      (MO.MdxArch(dim_f=256, dim_t=64, num_blocks=7, l=1, g=16, bn=2, bias=False), 3)]:
+        sd = MO.seeded_state_dict(a2, 5)
+        xi = MO.seeded_input(a2, batch, 6)
+        ref = MO.MdxOracle(a2, sd).forward(xi).numpy()
+        e = _rel(MdxEngine(a2, sd, bf16x3=True).forward(torch.from_numpy(xi).to("cuda:0")).cpu().numpy(), ref)
+        print(f"[mdxnet edge {a2.dim_f}x{a2.dim_t} g{a2.g} n{a2.n}, bf16x3] rel err {e:.2e}")
+        assert e < REL
+
+
+@pytest.mark.gpu
 def test_hip_network_strict_loading():
     from lemas_tts_amd import _lib
     from lemas_tts_amd.engine import MdxEngine

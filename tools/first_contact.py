@@ -290,7 +290,7 @@ def main(argv=None):
                 if m is not None:
                     cond = torch.from_numpy(synth.synth_cond_mel(5, 120))[None].to(a.device)
                     text = torch.from_numpy(synth.synth_tokens(6, 40, vs))[None].to(a.device)
-                    out, _ = m.sample(cond, text, 240, steps=2, cfg_strength=2.0, sway_sampling_coef=-1.0, seed=0, use_acc_grl=False)
+                    out, _ = m.sample(cond, text, 240, steps=2, cfg_strength=2.0, sway_sampling_coef=None, seed=0, use_acc_grl=False)
                     wav = VocosEngine(vsd, device=a.device, arch=varch).decode(out[:, 120:].transpose(1, 2).float().contiguous())
                     ok = bool(torch.isfinite(out).all() and torch.isfinite(wav).all())
                     report("6 device: 2-step synthesis on the real weights", "PASS" if ok else "FAIL", f"mel {tuple(out.shape)}, wav {tuple(wav.shape)}, |wav| max {float(wav.abs().max()):.3f}")

@@ -37,11 +37,12 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--prompt-seconds", type=float, default=10.0)
     ap.add_argument("--cpu-baseline", action="store_true")
+    ap.add_argument("--bf16x3", type=int, default=0, help="engine option bf16x3: the 3x3 convolutions on split-bf16 operands")
     ap.add_argument("--small", action="store_true", help="dim_f 768, dim_t 64 (a quick run under a profiler)")
     args = ap.parse_args()
     arch = MdxArch(dim_f=768, dim_t=64) if args.small else KIM_VOCAL_1
     sd = synth.synth_mdx_state_dict(arch, 20)
-    eng = MdxEngine(arch, sd)
+    eng = MdxEngine(arch, sd, bf16x3=bool(args.bf16x3))
     x = torch.from_numpy(synth.synth_mdx_input(arch, args.batch, 21)).to("cuda:0")
     for _ in range(2):
         eng.forward(x)
@@ -59,13 +60,13 @@ def main():
     line = {"metric": "MDX-Net forward (UVR5 prompt denoiser)", "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"ConvTDFNet [{args.batch}, {arch.dim_c}, {arch.dim_f}, {arch.dim_t}] g{arch.g} l{arch.l} n{arch.n} bn{arch.bn} "
                                    f"({sum(v.size for v in sd.values()) / 1e6:.1f} M values)"},
-            "network": {"ms_per_forward": dt * 1e3, "wall_ms_per_forward": wall * 1e3, "batch": args.batch, "iters": args.iters},
+            "network": {"bf16x3": bool(args.bf16x3), "ms_per_forward": dt * 1e3, "wall_ms_per_forward": wall * 1e3, "batch": args.batch, "iters": args.iters},
             "roofline": {"bound": "mfma", "achieved": fl / dt / 1e12, "peak": F32_MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": fl / dt / F32_MFMA_PEAK,
                          "flops_per_forward": fl, "peak_note": "exact-fp32 MFMA (v_mfma_f32_16x16x4_f32), MI355X_MICROARCH.md"}}
     if not args.small and args.prompt_seconds > 0:
         from lemas_tts_amd.uvr5 import MDXConfig, UVR5
         cfg = MDXConfig(is_denoise=True, mdx_batch_size=1)
-        uv = UVR5((arch, sd), cfg, device="cuda:0")
+        uv = UVR5((arch, sd), cfg, device="cuda:0", bf16x3=bool(args.bf16x3))
         n = int(args.prompt_seconds * 24000)
         t = torch.arange(n, device="cuda:0") / 24000.0
         wav = (0.1 * torch.sin(2 * np.pi * 180.0 * t) + 0.01 * torch.randn(n, device="cuda:0"))[None]
