@@ -420,6 +420,8 @@ struct MdxConvParams {
 };
 hipError_t launch_mdx_conv(int kind, const MdxConvParams& p, hipStream_t s);
 int mdx_conv_ciw(int kind);
+void mdx_conv_set_bx_products(int n);   // bf16 MFMAs per product of the split-bf16 kernel: 3 or 4
+void mdx_conv_set_ck(int ck);      // input channels per K chunk of the exact 3x3 kernel: 4 (default) or 8
 hipError_t launch_mdx_first(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout, int F, int T, int relu,
                             hipStream_t s);
 hipError_t launch_mdx_final(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout, int F, int T, hipStream_t s);

@@ -523,6 +523,16 @@ int lemas_mdx_set_option(lemas_mdx* m, const char* key, int64_t value) {
     m->bf16x3 = value != 0;
     return 0;
   }
+  if (!std::strcmp(key, "bf16x3_products")) {      // 3 (default) or 4 bf16 MFMAs per product in the split-bf16 convolutions; process-wide
+    if (value != 3 && value != 4) { set_error("lemas_mdx_set_option: bf16x3_products is 3 or 4"); return LEMAS_E_ARG; }
+    mdx_conv_set_bx_products((int)value);
+    return 0;
+  }
+  if (!std::strcmp(key, "conv_chunk")) {      // channels per K chunk of the exact 3x3 kernel (8 or 4); process-wide, takes effect at the next forward
+    if (value != 4 && value != 8) { set_error("lemas_mdx_set_option: conv_chunk is 4 or 8"); return LEMAS_E_ARG; }
+    mdx_conv_set_ck((int)value);
+    return 0;
+  }
   set_error("lemas_mdx_set_option: unknown option '%s'", key);
   return LEMAS_E_ARG;
 }

@@ -6,8 +6,8 @@
 //     D[co][position] = sum over (tap, ci) of  W[co][ci][tap] . x[ci][position + tap]
 // with positions as the MFMA's 16 columns (16 consecutive f of one t: 64-B coalesced stores) and output channels as its 16 rows:
 //   * one workgroup = 4 waves = 4 consecutive t rows x TF = 16 MT consecutive f x 48 output channels (MT x 3 accumulator tiles per wave);
-//   * K runs over chunks of 8 input channels; per chunk the workgroup stages the INPUT HALO ((3 S + KH) rows x ((TF-1) S + KW) columns per
-//     channel) and the 8 x taps x 48 weight slab in LDS once, and all KH x KW taps read their operands from that one halo: activations cross
+//   * K runs over chunks of 4 input channels (8 selectable: launch_geom); per chunk the workgroup stages the INPUT HALO ((3 S + KH) rows x ((TF-1) S + KW) columns per
+//     channel) and the 4 x taps x 48 weight slab in LDS once, and all KH x KW taps read their operands from that one halo: activations cross
 //     L2 -> LDS once per chunk, not once per tap (a 3 x 3 im2col GEMM moves 9x the bytes; this kernel's L2 pull is ~4 B/clk/CU against the
 //     ~11 B/clk a CU gets);
 //   * operands are fetched with ds_read_b32 (32 banks, two 32-lane groups): the 16 lanes of a k-group read 16 consecutive words, the second
@@ -25,7 +25,7 @@ namespace {
 constexpr int NTW = 48;        // output columns per workgroup (3 MFMA tiles)
 constexpr int CK = 8;          // input channels per K chunk
 
-template <int KH, int S, int PAD, int MT>
+template <int KH, int S, int PAD, int MT, int CKT = CK>
 struct Geom {
   static constexpr int KW = KH, TAPS = KH * KW, TF = 16 * MT;
   static constexpr int ROWS = 3 * S + KH;                                  // 4 output rows
@@ -37,21 +37,23 @@ struct Geom {
   static constexpr int CIW0 = TAPS * NTW;
   static constexpr int CIW = CIW0 + ((16 - CIW0 % 32) + 32) % 32;
   static constexpr int Q = ROWP / 4;
-  static constexpr int A_F4 = CK * ROWS * Q, W_F4 = CK * CIW / 4;
+  static constexpr int A_F4 = CKT * ROWS * Q, W_F4 = CKT * CIW / 4;
+  static_assert(PLANE % 4 == 0 && ROWP % 4 == 0 && CIW % 4 == 0 && (CKT == 4 || CKT == 8), "16-B LDS stores");
   static constexpr int A_IT = (A_F4 + 255) / 256, W_IT = (W_F4 + 255) / 256;
 };
 
-template <int KH, int S, int PAD, int MT, bool UP, bool VEC>
-__global__ __launch_bounds__(256, 2) void mdx_conv_kernel(const MdxConvParams p) {
-  using G = Geom<KH, S, PAD, MT>;
-  __shared__ __attribute__((aligned(16))) float As[2][CK * G::PLANE];
-  __shared__ __attribute__((aligned(16))) float Ws[2][CK * G::CIW];
+template <int KH, int S, int PAD, int MT, bool UP, bool VEC, int CKT>
+__global__ __launch_bounds__(256, CKT == 4 ? 3 : 2) void mdx_conv_kernel(const MdxConvParams p) {
+  using G = Geom<KH, S, PAD, MT, CKT>;
+  const int nchunks = p.nchunks * (CK / CKT);            // the slab is [ntile][ci][CIW] linear: a chunk of 4 channels is half a chunk of 8
+  __shared__ __attribute__((aligned(16))) float As[2][CKT * G::PLANE];
+  __shared__ __attribute__((aligned(16))) float Ws[2][CKT * G::CIW];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, lk = lane >> 4;
   const int f0 = blockIdx.x * G::TF, t0 = blockIdx.y * 4;
   const int b = blockIdx.z / p.ntiles, nt = blockIdx.z % p.ntiles;
   const float* xb = p.x + (size_t)b * p.Cin * p.Ti * p.Fi;
-  const float* wt = p.w + (size_t)nt * p.nchunks * (CK * G::CIW);
+  const float* wt = p.w + (size_t)nt * p.nchunks * (CK * G::CIW);        // (p.nchunks counts chunks of CK = 8)
   const size_t plane = (size_t)p.Ti * p.Fi;
 
   // Loader slots: a thread owns A_IT float4 slots of the halo (channel ci, halo row r, 4 columns from 4 q) and W_IT float4 of the weight slab;
@@ -87,8 +89,8 @@ __global__ __launch_bounds__(256, 2) void mdx_conv_kernel(const MdxConvParams p)
   auto gload = [&](int chunk) {
 #pragma unroll
     for (int it = 0; it < G::A_IT; ++it) {
-      const bool cok = chunk * CK < a_lim[it];
-      const float* src = cok ? a_ptr[it] + (size_t)chunk * CK * plane : xb;
+      const bool cok = chunk * CKT < a_lim[it];
+      const float* src = cok ? a_ptr[it] + (size_t)chunk * CKT * plane : xb;
       if (VEC) {
         ra[it] = *reinterpret_cast<const f32x4*>(src);
       } else {
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void mdx_conv_kernel(const MdxConvParams p)
 #pragma unroll
     for (int it = 0; it < G::W_IT; ++it) {
       const int idx = tid + it * 256;
-      rw[it] = wsrc[(size_t)chunk * (CK * G::CIW / 4) + (idx < G::W_F4 ? idx : 0)];
+      rw[it] = wsrc[(size_t)chunk * (CKT * G::CIW / 4) + (idx < G::W_F4 ? idx : 0)];
     }
   };
   auto park = [&](int buf, int chunk) {
@@ -110,8 +112,9 @@ __global__ __launch_bounds__(256, 2) void mdx_conv_kernel(const MdxConvParams p)
     for (int it = 0; it < G::A_IT; ++it) {
       if (a_lds[it] < 0) continue;
       f32x4 v = ra[it];
-      if (VEC && !((a_ok >> (4 * it) & 1) && chunk * CK < a_lim[it])) v = zv;
-      *reinterpret_cast<f32x4*>(&As[buf][a_lds[it]]) = v;
+      if (VEC && !((a_ok >> (4 * it) & 1) && chunk * CKT < a_lim[it])) v = zv;
+      reinterpret_cast<f32x4*>(As[buf])[a_lds[it] >> 2] = v;       // (index in float4 units: the compiler cannot see that a_lds is a multiple of 4
+                                                                   //  and splits a store through &As[..][a_lds] into ds_write2_b32 pairs: 4-way bank conflicts)
     }
 #pragma unroll
     for (int it = 0; it < G::W_IT; ++it) {
@@ -132,16 +135,16 @@ __global__ __launch_bounds__(256, 2) void mdx_conv_kernel(const MdxConvParams p)
   gload(0);
   park(0, 0);
   __syncthreads();
-  for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
     const int cur = chunk & 1;
-    if (chunk + 1 < p.nchunks) gload(chunk + 1);
+    if (chunk + 1 < nchunks) gload(chunk + 1);
     const float* A = &As[cur][a_base];
     const float* W = &Ws[cur][w_base];
 #pragma unroll
     for (int tap = 0; tap < G::TAPS; ++tap) {
       const int dt = tap / G::KW, df = tap % G::KW;
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
+      for (int kk = 0; kk < CKT / 4; ++kk) {
         float av[MT], bv[3];
 #pragma unroll
         for (int i = 0; i < MT; ++i) av[i] = A[kk * 4 * G::PLANE + dt * G::ROWP + i * 16 * S + df];
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void mdx_conv_kernel(const MdxConvParams p)
           for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[j], av[i], acc[i][j], 0, 0, 0);
       }
     }
-    if (chunk + 1 < p.nchunks) park(cur ^ 1, chunk + 1);
+    if (chunk + 1 < nchunks) park(cur ^ 1, chunk + 1);
     __syncthreads();
   }
 
@@ -403,19 +406,23 @@ __global__ __launch_bounds__(256, 2) void mdx_conv3_bx_kernel(const MdxConvParam
     }
 }
 
-template <bool VEC>
+static int g_bx_nprod = 3;      // bf16 MFMAs per product of the split-bf16 kernel: 3 (W_lo A_lo dropped) or 4
+template <bool VEC, int NPROD>
 hipError_t launch_bx(const MdxConvParams& p, hipStream_t s) {
   auto wgs = [&](int mt) { return (long)((p.Fg + 16 * mt - 1) / (16 * mt)) * ((p.Tg + 3) / 4) * p.B * p.ntiles; };
   int mt = 4;
   while (mt > 1 && wgs(mt) < 512) mt >>= 1;
   const dim3 grid((p.Fg + 16 * mt - 1) / (16 * mt), (p.Tg + 3) / 4, p.B * p.ntiles);
   if (grid.y > 65535 || grid.z > 65535) return hipErrorInvalidValue;
-  if (mt == 4) hipLaunchKernelGGL((mdx_conv3_bx_kernel<4, VEC, 3>), grid, dim3(256), 0, s, p);
-  else if (mt == 2) hipLaunchKernelGGL((mdx_conv3_bx_kernel<2, VEC, 3>), grid, dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((mdx_conv3_bx_kernel<1, VEC, 3>), grid, dim3(256), 0, s, p);
+  if (mt == 4) hipLaunchKernelGGL((mdx_conv3_bx_kernel<4, VEC, NPROD>), grid, dim3(256), 0, s, p);
+  else if (mt == 2) hipLaunchKernelGGL((mdx_conv3_bx_kernel<2, VEC, NPROD>), grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((mdx_conv3_bx_kernel<1, VEC, NPROD>), grid, dim3(256), 0, s, p);
   return hipGetLastError();
 }
 
+// chunk of 4 channels: half the LDS (28 KB at MT = 4) -> three workgroups per CU instead of two, twice the barriers per flop.  Chosen per launch
+// by mdx_conv_ck() (the 3x3 convolution only; measured: DESIGN.md section 10)
+static int g_ck3 = 4;      // measured at the Kim_Vocal_1 shape: 13.58 vs 14.25 ms (batch 2), 7.66 vs 8.00 ms (batch 1): profiles/r06/r06i_mdx_modes.txt
 template <int KH, int S, int PAD, bool UP, bool VEC>
 hipError_t launch_geom(const MdxConvParams& p, hipStream_t s) {
   // wider position tiles while they still give the chip ~2 workgroups per CU; the narrow ones for the deep, small levels
@@ -425,12 +432,20 @@ hipError_t launch_geom(const MdxConvParams& p, hipStream_t s) {
   while (mt > 1 && wgs(mt) < 512) mt >>= 1;
   const dim3 grid((p.Fg + 16 * mt - 1) / (16 * mt), (p.Tg + 3) / 4, p.B * p.ntiles);
   if (grid.y > 65535 || grid.z > 65535) return hipErrorInvalidValue;
+  if (KH == 3 && g_ck3 == 4) {
+    if constexpr (KH == 3) {
+      if (mt == 4) hipLaunchKernelGGL((mdx_conv_kernel<KH, S, PAD, 4, UP, VEC, 4>), grid, dim3(256), 0, s, p);
+      else if (mt == 2) hipLaunchKernelGGL((mdx_conv_kernel<KH, S, PAD, 2, UP, VEC, 4>), grid, dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((mdx_conv_kernel<KH, S, PAD, 1, UP, VEC, 4>), grid, dim3(256), 0, s, p);
+    }
+    return hipGetLastError();
+  }
   if (mt == 4) {
-    if constexpr (MAXMT >= 4) hipLaunchKernelGGL((mdx_conv_kernel<KH, S, PAD, 4, UP, VEC>), grid, dim3(256), 0, s, p);
+    if constexpr (MAXMT >= 4) hipLaunchKernelGGL((mdx_conv_kernel<KH, S, PAD, 4, UP, VEC, 8>), grid, dim3(256), 0, s, p);
   } else if (mt == 2) {
-    hipLaunchKernelGGL((mdx_conv_kernel<KH, S, PAD, 2, UP, VEC>), grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((mdx_conv_kernel<KH, S, PAD, 2, UP, VEC, 8>), grid, dim3(256), 0, s, p);
   } else {
-    hipLaunchKernelGGL((mdx_conv_kernel<KH, S, PAD, 1, UP, VEC>), grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((mdx_conv_kernel<KH, S, PAD, 1, UP, VEC, 8>), grid, dim3(256), 0, s, p);
   }
   return hipGetLastError();
 }
@@ -580,7 +595,8 @@ hipError_t launch_mdx_conv(int kind, const MdxConvParams& p, hipStream_t s) {
   if (p.B <= 0 || p.Cin <= 0 || p.Cout <= 0 || p.Tg <= 0 || p.Fg <= 0 || p.nchunks <= 0 || p.ntiles <= 0) return hipErrorInvalidValue;
   if (kind == MDX_CONV3_BX) {
     const bool vec = (p.Fi & 3) == 0 && (reinterpret_cast<size_t>(p.x) & 15) == 0;
-    return vec ? launch_bx<true>(p, s) : launch_bx<false>(p, s);
+    if (g_bx_nprod == 4) return vec ? launch_bx<true, 4>(p, s) : launch_bx<false, 4>(p, s);
+    return vec ? launch_bx<true, 3>(p, s) : launch_bx<false, 3>(p, s);
   }
   switch (kind) {
     case MDX_CONV3: return launch_geom<3, 1, 1, false>(p, s);
@@ -589,6 +605,9 @@ hipError_t launch_mdx_conv(int kind, const MdxConvParams& p, hipStream_t s) {
   }
   return hipErrorInvalidValue;
 }
+
+void mdx_conv_set_ck(int ck) { g_ck3 = ck == 8 ? 8 : 4; }
+void mdx_conv_set_bx_products(int n) { g_bx_nprod = n == 4 ? 4 : 3; }
 
 // padded K-slab row length of the re-laid weights (floats per input channel): the engine builds [ntile][chunk][8][mdx_conv_ciw(kind)]
 int mdx_conv_ciw(int kind) {

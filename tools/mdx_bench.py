@@ -38,11 +38,19 @@ def main():
     ap.add_argument("--prompt-seconds", type=float, default=10.0)
     ap.add_argument("--cpu-baseline", action="store_true")
     ap.add_argument("--bf16x3", type=int, default=0, help="engine option bf16x3: the 3x3 convolutions on split-bf16 operands")
+    ap.add_argument("--products", type=int, default=0, help="engine option bf16x3_products (3 or 4 bf16 MFMAs per product)")
+    ap.add_argument("--conv-chunk", type=int, default=0, help="engine option conv_chunk (4 or 8 channels per K chunk of the exact 3x3 kernel)")
     ap.add_argument("--small", action="store_true", help="dim_f 768, dim_t 64 (a quick run under a profiler)")
     args = ap.parse_args()
     arch = MdxArch(dim_f=768, dim_t=64) if args.small else KIM_VOCAL_1
     sd = synth.synth_mdx_state_dict(arch, 20)
     eng = MdxEngine(arch, sd, bf16x3=bool(args.bf16x3))
+    if args.products:
+        from lemas_tts_amd import _lib
+        _lib.check(_lib.lib().lemas_mdx_set_option(eng._h, b"bf16x3_products", args.products), "bf16x3_products")
+    if args.conv_chunk:
+        from lemas_tts_amd import _lib
+        _lib.check(_lib.lib().lemas_mdx_set_option(eng._h, b"conv_chunk", args.conv_chunk), "conv_chunk")
     x = torch.from_numpy(synth.synth_mdx_input(arch, args.batch, 21)).to("cuda:0")
     for _ in range(2):
         eng.forward(x)
