@@ -478,6 +478,9 @@ def main():
     ap.add_argument("--dual", type=int, default=1, help="1 = CFG branches as two concurrent lanes (default), 0 = one stream")
     ap.add_argument("--overlap", type=int, default=1, help="1 = Vocos decode + D2H of utterance i on a side stream under the step loop of "
                     "utterance i+1 (default), 0 = strictly serial")
+    ap.add_argument("--attn-f8qk", type=int, default=-1, help="engine option attn_f8qk (-1 = engine default 1: on the fp8 path attention's QK^T runs on the "
+                    "fp8 MFMA from MXFP8 q / k written by the QK epilogue; 0 = bf16 q / k; 2 = side-launch quantiser; +4 forces it on the bf16 path: a "
+                    "measurement, not a BASELINE bf16 configuration)")
     ap.add_argument("--ln-fused", type=int, default=-1, help="engine option ln_fused (-1 = engine default)")
     ap.add_argument("--ln-fold", type=int, default=-1, help="engine option ln_fold (-1 = engine default)")
     ap.add_argument("--outlier-weights", type=int, default=0, help="1 = synthetic weights WITH outlier residual channels (1 %% of the channels x30 in every block's "
@@ -570,6 +573,8 @@ def main():
         model.engine.set_option("xcd_runs", a.xcd_runs)
     model.engine.set_option("dual", a.dual)
     model.engine.set_option("fp8", a.fp8)
+    if a.attn_f8qk >= 0:
+        model.engine.set_option("attn_f8qk", a.attn_f8qk)
     if a.ln_fused >= 0:
         model.engine.set_option("ln_fused", a.ln_fused)
     if a.ln_fold >= 0:

@@ -26,6 +26,15 @@
 // structure minimises VALU instructions per key: the pair loop is unrolled by the ring depth (every LDS address is base
 // register + immediate), the exponent argument and the row sum use packed fp32 math (v_pk_fma_f32 / v_pk_add_f32),
 // v_exp_f32 is issued directly, and l / O are only rescaled when some query's running max grew by more than 2^8.
+//
+// fp8 path (variant bit ATTN_F8QK = 8192, round 6; with bits 1 and 16): q and k arrive as MXFP8 ([B2, H, pitch, 64] e4m3 + one E8M0 scale per
+// 32-wide half of a head, written by the QK GEMM epilogue, GemmParams::q8) and S^T of a 64-key tile is TWO v_mfma_scale_f32_32x32x64_f8f6f4 (64
+// matrix-pipe clocks each) instead of eight v_mfma_f32_32x32x16_bf16 (32 each).  A K tile is then 4 KiB (rows of 64 B, the 16-B chunk index
+// XOR-swizzled by (row >> 2) & 3 in the DMA's SOURCE address: conflict-free ds_read_b128), the pair's 128 key scales (256 B) ride along as one
+// dword LDS-DMA of wave 0 into the unused half of K0's slot, and the operand layout is the fp8 GEMM body's (gemm_bf16.hip; probed on hardware,
+// tools/exp/mx_probe.hip): lane (i = l & 31, h = l >> 5) holds row i, registers 0-3 = K 16h .. 16h+15, registers 4-7 = K 32+16h ..; the scale
+// of K-block beta comes from lane i + 32 beta.  P . V, the softmax, the merge, the fallback sweeps and the output forms are unchanged.
+// Measured (profiles/r06/r06j_*): 22.0 -> 18.1 us at N = 1875, 47.0 -> 36.9 us at N = 2814 (BH 16).
 #include <type_traits>
 
 #include "common.h"
@@ -74,12 +83,55 @@ __device__ __forceinline__ void wait_lgkm_frags(u32x4& a, u32x4& b) {
   asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
 }
 
+template <int OFF>
+__device__ __forceinline__ void lds_read_u8(int& d, unsigned addr) {
+  asm volatile("ds_read_u8 %0, %1 offset:%2" : "=&v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_lgkm_frags8(u32x4& a, u32x4& b, int& c) {
+  asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N) : "memory");
+}
+
+// q, k rows (bf16, [rows, 64]) -> MXFP8, one thread per (row, 32-wide block); blockIdx.y: 0 = q, 1 = k.  The arithmetic of the QK GEMM epilogue's
+// q8 / k8 output on rows that already exist in bf16 (test library, kbench).
+__global__ __launch_bounds__(256) void qk_mx8_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, uint8_t* __restrict__ q8,
+                                                     uint8_t* __restrict__ k8, uint8_t* __restrict__ qs, uint8_t* __restrict__ ks, size_t rows) {
+  const bf16_t* src = blockIdx.y ? k : q;
+  uint8_t* dst = blockIdx.y ? k8 : q8;
+  uint8_t* sc = blockIdx.y ? ks : qs;
+  const size_t nb = rows * 2;
+  for (size_t b = (size_t)blockIdx.x * 256 + threadIdx.x; b < nb; b += (size_t)gridDim.x * 256) {
+    const bf16x8* s = reinterpret_cast<const bf16x8*>(src + b * 32);
+    bf16x8 v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = s[c];
+    float amax = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf((float)v[c][e]));
+    const int ex = mx_exponent(amax);
+    const float inv = mx_inv_scale(ex);
+    u32x4 o[2];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      o[c >> 1][(c & 1) * 2 + 0] = pack_fp8x4((float)v[c][0] * inv, (float)v[c][1] * inv, (float)v[c][2] * inv, (float)v[c][3] * inv);
+      o[c >> 1][(c & 1) * 2 + 1] = pack_fp8x4((float)v[c][4] * inv, (float)v[c][5] * inv, (float)v[c][6] * inv, (float)v[c][7] * inv);
+    }
+    u32x4* d = reinterpret_cast<u32x4*>(dst + b * 32);
+    d[0] = o[0];
+    d[1] = o[1];
+    sc[b] = (uint8_t)(ex + 127);
+  }
+}
+
 // Split-KV: a workgroup owns 128 queries of one (batch, head) and runs 8 waves: waves 0-3 take the even key tiles, waves
 // 4-7 the odd ones (same queries), and the two partial results (m, l, O^T) are merged through LDS at the end.  Four waves
 // per SIMD (<= 128 VGPRs each) hide the long per-tile dependency chain (LDS read -> MFMA -> row max -> exchange -> exp ->
 // MFMA); a 4-wave one-group kernel measured slower at every size (B=1: 53 vs 47 us; BH=256: 154 vs 136 us) and was removed.
 // Ring: 2 stages of [K0 | V0^T | K1 | V1^T] (32 KiB each), one barrier per tile pair.
 constexpr int STAGE2 = 4 * TILE;
+constexpr int F8_SC_OFF = 4096;      // fp8 path: the pair's 256 B of key scales sit in the unused half of K0's 8-KiB slot
 
 // VAR (bit mask), variants kept selectable for A/B measurements (AttnParams::variant; 0 = the original schedule):
 //   1  max-free softmax: a wave's FIRST tile goes the classical way and fixes the running max m of each query; every later tile is
@@ -105,6 +157,7 @@ constexpr int STAGE2 = 4 * TILE;
 //      exponentials / bf16 packing of step e+1: the VALU work of the next step issues while the matrix pipe runs this one.
 //  32 / 64 / 128 / 256 / 512  ABLATIONS for measurement only (wrong results): no v_exp (one FMA instead) / no P.V MFMAs / no K,V DMA after
 //      the first pair / no s_barrier in the pair hand-off / no vmcnt wait either.  What each removes is that resource's share of the loop.
+// 8192 (ATTN_F8QK; with 1 and 16) q, k as MXFP8, S^T on the fp8 matrix path (see the top of the file)
 //   2  static priority for the younger half of the workgroup (waves 4-7), no per-cluster flips
 //   4  s_setprio 1 around the MFMA clusters
 template <int VAR>
@@ -129,7 +182,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   if (p.live_len && qblk * QB >= p.live_len[b2 % p.batch]) return;      // ragged batch: this block's queries are all padding nobody reads
   const int ntiles = (kvlen + KB - 1) / KB, nsup = (ntiles + 1) >> 1;
   const float c = (VAR & 16) != 0 ? 1.0f : p.scale * 1.4426950408889634f;    // VAR & 16: q arrives prescaled
-  const char* kg = reinterpret_cast<const char*>(p.k + (size_t)bh * p.pitch * 64);
+  constexpr bool F8 = (VAR & ATTN_F8QK) != 0;
+  static_assert(!F8 || ((VAR & 17) == 17 && (VAR & (8 | 1024)) == 0), "the fp8 QK^T path is built on the no-running-max softmax (bits 1 and 16)");
+  const char* kg = F8 ? reinterpret_cast<const char*>(p.k8 + (size_t)bh * p.pitch * 64) : reinterpret_cast<const char*>(p.k + (size_t)bh * p.pitch * 64);
+  const char* ksg = F8 ? reinterpret_cast<const char*>(p.k8_mx + (size_t)bh * p.pitch * 2) : nullptr;
   const char* vg = reinterpret_cast<const char*>(p.vt + (size_t)bh * 64 * p.npad);
   const int q_base = qblk * QB + wq * 32;
 
@@ -140,9 +196,30 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int cc = (lp ^ ((r >> 1) & 7)) << 3;
     koff = (unsigned)((r * 64 + cc) * 2);
     voff = (unsigned)((r * p.npad + cc) * 2);
+    if constexpr (F8) {      // 4-KiB K tile: ONE 1-KiB piece (16 rows of 64 B) per wave -- waves 0-3 of K0, waves 4-7 of K1
+      const int kr = 16 * (wave & 3) + (lane >> 2);
+      koff = (unsigned)(kr * 64 + (((lane & 3) ^ ((kr >> 2) & 3)) << 4));
+    }
   }
   auto issue = [&](int stage, int i) __attribute__((always_inline)) {
     char* base = smem + stage * STAGE2 + wave * 1024;
+    if constexpr (F8) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        int j = 2 * i + g;
+        j = j < ntiles ? j : ntiles - 1;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vg + (size_t)j * (KB * 2) + voff),
+                                         (__attribute__((address_space(3))) void*)(base + g * 2 * TILE + TILE), 16, 0, 0);
+      }
+      int j = 2 * i + grp;
+      j = j < ntiles ? j : ntiles - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kg + (size_t)j * (KB * 64) + koff),
+                                       (__attribute__((address_space(3))) void*)(smem + stage * STAGE2 + grp * 2 * TILE + (wave & 3) * 1024), 16, 0, 0);
+      if (wave == 0)     // scales of keys 128 i .. 128 i + 127 (the row pitch is a multiple of 128: always inside the sample's rows)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ksg + (size_t)i * 256 + lane * 4),
+                                         (__attribute__((address_space(3))) void*)(smem + stage * STAGE2 + F8_SC_OFF), 4, 0, 0);
+      return;
+    }
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
       int j = 2 * i + g;
@@ -157,18 +234,31 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int krow = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
   const int ksw = (krow >> 1) & 7, vsw = (l31 >> 1) & 7;
   const unsigned kx0 = krow * 128 + ((hi ^ ksw) << 4);   // k-step kk: kx0 ^ (kk << 5)
+  // fp8 path: K fragment of 32-key block t = LDS row 32 t + krow (64-B rows), 16-B chunks h and 2 + h, physical slot = chunk ^ ((row >> 2) & 3);
+  // scale byte of (key row, K-block h) at F8_SC_OFF + (64 grp + 32 t + krow) * 2 + h
+  const unsigned kx8 = krow * 64 + ((hi ^ ((krow >> 2) & 3)) << 4);
+  const unsigned sx8 = F8_SC_OFF + (grp * 64 + krow) * 2 + hi;
   // V^T fragment of 16-key step e: row l31, 16-B chunk (2 e + hi) ^ vsw.  2 e and hi occupy disjoint bits, so the chunk is
   // (hi ^ vsw) ^ 2 e and the byte offset vx0 ^ (e << 5): ONE register serves the four steps (the K side's trick)
   const int vx0 = l31 * 128 + ((hi ^ vsw) << 4);
   auto vx = [&](int e) __attribute__((always_inline)) { return vx0 ^ (e << 5); };
 
-  bf16x8 qf[4];
+  bf16x8 qf[F8 ? 1 : 4];
+  i32x8 qf8;
+  int qsc = 0;
   {
-    const bf16_t* Qg = p.q + (size_t)bh * p.pitch * 64;
     int qrow = q_base + l31;
     qrow = qrow < N ? qrow : N - 1;
+    if constexpr (F8) {
+      const uint8_t* Qg = p.q8 + ((size_t)bh * p.pitch + qrow) * 64;
+      const u32x4 a = *reinterpret_cast<const u32x4*>(Qg + 16 * hi), b = *reinterpret_cast<const u32x4*>(Qg + 32 + 16 * hi);
+      qf8[0] = a[0]; qf8[1] = a[1]; qf8[2] = a[2]; qf8[3] = a[3]; qf8[4] = b[0]; qf8[5] = b[1]; qf8[6] = b[2]; qf8[7] = b[3];
+      qsc = p.q8_mx[((size_t)bh * p.pitch + qrow) * 2 + hi];
+    } else {
+      const bf16_t* Qg = p.q + (size_t)bh * p.pitch * 64;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(Qg + (size_t)qrow * 64 + kk * 16 + hi * 8);
+      for (int kk = 0; kk < 4; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(Qg + (size_t)qrow * 64 + kk * 16 + hi * 8);
+    }
   }
   f32x16 o[2];
 #pragma unroll
@@ -201,7 +291,39 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     if (j >= ntiles) return true;
     const unsigned ka = lds_base + SG * STAGE2 + grp * 2 * TILE + kx0;
     f32x16 s[2];
-    {
+    if constexpr (F8) {
+      // S^T = K . Q^T of this tile on the fp8 matrix path: per 32-key block one scale byte + two ds_read_b128, one MFMA
+      const unsigned kb8 = lds_base + SG * STAGE2 + grp * 2 * TILE, sb8 = lds_base + SG * STAGE2 + sx8;
+      u32x4 f[2][2];
+      int sc[2];
+      const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      lds_read_u8<0>(sc[0], sb8);
+      lds_read_b128<0>(f[0][0], kb8 + kx8);
+      lds_read_b128<0>(f[0][1], kb8 + (kx8 ^ 32u));      // chunk 2 + h: bit 1 of the slot
+      lds_read_u8<64>(sc[1], sb8);
+      lds_read_b128<2048>(f[1][0], kb8 + kx8);
+      lds_read_b128<2048>(f[1][1], kb8 + (kx8 ^ 32u));
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        if (t == 0) wait_lgkm_frags8<3>(f[0][0], f[0][1], sc[0]);
+        else wait_lgkm_frags8<0>(f[1][0], f[1][1], sc[1]);
+        i32x8 kf;
+        kf[0] = f[t][0][0]; kf[1] = f[t][0][1]; kf[2] = f[t][0][2]; kf[3] = f[t][0][3];
+        kf[4] = f[t][1][0]; kf[5] = f[t][1][1]; kf[6] = f[t][1][2]; kf[7] = f[t][1][3];
+        s[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kf, qf8, zero, 0, 0, 0, sc[t], 0, qsc);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (__builtin_expect((j + 1) * KB > kvlen, 0)) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = j * KB + 32 * t + 16 * (r >> 3) + 8 * hi + (r & 7);
+            if (key >= kvlen) s[t][r] = -INFINITY;      // (also replaces what stale bytes of a masked key row produced, NaN included)
+          }
+      }
+    } else {
       // S^T = K . Q^T of this tile.  K fragment schedule (2 x ds_read_b128 per k-step, double-buffered in fk[2][2]): the reads of step
       // kk+1 are in flight under the MFMAs of step kk.  Left to the compiler every step was read -> s_waitcnt lgkmcnt(0) -> MFMA.
       u32x4 fk[2][2];
@@ -537,6 +659,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 }  // namespace
 
 bool attention_variant_ok(int v) {
+  if ((v & ATTN_F8QK) != 0) return false;    // the fp8 QK^T bit is the engine's to set (option "attn_f8qk": it also needs the QK epilogue's MXFP8 output)
   if ((v & ATTN_Q64) != 0) return false;     // the 64-queries-per-wave kernel lives in the test library (lemas_k_attention), not in an engine
   switch (v) {
     case 0: case 1: case 2: case 3: case 4: case 5: case 7: case 17: case 19: case 17 + 1024: case 19 + 1024: return true;
@@ -544,10 +667,19 @@ bool attention_variant_ok(int v) {
   }
 }
 
+hipError_t launch_qk_mx8(const bf16_t* q, const bf16_t* k, uint8_t* q8, uint8_t* k8, uint8_t* q8_mx, uint8_t* k8_mx, size_t rows, hipStream_t s) {
+  const size_t nb = rows * 2;
+  const unsigned gx = (unsigned)((nb + 255) / 256 < 4096 ? (nb + 255) / 256 : 4096);
+  hipLaunchKernelGGL(qk_mx8_kernel, dim3(gx, 2), dim3(256), 0, s, q, k, q8, k8, q8_mx, k8_mx, rows);
+  return hipGetLastError();
+}
+
 hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
   // K rows are loaded up to the next multiple of 64 without clamping: the row pitch must cover them
   if (p.npad % 64 != 0 || p.n <= 0 || p.pitch < ((p.n + 63) & ~63) || p.npad < ((p.n + 63) & ~63)) return hipErrorInvalidValue;
   if (p.out8 && !p.out_mx) return hipErrorInvalidValue;
+  // fp8 QK^T: K rows and key scales are loaded in whole 128-key pairs without clamping, so the row pitch is a multiple of 128
+  if ((p.variant & ATTN_F8QK) != 0 && (!p.q8 || !p.k8 || !p.q8_mx || !p.k8_mx || p.pitch % 128 != 0)) return hipErrorInvalidValue;
   dim3 grid(((p.n + QB - 1) / QB) * p.b2 * p.heads);
 #define LEMAS_ATTN_LAUNCH(V)                                                                                                   \
   case V:                                                                                                                      \
@@ -558,6 +690,7 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
   switch (p.variant) {
     LEMAS_ATTN_LAUNCH(0) LEMAS_ATTN_LAUNCH(1) LEMAS_ATTN_LAUNCH(2) LEMAS_ATTN_LAUNCH(3) LEMAS_ATTN_LAUNCH(4) LEMAS_ATTN_LAUNCH(5)
     LEMAS_ATTN_LAUNCH(7) LEMAS_ATTN_LAUNCH(17) LEMAS_ATTN_LAUNCH(19) LEMAS_ATTN_LAUNCH(17 + 1024) LEMAS_ATTN_LAUNCH(19 + 1024)
+    LEMAS_ATTN_LAUNCH(17 + ATTN_F8QK) LEMAS_ATTN_LAUNCH(19 + ATTN_F8QK)
 #ifdef LEMAS_PHASE_TIMESTAMPS      // measurement builds only: ablations (wrong results by construction) and the forms without a fallback pass
     LEMAS_ATTN_LAUNCH(8) LEMAS_ATTN_LAUNCH(10)
     LEMAS_ATTN_LAUNCH(17 + 32) LEMAS_ATTN_LAUNCH(17 + 64) LEMAS_ATTN_LAUNCH(17 + 128) LEMAS_ATTN_LAUNCH(17 + 256) LEMAS_ATTN_LAUNCH(17 + 256 + 512)

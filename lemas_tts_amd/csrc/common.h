@@ -196,6 +196,12 @@ struct GemmParams {
   int heads, npad;
   float q_scale;          // EPI_QK_ROPE: the q half is multiplied by this in fp32 before the bf16 rounding (0 = 1.0): the attention
                           // kernel's "prescaled q" variants take softmax_scale * log2(e) here (attention.hip VAR & 16)
+  // EPI_QK_ROPE of the fp8 bodies (f8 != 0), optional: when q8 is set, q and k leave as MXFP8 instead of bf16 -- the rotated (and prescaled) values are rounded to bf16
+  // exactly as before and THEN quantised, one E8M0 scale per 32-wide half of a head (attention.hip VAR & ATTN_F8QK consumes them)
+  uint8_t* q8;            // [B2, H, seq_pitch, 64] e4m3 (nullptr: bf16 q / k as above)
+  uint8_t* k8;
+  uint8_t* q8_mx;         // [B2, H, seq_pitch, 2] E8M0
+  uint8_t* k8_mx;
   // fp8 path (f8 != 0): A and W point at e4m3 bytes (same [rows][K] layouts, K % 128 == 0); activations carry MX block
   // scales, weights one fp32 scale per output channel (applied in the epilogue)
   int f8;
@@ -279,6 +285,11 @@ struct AttnParams {
   const bf16_t* q;   // [B2, H, pitch, 64]
   const bf16_t* k;   // [B2, H, pitch, 64]
   const bf16_t* vt;  // [B2, H, 64, npad]
+  // variants with bit ATTN_F8QK: q and k as MXFP8 (q, k above unused) -- S^T = K . Q^T on v_mfma_scale_f32_32x32x64_f8f6f4
+  const uint8_t* q8;     // [B2, H, pitch, 64] e4m3 (q prescaled by softmax_scale * log2(e) before the quantisation: bit 16 is required)
+  const uint8_t* k8;
+  const uint8_t* q8_mx;  // [B2, H, pitch, 2] E8M0: one scale per 32-wide half of a head
+  const uint8_t* k8_mx;
   bf16_t* out;       // [B2*pitch, H*64]
   const int* kv_len; // [B] or nullptr
   const int* live_len;  // [B] or nullptr: 128-query blocks that start at or past live_len of their sample are not computed (GemmParams::live_len)
@@ -297,6 +308,10 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t s);
 // AttnParams::variant with this bit (and bit 16: q prescaled): the 64-queries-per-wave kernel of attention_q64.hip; bits 0-1 pick its
 // schedule (1 = blocks skewed, 2 = static priority for the younger half-workgroup)
 constexpr int ATTN_Q64 = 4096;
+// AttnParams::variant with this bit (and bit 16): QK^T on the fp8 matrix path from MXFP8 q / k (AttnParams::q8 ...), P . V unchanged (attention.hip)
+constexpr int ATTN_F8QK = 8192;
+// q, k bf16 [rows, 64] -> MXFP8 (the arithmetic of the QK GEMM epilogue's q8 / k8 output; test library and kbench use it to feed the kernel alone)
+hipError_t launch_qk_mx8(const bf16_t* q, const bf16_t* k, uint8_t* q8, uint8_t* k8, uint8_t* q8_mx, uint8_t* k8_mx, size_t rows, hipStream_t s);
 hipError_t launch_attention_q64(const AttnParams& p, hipStream_t s);
 hipError_t attention_q64_init();
 // the variants a product engine may select (lemas_dit_set_option "attn_variant"); the measurement-only instantiations of attention.hip

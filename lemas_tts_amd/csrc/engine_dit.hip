@@ -18,6 +18,7 @@
 
 #include "engine_common.h"
 
+
 namespace lemas {
 
 enum ProfClass { PC_INPROJ, PC_CONVPOS, PC_LN, PC_GEMM_QKV, PC_GEMM_QK, PC_GEMM_V, PC_ATTN, PC_GEMM_OUT, PC_GEMM_FF1, PC_GEMM_FF2, PC_GEMM_FINAL,
@@ -106,6 +107,14 @@ struct lemas_dit {
   // measurement option: lane 1 launches stage k of a block only after lane 0's stage k has completed (the lanes run one stage apart
   // instead of in lock-step, so unlike kernels share the chip)
   int lane_skew = 0;
+  // fp8 QK^T in attention (attention.hip VAR & ATTN_F8QK): bits 0-1 = 0 off | 1 the QK GEMM epilogue writes q, k as MXFP8 | 2 a side launch
+  // quantises the bf16 rows (same bits, one more launch: the A/B form); bit 2 = also while the block GEMMs run on bf16 operands (measurements:
+  // BASELINE's bf16 configurations must not use it).  Takes effect with a prescaled-q attention variant (17 / 19) only.
+  int attn_f8qk = 1;
+  int f8qk_mode() const {
+    if ((attn_f8qk & 3) == 0 || (attn_variant & 17) != 17 || (attn_variant & ~19) != 0) return 0;
+    return ((attn_f8qk & 4) != 0 || fp8_sites() != 0) ? (attn_f8qk & 3) : 0;
+  }
   hipEvent_t ev_skew[8] = {};
   // measurement option (measurement builds only): the FF half of every block -- out-projection, ff_norm, FF1, FF2 -- as ONE persistent launch per
   // lane with grid barriers between the stages (gemm_bf16.hip gemm_chain_ffhalf_kernel); 2 = with the next stage's weights prefetched across the barrier
@@ -161,6 +170,7 @@ struct lemas_dit {
   DevBuf d_cond_eff, d_step_cond, d_pm, d_pt;             // conditioning
   DevBuf d_te, d_rowmask, d_t1, d_t2, d_t3, d_gx, d_ct;   // text embedding scratch
   DevBuf d_pconst, d_y, d_xres, d_hbf, d_q, d_k, d_vt, d_abf, d_ff, d_cmid, d_pred;
+  DevBuf d_q8, d_k8, d_qs8, d_ks8;      // option attn_f8qk: the MXFP8 images of q and k ([B2, H, pitch, 64] e4m3, [B2, H, pitch, 2] E8M0)
   DevBuf d_h8, d_hmx, d_a8, d_amx, d_ff8, d_ffmx;         // MXFP8 activations of the fp8 path (bytes + E8M0 scales)
   DevBuf d_lncnt;                                         // arrival counters of the fused LayerNorm tails: [block][site][lane][panel]
   DevBuf d_lnpart;                                        // ln fold: [rows][32][2] (sum, sum of squares) per 32-column slot
@@ -192,7 +202,7 @@ struct lemas_dit {
   std::vector<DevBuf*> own_bufs() {
     return {&wproj_out, &bproj_out, &d_tabW, &d_tabB, &wconv[0], &wconv[1], &d_step, &d_dt, &d_cfg, &d_t, &d_tab, &d_rope_cos,
             &d_rope_sin, &d_len, &d_live, &d_sin, &d_h1, &d_temb, &d_st, &d_cond_eff, &d_step_cond, &d_pm, &d_pt, &d_te,
-            &d_rowmask, &d_t1, &d_t2, &d_t3, &d_gx, &d_ct, &d_pconst, &d_y, &d_xres, &d_hbf, &d_q, &d_k, &d_vt,
+            &d_rowmask, &d_t1, &d_t2, &d_t3, &d_gx, &d_ct, &d_pconst, &d_y, &d_xres, &d_hbf, &d_q, &d_k, &d_vt, &d_q8, &d_k8, &d_qs8, &d_ks8,
             &d_abf, &d_ff, &d_cmid, &d_pred, &d_h8, &d_hmx, &d_a8, &d_amx, &d_ff8, &d_ffmx, &d_lncnt, &d_lnpart,
             &d_foldA, &d_foldtmp, &d_foldsites, &d_foldparams, &d_zero, &d_flagged};
   }
@@ -780,6 +790,10 @@ int lemas_dit::prepare(const lemas_sample_args* a, hipStream_t s) {
   RC_TRY(d_q.ensure((size_t)rows * in * 2));
   RC_TRY(d_k.ensure((size_t)rows * in * 2));
   RC_TRY(d_vt.ensure((size_t)BB * cfg.heads * 64 * npad * 2));
+  if (f8qk_mode() != 0) {
+    RC_TRY(d_q8.ensure((size_t)rows * in)); RC_TRY(d_k8.ensure((size_t)rows * in));
+    RC_TRY(d_qs8.ensure((size_t)rows * (in / 32))); RC_TRY(d_ks8.ensure((size_t)rows * (in / 32)));
+  }
   RC_TRY(d_ff.ensure((size_t)rows * cfg.ff_mult * d * 2));
   RC_TRY(d_cmid.ensure((size_t)rows * d * 2));
   RC_TRY(d_pred.ensure((size_t)rows * md * 4));
@@ -952,6 +966,17 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     // which of the block's GEMMs take fp8 operands (fp8_sites(): every site the option mask names, or none once the outlier guard has tripped)
     const int sites = fp8_sites();
     const bool f8_qkv = sites & 1, f8_out = sites & 2, f8_ff1 = sites & 4, f8_ff2 = sites & 8;
+    // attention's QK^T on the fp8 matrix path: q and k leave the QK epilogue as MXFP8 (mode 1) or are quantised by a side launch (mode 2)
+    const int f8qk = f8qk_mode() == 1 && !f8_qkv ? 2 : f8qk_mode();      // (only the fp8 QK GEMM bodies carry the MXFP8 epilogue)
+    if (f8qk != 0) {
+      at.q8 = d_q8.as<uint8_t>() + r0 * in; at.k8 = d_k8.as<uint8_t>() + r0 * in;
+      at.q8_mx = d_qs8.as<uint8_t>() + r0 * (in / 32); at.k8_mx = d_ks8.as<uint8_t>() + r0 * (in / 32);
+      at.variant = attn_variant | ATTN_F8QK;
+      if (f8qk == 1) {
+        g.q8 = const_cast<uint8_t*>(at.q8); g.k8 = const_cast<uint8_t*>(at.k8);
+        g.q8_mx = const_cast<uint8_t*>(at.q8_mx); g.k8_mx = const_cast<uint8_t*>(at.k8_mx);
+      }
+    }
     g.concurrency = lanes;
     g.xcd_gx = opt_xcd_gx;
     g.xcd_runs = opt_xcd_runs;
@@ -1040,6 +1065,8 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     };
     TL_SLOT(at);
     RC_TRY(skew_pre(ln, q));
+    if (f8qk == 2) HIP_TRY(launch_qk_mx8(g.q, g.k, const_cast<uint8_t*>(at.q8), const_cast<uint8_t*>(at.k8), const_cast<uint8_t*>(at.q8_mx),
+                                         const_cast<uint8_t*>(at.k8_mx), (size_t)rows * in / 64, q));
     HIP_TRY(launch_attention(at, q));
     RC_TRY(skew_post(ln, q));
     RC_TRY(pkernel(PC_GEMM_OUT, &g.ev_start, &g.ev_stop));
@@ -1338,6 +1365,12 @@ int lemas_dit_set_option(lemas_dit* m, const char* key, int64_t value) {
   if (!strcmp(key, "lane_split")) {
     if (value != 0 && value != 1 && value != 2 && value != 4) { set_error("lemas_dit_set_option: lane_split is 0 (automatic), 1, 2 or 4 sample groups per CFG branch"); return LEMAS_E_ARG; }
     m->lane_split = (int)value;
+    m->drop_graphs();
+    return 0;
+  }
+  if (!strcmp(key, "attn_f8qk")) {
+    if (value < 0 || value > 6 || (value & 3) == 3) { set_error("lemas_dit_set_option: attn_f8qk is 0 (off), 1 (QK epilogue writes MXFP8), 2 (side launch), + 4 = on the bf16 path too"); return LEMAS_E_ARG; }
+    m->attn_f8qk = (int)value;
     m->drop_graphs();
     return 0;
   }

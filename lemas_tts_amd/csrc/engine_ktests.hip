@@ -476,6 +476,18 @@ int lemas_k_attention_variant(const float* q, const float* k, const float* v, co
   AttnParams p{};
   p.q = qb; p.k = kb; p.vt = vt; p.out = ob; p.kv_len = seq_len; p.b2 = B; p.batch = B; p.heads = H; p.n = N; p.npad = npad; p.pitch = pitch;
   p.scale = 0.125f; p.variant = variant;
+  if (variant & ATTN_F8QK) {      // q, k quantised to MXFP8 by their own launch (in the engine: by the QK GEMM epilogue), then QK^T on the fp8 MFMA
+    if ((variant & 17) != 17 || (variant & ~(ATTN_F8QK | 19)) != 0) { set_error("lemas_k_attention: the fp8 QK^T path is variant 8192 + 17 / 19"); return LEMAS_E_ARG; }
+    const size_t rows = (size_t)B * H * pitch;
+    uint8_t* q8 = sc.get<uint8_t>(rows * 64);
+    uint8_t* k8 = sc.get<uint8_t>(rows * 64);
+    uint8_t* qs = sc.get<uint8_t>(rows * 2);
+    uint8_t* ks = sc.get<uint8_t>(rows * 2);
+    if (!q8 || !k8 || !qs || !ks) { set_error("lemas_k_attention: out of memory"); return LEMAS_E_STATE; }
+    HIP_TRY(launch_qk_mx8(qb, kb, q8, k8, qs, ks, rows, s));
+    p.q8 = q8; p.k8 = k8; p.q8_mx = qs; p.k8_mx = ks;
+    HIP_TRY(launch_attention(p, s));
+  } else
   HIP_TRY(launch_attention_any(p, s));
   hipLaunchKernelGGL(unpad_widen_kernel, dim3(2048), dim3(256), 0, s, ob, out, B, N, pitch, H * 64);
   HIP_TRY(hipStreamSynchronize(s));
@@ -633,8 +645,10 @@ extern "C" int lemas_k_bench(const char* what, int32_t M, int32_t N, int32_t K, 
               cnt[1], st[1] / std::max(cnt[1], 1), sp[1] / std::max(cnt[1], 1), sl[1] / std::max(cnt[1], 1), se[1] / std::max(cnt[1], 1));
     }
 #endif
-  } else if (w == "attention") {
+  } else if (w == "attention" || w == "attention_qkquant") {
     // M = sequence length, N = batch*heads
+    const bool quant_only = w == "attention_qkquant";
+    if (quant_only && !(variant & ATTN_F8QK)) { set_error("bench: attention_qkquant needs variant bit 8192"); return LEMAS_E_ARG; }
     const int n = M, bh = N, npad = (n + 127) & ~127, pitch = npad;
     bf16_t* q = sc.get<bf16_t>((size_t)bh * pitch * 64);
     bf16_t* k = sc.get<bf16_t>((size_t)bh * pitch * 64);
@@ -647,9 +661,21 @@ extern "C" int lemas_k_bench(const char* what, int32_t M, int32_t N, int32_t K, 
     AttnParams p{};
     p.q = q; p.k = k; p.vt = vt; p.out = o; p.kv_len = nullptr; p.b2 = bh / 16; p.batch = bh / 16; p.heads = 16; p.n = n; p.npad = npad; p.pitch = pitch;
     p.scale = 0.125f; p.variant = variant;
+    if (variant & ATTN_F8QK) {     // "attention_qkquant" times the quantising launch alone, "attention" the kernel on quantised rows
+      const size_t rows = (size_t)bh * pitch;
+      uint8_t* q8 = sc.get<uint8_t>(rows * 64);
+      uint8_t* k8 = sc.get<uint8_t>(rows * 64);
+      uint8_t* qs = sc.get<uint8_t>(rows * 2);
+      uint8_t* ks = sc.get<uint8_t>(rows * 2);
+      if (!q8 || !k8 || !qs || !ks) { set_error("bench: out of memory"); return LEMAS_E_STATE; }
+      HIP_TRY(launch_qk_mx8(q, k, q8, k8, qs, ks, rows, s));
+      p.q8 = q8; p.k8 = k8; p.q8_mx = qs; p.k8_mx = ks;
+      if (quant_only) rc = time_it([&]() { return launch_qk_mx8(q, k, q8, k8, qs, ks, rows, s); });
+      else rc = time_it([&]() { return launch_attention(p, s); });
+    } else
     rc = time_it([&]() { return launch_attention_any(p, s); });
 #ifdef LEMAS_PHASE_TIMESTAMPS
-    if (rc == 0) {   // phase timestamps of one more launch
+    if (rc == 0 && !(variant & ATTN_F8QK)) {   // phase timestamps of one more launch
       const int grid = ((n + 127) / 128) * bh;
       unsigned long long* d = sc.get<unsigned long long>((size_t)grid * 4);
       p.dbg = d;

@@ -385,7 +385,9 @@ struct EpiPre {
 // through the slab.
 // `lnx`: ln fold (GemmParams), consumer epilogues: the (r, -r mu) pairs of this wave tile's rows in LDS ([row][2], written by
 // ln_rowstat_store at the top of the kernel).  The producer side (EPI_GATE_RES with xs_out) needs nothing from the caller.
-template <int EPI, int TI, int TJ, bool COLS_ONCE, int AHEAD = 1, int LNA = (epi_lna<EPI>() ? 1 : 0)>
+// QK8 (EPI_QK_ROPE in the fp8 bodies only): the instantiation can write q / k as MXFP8 (GemmParams::q8); the bf16 kernels do not carry the code
+// (it cost the 256 x 128 and 256 x 256 QK kernels 16-36 B of scratch each)
+template <int EPI, int TI, int TJ, bool COLS_ONCE, int AHEAD = 1, int LNA = (epi_lna<EPI>() ? 1 : 0), bool QK8 = false>
 __device__ __forceinline__ void epilogue_row_blocks(const GemmParams& p, f32x16 (&acc)[TI][TJ], char* slab, int mw, int nw, int lane,
                                                     EpiPre<EPI, TJ, COLS_ONCE, LNA>& pre, const float* lnx = nullptr) {
   static_assert(EPI != EPI_BIAS_GELU_F8 && EPI != EPI_V_T, "bf16-path row epilogues only");
@@ -509,6 +511,11 @@ __device__ __forceinline__ void epilogue_row_blocks(const GemmParams& p, f32x16 
     row_window_kv(pre.win);
     const int rl = pre.win.rl, vo = (rr * 64 + d) * 2;
     const float qs = (which == 0 && p.q_scale != 0.f) ? p.q_scale : 1.0f;
+    // MXFP8 output (GemmParams::q8): the same bf16-rounded values, quantised per 32-wide half of the head = the four lanes of this lane's quad
+    uint8_t* qk8 = which == 0 ? p.q8 : p.k8;
+    uint8_t* qk8mx = which == 0 ? p.q8_mx : p.k8_mx;
+    const bool f8out = QK8 && p.q8 != nullptr;
+    const int vo8 = rr * 64 + d, vomx = (lane & 3) == 0 ? rr * 2 + (d >> 5) : BUF_OOB;
     float4 cnext[ITERS], snext[ITERS];
     auto blocks = [&](auto lna_c) {      // two copies of the unrolled blocks: with and without the folded LayerNorm (a run-time property of the launch)
     constexpr bool L = LNA != 0 && decltype(lna_c)::value;
@@ -554,7 +561,23 @@ __device__ __forceinline__ void epilogue_row_blocks(const GemmParams& p, f32x16 
         o[2] = (bf16_t)((a.z * c.y - a.w * sv.y) * qs); o[3] = (bf16_t)((a.w * c.y + a.z * sv.y) * qs);
         o[4] = (bf16_t)((b.x * c.z - b.y * sv.z) * qs); o[5] = (bf16_t)((b.y * c.z + b.x * sv.z) * qs);
         o[6] = (bf16_t)((b.z * c.w - b.w * sv.w) * qs); o[7] = (bf16_t)((b.w * c.w + b.z * sv.w) * qs);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), wst, vo + it * RPI * 128, 0, BUF_SC1);
+        if (QK8 && f8out) {
+          float v[8], amax = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { v[e] = (float)o[e]; amax = fmaxf(amax, fabsf(v[e])); }
+          amax = fmaxf(amax, dpp_f<0xB1>(amax));      // the quad's other three lanes hold the rest of the 32 values
+          amax = fmaxf(amax, dpp_f<0x4E>(amax));
+          const int ex = mx_exponent(amax);
+          const float inv = mx_inv_scale(ex);
+          const unsigned int __attribute__((ext_vector_type(2))) w8 = {pack_fp8x4(v[0] * inv, v[1] * inv, v[2] * inv, v[3] * inv),
+                                                                      pack_fp8x4(v[4] * inv, v[5] * inv, v[6] * inv, v[7] * inv)};
+          const __amdgpu_buffer_rsrc_t w8st = buf_rows(qk8, row0 + 32 * i, rl - 32 * i, 64);
+          const __amdgpu_buffer_rsrc_t wmx = buf_rows(qk8mx, row0 + 32 * i, rl - 32 * i, 2);
+          __builtin_amdgcn_raw_buffer_store_b64(w8, w8st, vo8 + it * RPI * 64, 0, BUF_SC1);
+          __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(ex + 127), wmx, vomx == BUF_OOB ? BUF_OOB : vomx + it * RPI * 2, 0, BUF_SC1);
+        } else {
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), wst, vo + it * RPI * 128, 0, BUF_SC1);
+        }
       }
     }
     };
@@ -1014,7 +1037,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams& p, char* smem, int m
   // the slab can be rewritten right after it was read): keeps the kernel's LDS footprint = the ring, not ring + big slabs
   char* slab = smem + wave * slab_bytes<EPI, 32, WTN>();
   if constexpr (SWAP && EPI != EPI_BIAS_GELU_F8) {
-    epilogue_row_blocks<EPI, TI, TJ, true, 1, LNA>(p, acc, slab, m0 + wm * WTM, n0 + wn * WTN, lane, pre, rs_lds + 2 * (wm * WTM));
+    epilogue_row_blocks<EPI, TI, TJ, true, 1, LNA, F8 && EPI == EPI_QK_ROPE>(p, acc, slab, m0 + wm * WTM, n0 + wn * WTN, lane, pre, rs_lds + 2 * (wm * WTM));
   } else {
 #pragma unroll
     for (int i = 0; i < TI; ++i) {

@@ -30,6 +30,8 @@ from __future__ import annotations
 import math
 from typing import Optional
 
+import numpy as np
+
 import torch
 import torch.nn.functional as F
 
@@ -150,10 +152,14 @@ def euler_solve(fn, y0: Tensor, t: Tensor) -> Tensor:
 # DiT (backbones/dit.py + model/modules.py)
 # ----------------------------------------------------------------------------------------------
 class OracleDiT:
-    def __init__(self, sd: dict, arch, prefix: str = "transformer.", fp8: bool = False):
+    def __init__(self, sd: dict, arch, prefix: str = "transformer.", fp8: bool = False, fp8_qk: Optional[bool] = None):
         """``fp8=True`` emulates the build's fp8 GEMM variant (BASELINE config 5; not a reference feature): the q/k/v/out
-        and ff linears of every DiTBlock see MXFP8-quantised inputs and per-channel e4m3 weights (oracle/mxfp8.py)."""
+        and ff linears of every DiTBlock see MXFP8-quantised inputs and per-channel e4m3 weights (oracle/mxfp8.py).
+        ``fp8_qk`` (default: follows ``fp8``; engine option attn_f8qk): the rotated q (already multiplied by
+        softmax_scale * log2(e)) and k are rounded to bf16 and quantised to MXFP8, one scale per 32-wide half of a head,
+        before Q K^T -- what csrc/attention.hip's fp8 QK^T path consumes (round 6)."""
         self.fp8 = fp8
+        self.fp8_qk = fp8 if fp8_qk is None else fp8_qk
         self._w8 = {}
         self.a = arch
         self.p = {k[len(prefix):]: torch.as_tensor(v, dtype=torch.float32) for k, v in sd.items()
@@ -233,7 +239,16 @@ class OracleDiT:
         kh = self.lin(q + "to_k", h).view(b, n, H, Dh).transpose(1, 2)
         vh = self.lin(q + "to_v", h).view(b, n, H, Dh).transpose(1, 2)
         qh, kh = rope_apply(qh, freqs), rope_apply(kh, freqs)
-        s = (qh @ kh.transpose(-1, -2)) * (1.0 / math.sqrt(Dh))
+        if self.fp8_qk:
+            from .mxfp8 import mx_quant
+            c = float(np.float32(1.0 / math.sqrt(Dh)) * np.float32(1.4426950408889634))      # the QK epilogue's q_scale (fp32)
+
+            def mx(x):
+                xb = x.to(torch.bfloat16).float()
+                return mx_quant(xb.reshape(-1, Dh))[2].reshape(x.shape)
+            s = (mx(qh * c) @ mx(kh).transpose(-1, -2)) * math.log(2.0)
+        else:
+            s = (qh @ kh.transpose(-1, -2)) * (1.0 / math.sqrt(Dh))
         if mask is not None:
             s = s.masked_fill(~mask[:, None, None, :], float("-inf"))
         o = (torch.softmax(s, dim=-1) @ vh).transpose(1, 2).reshape(b, n, H * Dh)
@@ -289,8 +304,8 @@ class OracleDiT:
 # CFM.sample (cfm.py:206-473) -- inference sampler only
 # ----------------------------------------------------------------------------------------------
 class OracleCFM:
-    def __init__(self, sd: dict, arch, fp8: bool = False):
-        self.dit = OracleDiT(sd, arch, fp8=fp8)
+    def __init__(self, sd: dict, arch, fp8: bool = False, fp8_qk: Optional[bool] = None):
+        self.dit = OracleDiT(sd, arch, fp8=fp8, fp8_qk=fp8_qk)
         self.a = arch
         self.prosody_to_mel = None
         if "prosody_to_mel.weight" in sd:

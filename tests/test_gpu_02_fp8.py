@@ -195,6 +195,48 @@ def test_fp8_cost_of_quantising_activations_and_outlier_stress(golden_dir, name,
     assert got[0] < got[2] < got[1], got          # each step of quantisation costs accuracy: bf16 < weights-only < weights + activations
 
 
+@pytest.mark.parametrize("name", ["mini_plain", "mini_batch", "full_plain"])
+def test_fp8_attn_f8qk_epilogue_equals_side_launch(golden_dir, name):
+    """Engine option attn_f8qk (default 1 on the fp8 path: attention's QK^T on the fp8 MFMA from MXFP8 q / k).  Mode 1 = the fp8 QK GEMM's
+    epilogue writes the MXFP8 rows; mode 2 = it writes bf16 and a side launch (launch_qk_mx8, pinned against oracle/mxfp8.py by
+    tests/test_gpu_14_attention_f8qk.py) quantises them: the same bytes, so the whole output tensor must be bit-identical.  Mode 0 (bf16
+    q / k) must differ and every mode must hold the fp8 path's tolerance against the reference's own output."""
+    import test_gpu_00_sample as T
+    fx, arch, sd = T._load(golden_dir, name)
+    m = _fp8_model(arch, int(fx["vocab"]), sd, bool(fx["prosody"]))
+    args, kw = _golden_args(fx)
+    outs, mse = {}, {}
+    for mode in (1, 2, 0, 1):
+        m.engine.set_option("attn_f8qk", mode)
+        out, _ = m.sample(*args, use_acc_grl=False, **kw)
+        o = out.cpu().numpy()
+        if mode in outs:
+            assert np.array_equal(outs[mode], o), "replay of mode 1 after the other modes differs"
+        outs[mode], mse[mode] = o, T._gen_mse(o, fx["out"], fx)
+    print(f"\n[attn_f8qk {name}] mel-MSE vs reference: bf16 q/k {mse[0]:.3e}, MXFP8 q/k {mse[1]:.3e}")
+    assert np.array_equal(outs[1], outs[2]), float(np.abs(outs[1] - outs[2]).max())
+    assert not np.array_equal(outs[0], outs[1])
+    tol = 1e-3 if name == "full_plain" else 1e-4          # (3-step solve: see test_fp8_sampler_vs_emulation_and_reference_golden)
+    assert mse[0] <= tol and mse[1] <= tol, mse
+
+
+def test_attn_f8qk_is_inert_on_the_bf16_path(golden_dir):
+    """BASELINE's bf16 configurations must not see it: with the block GEMMs on bf16 operands the option changes nothing (bit-identical),
+    unless bit 2 (measurement) forces it"""
+    import test_gpu_00_sample as T
+    from lemas_tts_amd.model.cfm import CFM
+    fx, arch, sd = T._load(golden_dir, "mini_plain")
+    m = CFM(arch, int(fx["vocab"]), sd, device=DEV)
+    args, kw = _golden_args(fx)
+    outs = {}
+    for mode in (0, 1, 2, 6):
+        m.engine.set_option("attn_f8qk", mode)
+        outs[mode] = m.sample(*args, use_acc_grl=False, **kw)[0].cpu().numpy()
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    assert not np.array_equal(outs[0], outs[6])
+    assert T._gen_mse(outs[6], fx["out"], fx) <= 1e-4
+
+
 @needs_measurement_build
 def test_outlier_rows_kernel():
     """csrc/outlier_rows.hip: the flagged output channels of a residual-writing projection from bf16 operands, gated and added in place --

@@ -61,6 +61,7 @@ def main():
         m.engine.set_option("lane_skew", int(opts.get("skew", 0)))
         m.engine.set_option("block_persist", int(opts.get("persist", 0)))   # measurement builds: the FF half of a block as one persistent launch
         m.engine.set_option("attn_variant", int(opts.get("attn", DEFAULT_ATTN)))
+        m.engine.set_option("attn_f8qk", int(opts.get("f8qk", 1)))           # fp8 QK^T in attention (engine default 1: active on the fp8 path only; +4 forces it)
         m.engine.set_option("fp8", int(opts.get("fp8", 0)))
         m.engine.set_option("qkv_fused", int(opts.get("qkv_fused", 1)))
         m.engine.set_option("dual", int(opts.get("dual", 1)))          # drops the cached graphs: the next sample captures under this arm's choices

@@ -15,6 +15,7 @@
 #   traffic:<workload>           FETCH_SIZE / WRITE_SIZE passes -> <TAG>_pmc_traffic_<w>.txt
 #   timeline[:<workload>]        measurement build (-DLEMAS_PHASE_TIMESTAMPS) -> tools/timeline_step.py -> product build again
 #   kbench[:<args, '+' for spaces>]   tools/kbench.py
+#   mbuild / pbuild              rebuild the libraries with -DLEMAS_MEASUREMENT_BUILD (no phase stamps) / as the product
 #   scale:<n>                    bench.py with n ranks sharing the one GPU over gloo (weak-scaling line + the sharded job)
 #   py:<script, '+' for spaces>  python <script> (experiments under tools/exp or tools/)
 #   pyprof:<name>:<script, '+' for spaces>   rocprofv3 --kernel-trace --stats over `python <script>` -> <TAG>_kernel_stats_<name>.txt
@@ -85,6 +86,10 @@ for step in "$@"; do
       for w in $(echo "${rest:-configs1}" | tr ',' ' '); do
         timeout 600 python tools/timeline_step.py --workload $w --json "$O/${TAG}_timeline_$w${TLOPT:+_$(echo $TLOPT | tr -d ' =')}.json" ${TLOPT:+--opt $TLOPT} 2>&1 | grep -v amdgpu.ids > "$O/${TAG}_timeline_step_$w${TLOPT:+_$(echo $TLOPT | tr -d ' =')}.txt"; head -40 "$O/${TAG}_timeline_step_$w${TLOPT:+_$(echo $TLOPT | tr -d ' =')}.txt"
       done
+      timeout 900 python -c "from lemas_tts_amd import build; build.build_library(force=True)" ;;
+    mbuild)     # measurement build WITHOUT the phase stamps (engine options of the kept experiments, e.g. attn_f8qk); `pbuild` restores the product
+      LEMAS_EXTRA_HIPCC_FLAGS=-DLEMAS_MEASUREMENT_BUILD timeout 900 python -c "from lemas_tts_amd import build; build.build_library(force=True)" ;;
+    pbuild)
       timeout 900 python -c "from lemas_tts_amd import build; build.build_library(force=True)" ;;
     kbench)
       timeout 900 python tools/kbench.py $(sp "${rest:-gemm}") 2>&1 | grep -v amdgpu.ids | tee -a "$O/${TAG}_kbench.txt" ;;

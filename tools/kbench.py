@@ -60,6 +60,9 @@ def main():
                 for v in args.variants:
                     us = bench(L, "attention", n, bh, 0, args.iters, v)
                     cells.append(f"v{v}:      n/a      " if us is None else f"v{v}: {us:6.1f} us ({4.0 * n * n * 64 * bh / us / 1e6:4.0f} TF)")
+                    if v & 8192 and us is not None:      # attention_f8qk.h: the launch that quantises q and k to MXFP8, timed alone
+                        qus = bench(L, "attention_qkquant", n, bh, 0, args.iters, v)
+                        cells.append(f"(+ q,k -> MXFP8 launch {qus:5.1f} us)" if qus is not None else "(quant n/a)")
                 print(f"attention N={n} BH={bh}: " + "   ".join(cells))
     else:
         us = bench(L, args.what, args.M, args.N, args.K, args.iters, args.tile)
