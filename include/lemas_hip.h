@@ -120,6 +120,11 @@ int lemas_dit_finalize(lemas_dit* m);
  *        activations (one E8M0 scale per 32 K); attention, norms, residual stream and ODE state unchanged; default 0;
  *        takes effect at the next prepare()/sample().  2 = accuracy point, not a speed path: the same e4m3 weights with bf16
  *        ACTIVATIONS (weights-only fp8), computed by the bf16 kernels on the dequantised weights),
+ * "attn_f8qk" (what attention does WHILE the block GEMMs run on fp8 operands, i.e. under "fp8" = 1 with no tripped outlier guard: 1 (default) =
+ *        the fp8 QK GEMM's epilogue writes the rotated q (prescaled by softmax_scale * log2 e) and k as MXFP8, one E8M0 scale per 32-wide half of a
+ *        head, and Q K^T runs on v_mfma_scale_f32_32x32x64_f8f6f4 (csrc/attention.hip, variant bit 8192); P . V stays bf16.  0 = bf16 q / k as on
+ *        the bf16 path.  2 = as 1 with a side launch quantising bf16 rows (the same bytes: A/B form).  + 4 = also on the bf16 path (a measurement:
+ *        BASELINE's bf16 configurations never use it).  Needs attn_variant 17 or 19 (q prescaled by the QK epilogue), else it is inert),
  * "ln_fold" (1 = those LayerNorms folded ACROSS the GEMMs on either side -- the gate + residual epilogues write the scaled bf16 rows and
  *        per-row partial sums, the QKV / FF1 epilogues apply the row statistics, c1 / c2 rows per ODE step in the AdaLN table: no
  *        LayerNorm launch after a step's first; bf16 activations only; a different rounding of the same arithmetic, inside the
