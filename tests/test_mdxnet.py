@@ -68,14 +68,17 @@ def test_oracle_kim_shape_matches_the_reference_class(golden_dir):
     _check_kim(y, fx, 2e-5)
 
 
-def _check_kim(y, fx, rel):
+def _check_kim(y, fx, rel, rel_sums=None):
     KIM_SAMPLE = MO.KIM_SAMPLE
     rms = float(fx["rms"][0])
+    rel_sums = rel if rel_sums is None else rel_sums
     assert np.abs(y[KIM_SAMPLE] - fx["sample"]).max() / rms < rel
     assert abs(np.sqrt((y.astype(np.float64) ** 2).mean()) - rms) / rms < rel
     # sums over [b, c, t] per frequency bin (768 values each) and over [b, c, f] per frame (12288 values each): every output element is in one
-    assert np.abs(y.astype(np.float64).sum(axis=(0, 1, 3)) - fx["row_sums"]).max() / (rms * np.sqrt(768)) < rel
-    assert np.abs(y.astype(np.float64).sum(axis=(0, 1, 2)) - fx["col_sums"]).max() / (rms * np.sqrt(12288)) < rel
+    er = np.abs(y.astype(np.float64).sum(axis=(0, 1, 3)) - fx["row_sums"]).max() / (rms * np.sqrt(768))
+    ec = np.abs(y.astype(np.float64).sum(axis=(0, 1, 2)) - fx["col_sums"]).max() / (rms * np.sqrt(12288))
+    print(f"[mdxnet kim] row sums {er:.2e}, column sums {ec:.2e} (of rms * sqrt(count))")
+    assert er < rel_sums and ec < rel_sums, (er, ec)
 
 
 # ------------------------------------------------------------------------------------------------------------------ GPU
@@ -177,7 +180,10 @@ def test_hip_network_split_bf16_kim_shape_and_edges(golden_dir):
     d = y[MO.KIM_SAMPLE].astype(np.float64) - fx["sample"]
     print(f"\n[mdxnet kim, bf16x3] sample: max err / rms {np.abs(d).max() / rms:.2e}, rms err / rms {np.sqrt((d ** 2).mean()) / rms:.2e}")
     assert np.sqrt((d ** 2).mean()) / rms < BX_RMS
-    _check_kim(y, fx, BX_MAX)
+    # the checksums get their own bar in this mode: a split-bf16 product drops the lo x lo term and rounds the WEIGHTS' hi / lo parts once, so the
+    # error of an output element has a part that is common to everything the same weights produced -- the 768 errors of a frequency bin (same
+    # TDF rows, every frame) add coherently instead of as a random walk: measured 1.8e-3 / 1.1e-3 of rms * sqrt(count) (exact mode: 2e-5)
+    _check_kim(y, fx, BX_MAX, rel_sums=5e-3)
     with pytest.raises(_lib.LemasError, match="before finalize"):          # the option decides the weight layout
         _lib.check(_lib.lib().lemas_mdx_set_option(eng._h, b"bf16x3", 0), "set_option")
     del eng
