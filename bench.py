@@ -698,7 +698,8 @@ def main():
             "rtf": elapsed / (a.steps * audio_per_step),
             "mel_mse_vs_reference": mse,
             "config": {"workload": f"{w['desc']} (F={F_REF}, N={N_TOT}), NFE={nfe}, CFG={CFG}, sway coef {sway} (capped), "
-                                   + ("fp8-e4m3 (MXFP8) GEMM operands, bf16 attention" if a.fp8 else "bf16 MFMA operands")
+                                   + (("fp8-e4m3 (MXFP8) GEMM operands, " + ("bf16 attention" if a.attn_f8qk == 0 else "attention: Q K^T on MXFP8 q / k (fp8 MFMA), P V bf16"))
+                                      if a.fp8 else "bf16 MFMA operands")
                                    + " / fp32 state, Vocos decode + D2H included",
                        "workload_key": a.workload,
                        "utterances_per_gpu_per_step": B, "audio_seconds_per_step": audio_per_step,
