@@ -131,6 +131,27 @@ def test_dual_lane_is_bit_identical_to_single_lane(golden_dir, name):
         np.testing.assert_array_equal(v, ref, err_msg=str(k))
 
 
+@pytest.mark.parametrize("name", ["mini_plain", "mini_batch", "full_plain"])
+def test_default_dispatch_equals_the_tiles_without_loader_waves(golden_dir, name):
+    """Round 6: for bf16 operands the dispatch picks the LOADER-WAVE forms of the lock-step GEMM tiles (gemm_bf16.hip pick_tile / pick_qkv_tile:
+    tiles 28 / 30 / 31, four waves that only request and await the ring's LDS-DMA pieces behind the compute waves).  Same ring, LDS image, barriers
+    and MFMA order: forcing the plain tiles (engine measurement options) must reproduce the default's output bit for bit -- the block GEMMs of
+    both widths and the fused QK + V launch, on short rows (64 x 64 / 128 x 64 tiles) and at full depth."""
+    fx, arch, sd = _load(golden_dir, name)
+    m = _model(arch, int(fx["vocab"]), int(fx["wseed"]), bool(fx["prosody"]), sd)
+    outs = {}
+    arms = {"default": {}, "plain small": {"tile_n1024": 19, "tile_n2048": 18, "tile_qkv": 18}, "plain 128": {"tile_n1024": 17, "tile_n2048": 26, "tile_qkv": 26},
+            "loaders 128": {"tile_n1024": 28, "tile_n2048": 28, "tile_qkv": 28}, "loaders small": {"tile_n1024": 31, "tile_n2048": 30, "tile_qkv": 30}}
+    for arm, opts in arms.items():
+        for k in ("tile_n1024", "tile_n2048", "tile_qkv"):
+            m.engine.set_option(k, opts.get(k, 0))
+        outs[arm] = _run_case(fx, arch, sd, graph=True, traj=False)[0]      # (_model caches: the same engine)
+    for k in ("tile_n1024", "tile_n2048", "tile_qkv"):
+        m.engine.set_option(k, 0)
+    for arm, v in outs.items():
+        np.testing.assert_array_equal(v, outs["default"], err_msg=arm)
+
+
 @needs_measurement_build
 @pytest.mark.parametrize("name", ["mini_plain", "mini_batch", "full_plain"])
 def test_fused_layernorm_tail_is_bit_identical_to_separate_launches(golden_dir, name):

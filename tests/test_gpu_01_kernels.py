@@ -243,7 +243,7 @@ def _gemm_epi_case(tile, epi, batch, frames, N, K, seed, ragged=False):
     assert err < tol, (tile, epi, batch, frames, N, K, err)
 
 
-@pytest.mark.parametrize("tile", [16, 17, 18, 19, 22, 26])
+@pytest.mark.parametrize("tile", [16, 17, 18, 19, 22, 26, 27, 28, 29, 30, 31])
 @pytest.mark.parametrize("epi,N,K", [(EPI_F32, 1024, 1024), (EPI_GELU, 2048, 1024), (EPI_GATE, 1024, 2048), (EPI_QK, 2048, 1024),
                                      (EPI_VT, 1024, 1024), (EPI_BF16, 1024, 1024)])
 def test_gemm_every_tile_and_epilogue_batch1(tile, epi, N, K):
@@ -259,6 +259,37 @@ def test_gemm_batched_row_counts(tile, epi, N, K, batch, frames):
     """M = 15360 (config3's lane), 30720 (8 x configs[1]), 8320 (>= 8192, odd tile count): the shapes where the dispatch
     switches to 256x256 tiles; gate/residual with ragged per-sample lengths"""
     _gemm_epi_case(tile, epi, batch, frames, N, K, seed=batch * 100 + tile + epi, ragged=True)
+
+
+@pytest.mark.parametrize("plain,loaders", [(17, 27), (26, 28), (26, 29), (18, 30), (19, 31)])
+@pytest.mark.parametrize("epi,N,K,batch,frames", [(EPI_GATE, 1024, 1024, 1, 1875), (EPI_GATE, 1024, 2048, 3, 700), (EPI_GELU, 2048, 1024, 1, 1875),
+                                                   (EPI_QK, 2048, 1024, 2, 333), (EPI_VT, 1024, 1024, 1, 130), (EPI_F32, 1024, 64, 1, 100)])
+def test_gemm_loader_wave_tiles_are_bit_identical(plain, loaders, epi, N, K, batch, frames):
+    """tiles 27 / 28 = tiles 17 / 26 with four loader waves behind the compute waves (gemm_bf16.hip gemm_body NL): the same ring, LDS image, barriers
+    and MFMA order, so every output bit must be the same -- incl. K = 64 (one K-tile: the loaders' prologue only) and ragged batches"""
+    L, lib = _lib()
+    dev = "cuda:0"
+    pitch = (frames + 127) // 128 * 128
+    M = batch * pitch
+    g = torch.Generator(device=dev).manual_seed(plain * 1000 + epi * 10 + batch)
+    A = torch.randn(M, K, generator=g, device=dev)
+    W = torch.randn(N, K, generator=g, device=dev) * 0.05
+    bias = torch.randn(N, generator=g, device=dev)
+    aux = lens = None
+    if epi == EPI_GATE:
+        aux = torch.randn(N, generator=g, device=dev)
+        lens = torch.randint(1, frames + 1, (batch,), generator=g, device=dev, dtype=torch.int32)
+    elif epi == EPI_QK:
+        ang = torch.arange(frames, device=dev).float()[:, None] * (1.0 / (10000.0 ** (torch.arange(0, 64, 2, device=dev).float() / 64)))[None, :]
+        aux = torch.cat([ang.cos().reshape(-1), ang.sin().reshape(-1)]).contiguous()
+    x0 = torch.randn(M, N, generator=g, device=dev)
+    outs = []
+    for tile in (plain, loaders):
+        out = x0.clone() if epi in (EPI_GATE, EPI_F32, EPI_GELU) else torch.zeros(2 * M * N if epi == EPI_QK else M * N, device=dev)
+        L.check(lib.lemas_k_gemm_epi(epi, tile, A.data_ptr(), W.data_ptr(), bias.data_ptr(), aux.data_ptr() if aux is not None else None,
+                                     lens.data_ptr() if lens is not None else None, out.data_ptr(), batch, pitch, frames, N, K, None), f"tile {tile}")
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
 
 
 def test_gemm_production_choice_matches_explicit_tiles():

@@ -171,14 +171,14 @@ def _ln_fold_case(prod_tile, cons_epi, cons_tile, batch, frames, Kp, Nc, seed, u
     return ea, eb
 
 
-@pytest.mark.parametrize("prod_tile", [16, 17, 18, 19, 22, 26])
+@pytest.mark.parametrize("prod_tile", [16, 17, 18, 19, 22, 26, 28, 30, 31])
 @pytest.mark.parametrize("Kp", [1024, 2048])
 def test_ln_fold_every_producer_tile(prod_tile, Kp):
     """the gate + residual GEMM writing the scaled bf16 rows + row partial sums, on every tile the sampler can pick for it"""
     _ln_fold_case(prod_tile, 1, 26, 1, 1875, Kp, 2048, seed=prod_tile * 3 + Kp)
 
 
-@pytest.mark.parametrize("cons_epi,cons_tile,Nc", [(1, 16, 2048), (1, 17, 2048), (1, 18, 2048), (1, 19, 2048), (1, 22, 2048), (1, 26, 2048),
+@pytest.mark.parametrize("cons_epi,cons_tile,Nc", [(1, 16, 2048), (1, 17, 2048), (1, 18, 2048), (1, 19, 2048), (1, 22, 2048), (1, 26, 2048), (1, 28, 2048), (1, 30, 2048), (4, 28, 2048), (4, 30, 2048), (5, 28, 1024), (5, 31, 1024),
                                                    (4, 16, 2048), (4, 17, 2048), (4, 18, 2048), (4, 22, 2048), (4, 26, 2048),
                                                    (5, 16, 1024), (5, 17, 1024), (5, 18, 1024), (5, 19, 1024), (5, 22, 1024), (5, 26, 1024)])
 def test_ln_fold_every_consumer_epilogue_and_tile(cons_epi, cons_tile, Nc):
