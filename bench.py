@@ -811,7 +811,10 @@ def main():
             # the same time per K-tile, and a loop that overlaps them to 56 %.  Read from the committed JSON that tools/kloop_pipes_json.py
             # derives from the raw profile lines -- no number is typed in here.
             t17 = pipes["tiles"]["17"]
-            result["roofline"]["k_loop_pipes"] = {"tile": "128 x 128 x 64, 8 waves, one workgroup per CU",
+            result["roofline"]["k_loop_pipes"] = {"tile": "128 x 128 x 64, 8 waves, one workgroup per CU (round 4's 8-wave tile; since round 6 this launch runs its "
+                                                          "4 compute + 4 loader wave form: same 0.43-0.44 us per K-tile with the compute waves free of LDS-DMA "
+                                                          "issue and with a 4-stage ring -- profiles/r06/r06v_kbench_loader_wave_tiles.txt -- i.e. the loop sits on the "
+                                                          "LDS port: 32 KB of DMA writes + 64-96 KB of fragment reads per K-tile; 0.7 us less outside the loop)",
                                                   "us_per_k_tile": dict(t17["us_per_k_tile"], **{k + "_ideal": v for k, v in pipes["ideal_us_per_k_tile"].items() if k != "clock_ghz"}),
                                                   "outside_the_loop_us": t17["outside_the_loop_us"], "source": pipes_src}
         if bounds_all:
