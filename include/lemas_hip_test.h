@@ -54,6 +54,8 @@ int lemas_k_convpos(const float* x, const float* w1, const float* b1, const floa
 /* one production bf16 GEMM launch with an explicit tile and epilogue in the engine's row space: rows = batch x pitch
  * (pitch % 128 == 0), `frames` valid rows per sample.  A [batch*pitch, K], W [N, K], bias [N] fp32 (rounded to bf16 inside).
  *   tile: 0 production choice | 16 = 256x128 | 17 = 128x128 | 18 = 128x64 | 19 = 64x64 | 22 = 256x256 | 26 = 128x128 (4 waves)
+ *         | bf16 only, the lock-step tiles with four LOADER waves behind the compute waves (bit-identical to the plain form): 27 = 17 + loaders,
+ *           28 = 26 + loaders, 29 = 28 with a 4-stage ring (measurement), 30 = 18 + loaders, 31 = 19 + loaders
  *   epi 0: out[M,N] = bf16(acc + bias)        1: out = bf16(gelu_tanh(acc + bias))       2: out = acc + bias (fp32)
  *   epi 3: out[M,N] += aux[n] * (acc + bias) for rows with pos < frames (and pos < seq_len[b] when given); aux = gate [N]
  *   epi 4: N = 2*H*64: +bias, RoPE with aux = [cos | sin] ([frames][32] each) -> out = q then k, each [batch][H][pitch][64]
