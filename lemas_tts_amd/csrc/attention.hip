@@ -183,6 +183,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int ntiles = (kvlen + KB - 1) / KB, nsup = (ntiles + 1) >> 1;
   const float c = (VAR & 16) != 0 ? 1.0f : p.scale * 1.4426950408889634f;    // VAR & 16: q arrives prescaled
   constexpr bool F8 = (VAR & ATTN_F8QK) != 0;
+  // ABLATION (measurement builds, wrong results): P . V on the fp8 MFMA as well, with NO block maximum for P's scale and unit scales for V^T -- the
+  // work of the cheapest conceivable fp8 P . V (half the V^T bytes, 4 instead of 8 fragment reads, 2 instead of 8 MFMAs per tile): an UPPER bound
+  // on what a real one (which needs a per-(query, 32-key) maximum for P's E8M0 scale and MXFP8 v^T from the V epilogue) could gain
+  constexpr bool PV8 = (VAR & 16384) != 0;
+  static_assert(!PV8 || F8, "the fp8 P.V ablation sits on the fp8 QK^T path");
   static_assert(!F8 || ((VAR & 17) == 17 && (VAR & (8 | 1024)) == 0), "the fp8 QK^T path is built on the no-running-max softmax (bits 1 and 16)");
   const char* kg = F8 ? reinterpret_cast<const char*>(p.k8 + (size_t)bh * p.pitch * 64) : reinterpret_cast<const char*>(p.k + (size_t)bh * p.pitch * 64);
   const char* ksg = F8 ? reinterpret_cast<const char*>(p.k8_mx + (size_t)bh * p.pitch * 2) : nullptr;
@@ -204,12 +209,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   auto issue = [&](int stage, int i) __attribute__((always_inline)) {
     char* base = smem + stage * STAGE2 + wave * 1024;
     if constexpr (F8) {
+      if constexpr (PV8) {      // half the V^T bytes: one 1-KiB piece per wave (any finite bytes do for the timing)
+        int j = 2 * i + grp;
+        j = j < ntiles ? j : ntiles - 1;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vg + (size_t)j * (KB * 2) + voff),
+                                         (__attribute__((address_space(3))) void*)(smem + stage * STAGE2 + grp * 2 * TILE + TILE + (wave & 3) * 1024), 16, 0, 0);
+      } else {
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
         int j = 2 * i + g;
         j = j < ntiles ? j : ntiles - 1;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vg + (size_t)j * (KB * 2) + voff),
                                          (__attribute__((address_space(3))) void*)(base + g * 2 * TILE + TILE), 16, 0, 0);
+      }
       }
       int j = 2 * i + grp;
       j = j < ntiles ? j : ntiles - 1;
@@ -427,6 +439,34 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       }
       l_run += ps[0] + ps[1];
       return true;
+    } else if constexpr (FAST && PV8) {
+      f32x2 ps = {0.f, 0.f};
+      i32x8 pf8;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; r += 4) {
+          const f32x2 p0 = {__builtin_amdgcn_exp2f(s[t][r]), __builtin_amdgcn_exp2f(s[t][r + 1])};
+          const f32x2 p1 = {__builtin_amdgcn_exp2f(s[t][r + 2]), __builtin_amdgcn_exp2f(s[t][r + 3])};
+          ps += p0;
+          ps += p1;
+          int w = 0;
+          w = __builtin_amdgcn_cvt_pk_fp8_f32(p0[0], p0[1], w, false);
+          w = __builtin_amdgcn_cvt_pk_fp8_f32(p1[0], p1[1], w, true);
+          pf8[t * 4 + (r >> 2)] = w;
+        }
+      l_run += ps[0] + ps[1];
+      const char* sV8 = smem + SG * STAGE2 + grp * 2 * TILE + TILE;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const int row = dt * 32 + l31;
+        const u32x4 a0 = *reinterpret_cast<const u32x4*>(sV8 + row * 64 + ((hi ^ ((row >> 2) & 3)) << 4));
+        const u32x4 a1 = *reinterpret_cast<const u32x4*>(sV8 + row * 64 + (((2 + hi) ^ ((row >> 2) & 3)) << 4));
+        i32x8 vf;
+        vf[0] = a0[0]; vf[1] = a0[1]; vf[2] = a0[2]; vf[3] = a0[3]; vf[4] = a1[0]; vf[5] = a1[1]; vf[6] = a1[2]; vf[7] = a1[3];
+        o[dt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf, pf8, o[dt], 0, 0, 0, 127, 0, 127);
+      }
+      return true;
     } else if constexpr (FAST && (VAR & 16) != 0) {
       f32x2 ps = {0.f, 0.f};                // P = exp2(S) (second sweep of the fallback: exp2(S - m_run)): see VAR & 16
       const f32x2 m2 = {m_run, m_run};
@@ -569,7 +609,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       if (lane == 0) flags[wq] = bad ? 1 : 0;
     }
     __syncthreads();                                   // xch consumed, flags visible
-    if (__builtin_expect((VAR & (32 | 64 | 128 | 256 | 512 | 2048)) == 0 && (flags[0] | flags[1] | flags[2] | flags[3]) != 0, 0)) {     // (ablation builds never redo)
+    if (__builtin_expect((VAR & (32 | 64 | 128 | 256 | 512 | 2048 | 16384)) == 0 && (flags[0] | flags[1] | flags[2] | flags[3]) != 0, 0)) {     // (ablation builds never redo)
       __syncthreads();                                 // every wave has read the flags before any refill DMA may overwrite them
       restart();                                       // two-pass softmax: every row's maximum over this wave's tiles ...
       key_loop_cold(maxonly_t{});
@@ -695,6 +735,7 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
     LEMAS_ATTN_LAUNCH(8) LEMAS_ATTN_LAUNCH(10)
     LEMAS_ATTN_LAUNCH(17 + 32) LEMAS_ATTN_LAUNCH(17 + 64) LEMAS_ATTN_LAUNCH(17 + 128) LEMAS_ATTN_LAUNCH(17 + 256) LEMAS_ATTN_LAUNCH(17 + 256 + 512)
     LEMAS_ATTN_LAUNCH(17 + 128 + 256 + 512) LEMAS_ATTN_LAUNCH(19 + 2048) LEMAS_ATTN_LAUNCH(19 + 1024 + 2048)
+    LEMAS_ATTN_LAUNCH(19 + ATTN_F8QK + 16384)
 #endif
     default: return hipErrorInvalidValue;
   }

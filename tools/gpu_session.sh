@@ -87,6 +87,8 @@ for step in "$@"; do
         timeout 600 python tools/timeline_step.py --workload $w --json "$O/${TAG}_timeline_$w${TLOPT:+_$(echo $TLOPT | tr -d ' =')}.json" ${TLOPT:+--opt $TLOPT} 2>&1 | grep -v amdgpu.ids > "$O/${TAG}_timeline_step_$w${TLOPT:+_$(echo $TLOPT | tr -d ' =')}.txt"; head -40 "$O/${TAG}_timeline_step_$w${TLOPT:+_$(echo $TLOPT | tr -d ' =')}.txt"
       done
       timeout 900 python -c "from lemas_tts_amd import build; build.build_library(force=True)" ;;
+    tbuild)     # measurement build WITH the phase stamps (-DLEMAS_PHASE_TIMESTAMPS: the ablation instantiations of attention.hip / gemm_bf16.hip); `pbuild` restores
+      LEMAS_EXTRA_HIPCC_FLAGS=-DLEMAS_PHASE_TIMESTAMPS timeout 900 python -c "from lemas_tts_amd import build; build.build_library(force=True)" ;;
     mbuild)     # measurement build WITHOUT the phase stamps (engine options of the kept experiments, e.g. attn_f8qk); `pbuild` restores the product
       LEMAS_EXTRA_HIPCC_FLAGS=-DLEMAS_MEASUREMENT_BUILD timeout 900 python -c "from lemas_tts_amd import build; build.build_library(force=True)" ;;
     pbuild)
