@@ -79,7 +79,7 @@ __device__ __forceinline__ bool tile_of(int bid, int tiles_m, int tiles_n, int g
 #ifndef LEMAS_MEASUREMENT_BUILD
   runs = 0;      // round 3's order is an A/B arm of measurement builds (engine option "xcd_runs")
 #endif
-  if (runs) {
+  if (runs == 1) {      // (2 = the tail-skip ablation of the ping-pong launches, see tail_skip_grid: the default order)
     const int nwg = tiles_m * tiles_n;
     if (bid >= nwg) return false;
     tile_coords(xcd_remap(bid, nwg), tiles_m, tiles_n, gx, tm, tn);
@@ -98,7 +98,17 @@ static inline int grid_of(int tiles_m, int tiles_n, int gx, int runs) {
 #ifndef LEMAS_MEASUREMENT_BUILD
   runs = 0;
 #endif
-  return runs ? tiles_m * tiles_n : xcd_grid(tiles_m, tiles_n, gx);
+  return runs == 1 ? tiles_m * tiles_n : xcd_grid(tiles_m, tiles_n, gx);
+}
+// ABLATION, measurement builds only (engine option xcd_runs = 2; WRONG RESULTS by construction): a multi-round ping-pong launch drops the workgroups
+// of its partial last round, i.e. the work a stream-K / tail-splitting scheme would have to redistribute simply vanishes.  What that buys end to end is
+// an UPPER bound on what any such scheme can buy in situ (round-5 review, item 2c: measured instead of argued).
+static inline int tail_skip_grid(const GemmParams& p, int grid) {
+#ifdef LEMAS_MEASUREMENT_BUILD
+  if (p.xcd_runs == 2 && grid > 256) return grid / 256 * 256;
+#endif
+  (void)p;
+  return grid;
 }
 __device__ __forceinline__ void tile_coords(int seq, int tiles_m, int tiles_n, int gx, int& tm, int& tn) {
   const int gy = 8 / gx;
@@ -1468,7 +1478,7 @@ struct LaunchPP2 {
   }
   static hipError_t run(const GemmParams& p, hipStream_t s) {
     if (p.N % 128 != 0 || p.K % 64 != 0) return hipErrorInvalidValue;
-    const dim3 grid(grid_of((p.M + 255) / 256, p.N / 128, p.xcd_gx, p.xcd_runs)), block(512);
+    const dim3 grid(tail_skip_grid(p, grid_of((p.M + 255) / 256, p.N / 128, p.xcd_gx, p.xcd_runs))), block(512);
     // the (r, -r mu) table behind the ring is only there for a ln-fold consumer: every other launch keeps the ring's own footprint
     const int lds_now = p.ln_part ? lds : lds - 256 * 8;
     if (p.ev_start) hipExtLaunchKernelGGL((gemm_pp2_kernel<EPI>), grid, block, lds_now, s, p.ev_start, p.ev_stop, 0, p);
@@ -1495,7 +1505,7 @@ struct LaunchPP {
   }
   static hipError_t run(const GemmParams& p, hipStream_t s) {
     if (p.N % 256 != 0 || p.K % 64 != 0) return hipErrorInvalidValue;
-    const dim3 grid(grid_of((p.M + 255) / 256, p.N / 256, p.xcd_gx, p.xcd_runs)), block(512);
+    const dim3 grid(tail_skip_grid(p, grid_of((p.M + 255) / 256, p.N / 256, p.xcd_gx, p.xcd_runs))), block(512);
     const int lds_now = p.ln_part ? lds : lds - 256 * 8;
     if (p.ev_start) hipExtLaunchKernelGGL((gemm_pp_kernel<EPI>), grid, block, lds_now, s, p.ev_start, p.ev_stop, 0, p);
     else hipLaunchKernelGGL((gemm_pp_kernel<EPI>), grid, block, lds_now, s, p);
