@@ -107,6 +107,7 @@ struct lemas_dit {
   // measurement option: lane 1 launches stage k of a block only after lane 0's stage k has completed (the lanes run one stage apart
   // instead of in lock-step, so unlike kernels share the chip)
   int lane_skew = 0;
+  int ln_skip = 0;            // ABLATION, measurement builds only (wrong results): 1 = no LayerNorm launch after block 0's first -- the upper bound of any LayerNorm fusion
   // fp8 QK^T in attention (attention.hip VAR & ATTN_F8QK): bits 0-1 = 0 off | 1 the QK GEMM epilogue writes q, k as MXFP8 | 2 a side launch
   // quantises the bf16 rows (same bits, one more launch: the A/B form); bit 2 = also while the block GEMMs run on bf16 operands (measurements:
   // BASELINE's bf16 configurations must not use it).  Takes effect with a prescaled-q attention variant (17 / 19) only.
@@ -1001,7 +1002,7 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
         RC_TRY(pend(q));
       }
       g.ln_part = lnpart; g.ln_np = d / 32;
-    } else if (!(fuse_ln && l > 0)) {      // fused: block l's attn_norm rows were written by block l-1's FF2 launch
+    } else if (!(fuse_ln && l > 0) && !(ln_skip && l > 0)) {      // fused: block l's attn_norm rows were written by block l-1's FF2 launch
       RC_TRY(pbegin(PC_LN, q));
       if (f8_qkv) HIP_TRY(launch_ln_mod_f8(xres, h8, hmx, rows, d, tab, tab_stride, base + d, base, step, q));
       else HIP_TRY(launch_ln_mod(xres, hbf, rows, d, tab, tab_stride, base + d, base, step, q, live_a_l, pitch, len_batch));
@@ -1089,7 +1090,7 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     RC_TRY(skew_post(ln, q));
     g.ln_out = nullptr; g.xs_out = nullptr;
     g.live_len = live_l;        // FF half
-    if (!fuse_ln && !fold && !persist) {
+    if (!fuse_ln && !fold && !persist && !ln_skip) {
       RC_TRY(pbegin(PC_LN, q));
       if (f8_ff1) HIP_TRY(launch_ln_mod_f8(xres, h8, hmx, rows, d, tab, tab_stride, base + 4 * d, base + 3 * d, step, q));
       else HIP_TRY(launch_ln_mod(xres, hbf, rows, d, tab, tab_stride, base + 4 * d, base + 3 * d, step, q, live_l, pitch, len_batch));
@@ -1380,6 +1381,7 @@ int lemas_dit_set_option(lemas_dit* m, const char* key, int64_t value) {
     return 0;
   }
 #ifdef LEMAS_MEASUREMENT_BUILD
+  if (!strcmp(key, "ln_skip")) { m->ln_skip = value != 0; m->drop_graphs(); return 0; }
   if (!strcmp(key, "block_persist")) {
     if (value < 0 || value > 2) { set_error("lemas_dit_set_option: block_persist is 0, 1 or 2 (with the weight prefetch across the barrier)"); return LEMAS_E_ARG; }
     m->block_persist = (int)value;
@@ -1388,7 +1390,8 @@ int lemas_dit_set_option(lemas_dit* m, const char* key, int64_t value) {
   }
 #endif
 #ifndef LEMAS_MEASUREMENT_BUILD
-  if (!strcmp(key, "ln_fused") || !strcmp(key, "lane_skew") || !strcmp(key, "xcd_runs") || !strcmp(key, "block_persist") || !strcmp(key, "fp8_outlier_mode")) {
+  if (!strcmp(key, "ln_fused") || !strcmp(key, "lane_skew") || !strcmp(key, "xcd_runs") || !strcmp(key, "block_persist") || !strcmp(key, "fp8_outlier_mode") ||
+      !strcmp(key, "ln_skip")) {
     if (value == 0) return 0;       // "off" is what the product does anyway
     set_error("lemas_dit_set_option: '%s' is a measurement option -- its code exists only in builds of the library with -DLEMAS_MEASUREMENT_BUILD "
               "(LEMAS_EXTRA_HIPCC_FLAGS, lemas_tts_amd/build.py); the product library does not carry it", key);

@@ -59,6 +59,7 @@ def main():
         m.engine.set_option("ln_fold", int(opts.get("ln_fold", 0)))
         m.engine.set_option("lane_split", int(opts.get("split", 0)))       # sample groups per CFG branch (2 x split lanes); 0 = automatic
         m.engine.set_option("lane_skew", int(opts.get("skew", 0)))
+        m.engine.set_option("ln_skip", int(opts.get("ln_skip", 0)))        # measurement builds, ABLATION (wrong results): no LayerNorm launches after the first
         m.engine.set_option("block_persist", int(opts.get("persist", 0)))   # measurement builds: the FF half of a block as one persistent launch
         m.engine.set_option("attn_variant", int(opts.get("attn", DEFAULT_ATTN)))
         m.engine.set_option("attn_f8qk", int(opts.get("f8qk", 1)))           # fp8 QK^T in attention (engine default 1: active on the fp8 path only; +4 forces it)
