@@ -117,6 +117,12 @@ struct lemas_prosody {
     return 0;
   }
 
+  // a Linear on ONE row (SE gates, global-context bias, fc): the wave-per-output kernel when the operands allow its float4 reads
+  static hipError_t row_linear(int epi, const GemmF32Params& g, hipStream_t s) {
+    if (((uintptr_t)g.A & 15) || ((uintptr_t)g.W & 15) || (g.ldw & 3) || (g.K & 3)) return launch_gemm_f32(epi, g, s);
+    return launch_gemv_f32(epi, g, s);
+  }
+
   // y = LayerNorm(relu(conv_k,dil(x (+ add)))) ; x [T][ldx] with cin channels -> out [T][ldo] with cout channels
   int tdnn(const std::string& p, const float* x, int ldx, const float* add, int ldadd, int T, int cin, int cout, int k, int dil, float* scratch,
            float* out, int ldo, int act_tanh, const float* bias_override, int w_cols, hipStream_t s) {
@@ -181,10 +187,10 @@ struct lemas_prosody {
       GemmF32Params g{};
       g.A = mean; g.lda = c; g.W = ws.ptr(p + "se_block.conv1.weight"); g.ldw = c; g.bias = ws.ptr(p + "se_block.conv1.bias"); g.out = s1; g.ldc = cfg.se_channels;
       g.M = 1; g.N = cfg.se_channels; g.K = c;
-      HIP_TRY(launch_gemm_f32(F32_BIAS_RELU, g, s));
+      HIP_TRY(row_linear(F32_BIAS_RELU, g, s));
       g.A = s1; g.lda = cfg.se_channels; g.W = ws.ptr(p + "se_block.conv2.weight"); g.ldw = cfg.se_channels; g.bias = ws.ptr(p + "se_block.conv2.bias"); g.out = s2;
       g.ldc = c; g.N = c; g.K = cfg.se_channels;
-      HIP_TRY(launch_gemm_f32(F32_BIAS_SIGMOID, g, s));
+      HIP_TRY(row_linear(F32_BIAS_SIGMOID, g, s));
       const float* res = xin;
       int ldr = ldin;
       if (ch[i - 1] != c) {                                                                    // projection shortcut :318-324
@@ -213,7 +219,7 @@ struct lemas_prosody {
       GemmF32Params g{};
       g.A = vec; g.lda = 2 * cl; g.W = ws.ptr("asp.tdnn.conv.weight") + cl; g.ldw = 3 * cl; g.bias = ws.ptr("asp.tdnn.conv.bias"); g.out = bias2;
       g.ldc = cfg.attention_channels; g.M = 1; g.N = cfg.attention_channels; g.K = 2 * cl;
-      HIP_TRY(launch_gemm_f32(F32_BIAS, g, s));
+      HIP_TRY(row_linear(F32_BIAS, g, s));
       tb = bias2; wcols = 3 * cl;
     }
     RC_TRY(tdnn("asp.tdnn.", M, cl, nullptr, 0, T, cl, cfg.attention_channels, 1, 1, tmp, d_att1.as<float>(), cfg.attention_channels, 1 /*tanh*/, tb, wcols, s));
@@ -231,7 +237,7 @@ struct lemas_prosody {
       GemmF32Params g{};
       g.A = vec; g.lda = 2 * cl; g.W = ws.ptr("fc.weight"); g.ldw = 2 * cl; g.bias = ws.ptr("fc.bias"); g.out = raw; g.ldc = cfg.embed_dim;
       g.M = 1; g.N = cfg.embed_dim; g.K = 2 * cl;
-      HIP_TRY(launch_gemm_f32(F32_BIAS, g, s));
+      HIP_TRY(row_linear(F32_BIAS, g, s));
     }
     HIP_TRY(launch_l2_normalize(raw, cfg.embed_dim, 1e-12f, emb, s));
     return 0;

@@ -32,24 +32,46 @@ __global__ void im2col_dil_kernel(const float* __restrict__ x, int ldx, const fl
   }
 }
 
-// LayerNorm over the C channels of each row (affine, eps inside the sqrt), optional tanh; one wave per row
+// LayerNorm over the C channels of each row (affine, eps inside the sqrt), optional tanh; one wave per row.  C % 4 == 0, C <= 4096 and
+// 16-B aligned rows (launch_ln_rows checks): the row is read ONCE, as float4, and stays in registers for the two-pass statistics and the output (the first
+// form read it three times with scalar loads: 30 us for the 998 x 1536 MFA rows, profiles/r06/r06fe_kernel_stats_frontend.txt)
+template <int NV>
 __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ x, int ldx, int T, int C, const float* __restrict__ w,
                                                       const float* __restrict__ b, float eps, int act_tanh, float* __restrict__ out, int ldo) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= T) return;
-  const int lane = threadIdx.x & 63;
-  const float* xr = x + (size_t)row * ldx;
+  const int lane = threadIdx.x & 63, nv = C >> 2;
+  const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * ldx);
+  float4 v[NV];
   float s = 0.f;
-  for (int c = lane; c < C; c += 64) s += xr[c];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c4 = lane + 64 * i;
+    v[i] = c4 < nv ? xr[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
   const float mean = wave_sum(s) / (float)C;
   float q = 0.f;
-  for (int c = lane; c < C; c += 64) { const float d = xr[c] - mean; q += d * d; }
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    if (lane + 64 * i < nv) {
+      const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+      q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
   const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
-  float* o = out + (size_t)row * ldo;
-  for (int c = lane; c < C; c += 64) {
-    float v = (xr[c] - mean) * rstd * w[c] + b[c];
-    if (act_tanh) v = tanhf(v);
-    o[c] = v;
+  float4* o = reinterpret_cast<float4*>(out + (size_t)row * ldo);
+  const float4* w4 = reinterpret_cast<const float4*>(w);
+  const float4* b4 = reinterpret_cast<const float4*>(b);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c4 = lane + 64 * i;
+    if (c4 < nv) {
+      const float4 ww = w4[c4], bb = b4[c4];
+      float4 r = make_float4((v[i].x - mean) * rstd * ww.x + bb.x, (v[i].y - mean) * rstd * ww.y + bb.y,
+                             (v[i].z - mean) * rstd * ww.z + bb.z, (v[i].w - mean) * rstd * ww.w + bb.w);
+      if (act_tanh) r = make_float4(tanhf(r.x), tanhf(r.y), tanhf(r.z), tanhf(r.w));
+      o[c4] = r;
+    }
   }
 }
 
@@ -63,27 +85,38 @@ __global__ void copy_cols_kernel(const float* __restrict__ x, int ldx, int T, in
 }
 
 // per-channel mean and std over time with uniform weights 1/T: std = sqrt(clamp(sum w (x - mean)^2, eps)).
-// block = 32 channels x 8 row lanes
-__global__ __launch_bounds__(256) void col_stats_kernel(const float* __restrict__ x, int ldx, int T, int C, float eps,
-                                                        float* __restrict__ mean, float* __restrict__ stdv) {
-  __shared__ float red[8][33];
-  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5, c = blockIdx.x * 32 + cx;
+// block = COL_CX channels x COL_RY row lanes (1024 threads): a column of ~1000 frames is ~16 rows per thread, requested eight at a time.  (The
+// first form -- 32 channels x 8 row lanes -- walked 125 dependent loads per thread: 50 us for 2 MB, profiles/r06/r06fe_kernel_stats_frontend.txt.)
+constexpr int COL_CX = 16, COL_RY = 64;
+
+template <bool IS_MAX>
+__device__ __forceinline__ float col_reduce(float (&red)[COL_RY][COL_CX + 1], float v, int ry, int cx) {
+  red[ry][cx] = v;
+  __syncthreads();
+  for (int h = COL_RY / 2; h >= 1; h >>= 1) {
+    if (ry < h) red[ry][cx] = IS_MAX ? fmaxf(red[ry][cx], red[ry + h][cx]) : red[ry][cx] + red[ry + h][cx];
+    __syncthreads();
+  }
+  const float r = red[0][cx];
+  __syncthreads();
+  return r;
+}
+
+__global__ __launch_bounds__(COL_CX * COL_RY) void col_stats_kernel(const float* __restrict__ x, int ldx, int T, int C, float eps,
+                                                                    float* __restrict__ mean, float* __restrict__ stdv) {
+  __shared__ float red[COL_RY][COL_CX + 1];
+  const int cx = threadIdx.x % COL_CX, ry = threadIdx.x / COL_CX, c = blockIdx.x * COL_CX + cx;
   const bool ok = c < C;
+  const float* xc = x + (ok ? c : 0);
   float s = 0.f;
-  if (ok) for (int t = ry; t < T; t += 8) s += x[(size_t)t * ldx + c];
-  red[ry][cx] = s;
-  __syncthreads();
-  float m = 0.f;
-  for (int r = 0; r < 8; ++r) m += red[r][cx];
-  m /= (float)T;
-  __syncthreads();
+#pragma unroll 8
+  for (int t = ry; t < T; t += COL_RY) s += xc[(size_t)t * ldx];
+  const float m = col_reduce<false>(red, s, ry, cx) / (float)T;
   float q = 0.f;
-  if (ok) for (int t = ry; t < T; t += 8) { const float d = x[(size_t)t * ldx + c] - m; q += d * d; }
-  red[ry][cx] = q;
-  __syncthreads();
+#pragma unroll 8
+  for (int t = ry; t < T; t += COL_RY) { const float d = xc[(size_t)t * ldx] - m; q += d * d; }
+  const float v = col_reduce<false>(red, q, ry, cx);
   if (ry == 0 && ok) {
-    float v = 0.f;
-    for (int r = 0; r < 8; ++r) v += red[r][cx];
     mean[c] = m;
     if (stdv) stdv[c] = sqrtf(fmaxf(v / (float)T, eps));
   }
@@ -101,31 +134,54 @@ __global__ void scale_cols_add_kernel(const float* __restrict__ x, int ldx, cons
 }
 
 // attentive statistics: a = softmax over time of att[:, c]; mean = sum a x; std = sqrt(clamp(sum a (x - mean)^2, eps))
-__global__ __launch_bounds__(256) void softmax_pool_kernel(const float* __restrict__ att, int lda, const float* __restrict__ x, int ldx, int T,
-                                                           int C, float eps, float* __restrict__ mean, float* __restrict__ stdv) {
-  __shared__ float red[8][33];
-  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5, c = blockIdx.x * 32 + cx;
+__global__ __launch_bounds__(COL_CX * COL_RY) void softmax_pool_kernel(const float* __restrict__ att, int lda, const float* __restrict__ x, int ldx, int T,
+                                                                       int C, float eps, float* __restrict__ mean, float* __restrict__ stdv) {
+  __shared__ float red[COL_RY][COL_CX + 1];
+  const int cx = threadIdx.x % COL_CX, ry = threadIdx.x / COL_CX, c = blockIdx.x * COL_CX + cx;
   const bool ok = c < C;
-  auto reduce = [&](float v, bool is_max) {
-    red[ry][cx] = v;
-    __syncthreads();
-    float r = red[0][cx];
-    for (int i = 1; i < 8; ++i) r = is_max ? fmaxf(r, red[i][cx]) : r + red[i][cx];
-    __syncthreads();
-    return r;
-  };
+  const float* ac = att + (ok ? c : 0);
+  const float* xc = x + (ok ? c : 0);
   float mx = -INFINITY;
-  if (ok) for (int t = ry; t < T; t += 8) mx = fmaxf(mx, att[(size_t)t * lda + c]);
-  mx = reduce(mx, true);
+#pragma unroll 8
+  for (int t = ry; t < T; t += COL_RY) mx = fmaxf(mx, ac[(size_t)t * lda]);
+  mx = col_reduce<true>(red, mx, ry, cx);
   float se = 0.f, sx = 0.f;
-  if (ok) for (int t = ry; t < T; t += 8) { const float e = expf(att[(size_t)t * lda + c] - mx); se += e; sx += e * x[(size_t)t * ldx + c]; }
-  se = reduce(se, false);
-  sx = reduce(sx, false);
+#pragma unroll 8
+  for (int t = ry; t < T; t += COL_RY) { const float e = expf(ac[(size_t)t * lda] - mx); se += e; sx += e * xc[(size_t)t * ldx]; }
+  se = col_reduce<false>(red, se, ry, cx);
+  sx = col_reduce<false>(red, sx, ry, cx);
   const float m = sx / se;
   float q = 0.f;
-  if (ok) for (int t = ry; t < T; t += 8) { const float e = expf(att[(size_t)t * lda + c] - mx); const float d = x[(size_t)t * ldx + c] - m; q += e * d * d; }
-  q = reduce(q, false);
+#pragma unroll 8
+  for (int t = ry; t < T; t += COL_RY) { const float e = expf(ac[(size_t)t * lda] - mx); const float d = xc[(size_t)t * ldx] - m; q += e * d * d; }
+  q = col_reduce<false>(red, q, ry, cx);
   if (ry == 0 && ok) { mean[c] = m; stdv[c] = sqrtf(fmaxf(q / se, eps)); }
+}
+
+// one-row Linear (the SE gates, the global-context bias, the final fc): out[n] = act(bias[n] + sum_k a[k] W[n][k]); one wave per output,
+// float4 reads of the weight row.  As a 32 x 64 tile of the matrix GEMM a single row walked K = 3072 in 96 dependent K-tiles on 2-8
+// workgroups: 47-48 us per call (profiles/r06/r06fg_sequence_frontend.txt).  EPI: F32_BIAS / F32_BIAS_RELU / F32_BIAS_SIGMOID
+template <int EPI>
+__global__ __launch_bounds__(256) void gemv_f32_kernel(const float* __restrict__ a, const float* __restrict__ W, int ldw, const float* __restrict__ bias,
+                                                       int N, int K, float* __restrict__ out) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const int lane = threadIdx.x & 63, k4 = K >> 2;
+  const float4* w4 = reinterpret_cast<const float4*>(W + (size_t)n * ldw);
+  const float4* a4 = reinterpret_cast<const float4*>(a);
+  float acc = 0.f;
+#pragma unroll 4
+  for (int i = lane; i < k4; i += 64) {
+    const float4 w = w4[i], x = a4[i];
+    acc = fmaf(w.x, x.x, fmaf(w.y, x.y, fmaf(w.z, x.z, fmaf(w.w, x.w, acc))));
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    float v = acc + (bias ? bias[n] : 0.f);
+    if (EPI == F32_BIAS_RELU) v = fmaxf(v, 0.f);
+    if (EPI == F32_BIAS_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+    out[n] = v;
+  }
 }
 
 // F.normalize: x / max(||x||, eps); one wave
@@ -185,14 +241,23 @@ hipError_t launch_im2col_dil(const float* x, int ldx, const float* add, int ldad
 }
 hipError_t launch_ln_rows(const float* x, int ldx, int T, int C, const float* w, const float* b, float eps, int act_tanh, float* out, int ldo,
                           hipStream_t s) {
-  hipLaunchKernelGGL(ln_rows_kernel, dim3((T + 3) / 4), dim3(256), 0, s, x, ldx, T, C, w, b, eps, act_tanh, out, ldo);
+  const dim3 grid((T + 3) / 4), block(256);
+  // float4 rows: every row start and the width on 16 B (the engine's buffers are; a width that is not a multiple of 4 never gets here --
+  // the GEMM in front of every LayerNorm refuses K % 4 != 0)
+  if ((C & 3) || (ldx & 3) || (ldo & 3) || C > 4096 || ((uintptr_t)x & 15) || ((uintptr_t)out & 15) || ((uintptr_t)w & 15) || ((uintptr_t)b & 15))
+    return hipErrorInvalidValue;
+  if (C <= 256) hipLaunchKernelGGL(ln_rows_kernel<1>, grid, block, 0, s, x, ldx, T, C, w, b, eps, act_tanh, out, ldo);
+  else if (C <= 512) hipLaunchKernelGGL(ln_rows_kernel<2>, grid, block, 0, s, x, ldx, T, C, w, b, eps, act_tanh, out, ldo);
+  else if (C <= 1024) hipLaunchKernelGGL(ln_rows_kernel<4>, grid, block, 0, s, x, ldx, T, C, w, b, eps, act_tanh, out, ldo);
+  else if (C <= 2048) hipLaunchKernelGGL(ln_rows_kernel<8>, grid, block, 0, s, x, ldx, T, C, w, b, eps, act_tanh, out, ldo);
+  else hipLaunchKernelGGL(ln_rows_kernel<16>, grid, block, 0, s, x, ldx, T, C, w, b, eps, act_tanh, out, ldo);
   return hipGetLastError();
 }
 hipError_t launch_copy_cols(const float* x, int ldx, int T, int C, float* out, int ldo, hipStream_t s) {
   LAUNCH1(copy_cols_kernel, (size_t)T * C, x, ldx, T, C, out, ldo)
 }
 hipError_t launch_col_stats(const float* x, int ldx, int T, int C, float eps, float* mean, float* stdv, hipStream_t s) {
-  hipLaunchKernelGGL(col_stats_kernel, dim3((C + 31) / 32), dim3(256), 0, s, x, ldx, T, C, eps, mean, stdv);
+  hipLaunchKernelGGL(col_stats_kernel, dim3((C + COL_CX - 1) / COL_CX), dim3(COL_CX * COL_RY), 0, s, x, ldx, T, C, eps, mean, stdv);
   return hipGetLastError();
 }
 hipError_t launch_scale_cols_add(const float* x, int ldx, const float* scale, const float* res, int ldr, int T, int C, float* out, int ldo,
@@ -201,7 +266,19 @@ hipError_t launch_scale_cols_add(const float* x, int ldx, const float* scale, co
 }
 hipError_t launch_softmax_pool(const float* att, int lda, const float* x, int ldx, int T, int C, float eps, float* mean, float* stdv,
                                hipStream_t s) {
-  hipLaunchKernelGGL(softmax_pool_kernel, dim3((C + 31) / 32), dim3(256), 0, s, att, lda, x, ldx, T, C, eps, mean, stdv);
+  hipLaunchKernelGGL(softmax_pool_kernel, dim3((C + COL_CX - 1) / COL_CX), dim3(COL_CX * COL_RY), 0, s, att, lda, x, ldx, T, C, eps, mean, stdv);
+  return hipGetLastError();
+}
+hipError_t launch_gemv_f32(int epi, const GemmF32Params& p, hipStream_t s) {
+  if (p.M != 1 || p.N <= 0 || p.K <= 0 || (p.K & 3) || (p.ldw & 3) || ((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15) || p.nbatch > 0 || p.rowmask)
+    return hipErrorInvalidValue;
+  const dim3 grid((p.N + 3) / 4), block(256);
+  switch (epi) {
+    case F32_BIAS: hipLaunchKernelGGL(gemv_f32_kernel<F32_BIAS>, grid, block, 0, s, p.A, p.W, p.ldw, p.bias, p.N, p.K, p.out); break;
+    case F32_BIAS_RELU: hipLaunchKernelGGL(gemv_f32_kernel<F32_BIAS_RELU>, grid, block, 0, s, p.A, p.W, p.ldw, p.bias, p.N, p.K, p.out); break;
+    case F32_BIAS_SIGMOID: hipLaunchKernelGGL(gemv_f32_kernel<F32_BIAS_SIGMOID>, grid, block, 0, s, p.A, p.W, p.ldw, p.bias, p.N, p.K, p.out); break;
+    default: return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
 hipError_t launch_l2_normalize(const float* x, int n, float eps, float* out, hipStream_t s) {
