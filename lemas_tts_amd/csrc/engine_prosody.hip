@@ -7,6 +7,8 @@
 // time-major [T][C] activations, dilated convolutions as im2col + GEMM on the reference's own [out][in][k] weights.
 #include <cmath>
 #include <cstring>
+#include <map>
+#include <string>
 #include <vector>
 
 #include "engine_common.h"
@@ -22,11 +24,13 @@ struct lemas_prosody {
   DevBuf d_frames, d_spec, d_pow;
   // encoder workspaces
   DevBuf d_col, d_a, d_b, d_r, d_tmp, d_cat, d_m, d_att1, d_att2, d_vec, d_small;
+  DevBuf d_r2w;                        // lane-major weight images of the Res2Net chunks the fused step kernel takes (finalize())
+  std::map<std::string, const float*> r2w;
   int nb = 257, ldk = 516, ldp = 260;
 
   ~lemas_prosody() {
     for (DevBuf* b : {&basis, &banks, &d_frames, &d_spec, &d_pow, &d_col, &d_a, &d_b, &d_r, &d_tmp, &d_cat, &d_m, &d_att1, &d_att2,
-                      &d_vec, &d_small})
+                      &d_vec, &d_small, &d_r2w})
       b->release();
     ws.release();
   }
@@ -92,6 +96,24 @@ struct lemas_prosody {
   int finalize() {
     RC_TRY(ws.check_complete());
     if (!basis.p) RC_TRY(init_fbank());
+    // Res2Net chunks at the fused kernel's shape: their weights once more, lane-major
+    r2w.clear();
+    std::vector<std::string> names;
+    for (int i = 1; i < cfg.n_layers - 1; ++i) {
+      const int sub = cfg.channels[i] / cfg.res2net_scale;
+      if (!res2net_step_fits(sub, sub, cfg.kernel_sizes[i], cfg.dilations[i])) continue;
+      for (int j = 0; j < cfg.res2net_scale - 1; ++j) names.push_back("blocks." + std::to_string(i) + ".res2net_block.blocks." + std::to_string(j) + ".");
+    }
+    if (!names.empty()) {
+      const size_t n = res2net_weight_image_floats();
+      RC_TRY(d_r2w.ensure(names.size() * n * 4));
+      for (size_t q = 0; q < names.size(); ++q) {
+        float* img = d_r2w.as<float>() + q * n;
+        HIP_TRY(launch_res2net_weight_image(ws.ptr(names[q] + "conv.weight"), img, nullptr));
+        r2w[names[q]] = img;
+      }
+      HIP_TRY(hipStreamSynchronize(nullptr));
+    }
     finalized = true;
     return 0;
   }
@@ -123,9 +145,18 @@ struct lemas_prosody {
     return launch_gemv_f32(epi, g, s);
   }
 
+  static bool add_ok_fused(const float* x, const float* add, int ldx, int ldadd) {
+    return !((uintptr_t)x & 15) && !((uintptr_t)add & 15) && !(ldx & 3) && (!add || !(ldadd & 3));
+  }
   // y = LayerNorm(relu(conv_k,dil(x (+ add)))) ; x [T][ldx] with cin channels -> out [T][ldo] with cout channels
   int tdnn(const std::string& p, const float* x, int ldx, const float* add, int ldadd, int T, int cin, int cout, int k, int dil, float* scratch,
            float* out, int ldo, int act_tanh, const float* bias_override, int w_cols, hipStream_t s) {
+    const auto img = r2w.find(p);
+    if (img != r2w.end() && add_ok_fused(x, add, ldx, ldadd) && !bias_override && !w_cols && !act_tanh && res2net_step_fits(cin, cout, k, dil)) {
+      HIP_TRY(launch_res2net_step(x, ldx, add, ldadd, T, dil, img->second, ws.ptr(p + "conv.bias"), ws.ptr(p + "norm.weight"),
+                                  ws.ptr(p + "norm.bias"), 1e-12f, out, ldo, s));
+      return 0;
+    }
     GemmF32Params g{};
     g.W = ws.ptr(p + "conv.weight"); g.ldw = w_cols ? w_cols : cin * k; g.bias = bias_override ? bias_override : ws.ptr(p + "conv.bias");
     g.M = T; g.N = cout; g.out = scratch; g.ldc = cout;

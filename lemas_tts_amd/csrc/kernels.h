@@ -41,6 +41,13 @@ hipError_t launch_log_clamp(float* x, size_t n, float lo, hipStream_t s);
 hipError_t launch_im2col_dil(const float* x, int ldx, const float* add, int ldadd, int T, int C, int k, int dil, float* col, hipStream_t s);
 hipError_t launch_ln_rows(const float* x, int ldx, int T, int C, const float* w, const float* b, float eps, int act_tanh, float* out, int ldo, hipStream_t s);
 hipError_t launch_copy_cols(const float* x, int ldx, int T, int C, float* out, int ldo, hipStream_t s);
+// one Res2Net chunk (64 -> 64 channels, 3 taps) as one launch: y = LayerNorm(relu(conv_dil(x + add) + bias)); Wimg = the lane-major image
+// launch_res2net_weight_image makes of the reference's [out][in][k] weight (res2net_weight_image_floats() floats)
+bool res2net_step_fits(int cin, int cout, int k, int dil);
+size_t res2net_weight_image_floats();
+hipError_t launch_res2net_weight_image(const float* W, float* img, hipStream_t s);
+hipError_t launch_res2net_step(const float* x, int ldx, const float* add, int ldadd, int T, int dil, const float* Wimg, const float* bias,
+                               const float* lnw, const float* lnb, float eps, float* out, int ldo, hipStream_t s);
 // one-row Linear (M == 1; F32_BIAS / F32_BIAS_RELU / F32_BIAS_SIGMOID; A, W rows on 16 B): a wave per output instead of a GEMM tile
 hipError_t launch_gemv_f32(int epi, const GemmF32Params& p, hipStream_t s);
 hipError_t launch_col_stats(const float* x, int ldx, int T, int C, float eps, float* mean, float* stdv, hipStream_t s);

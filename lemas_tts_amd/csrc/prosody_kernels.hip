@@ -75,6 +75,79 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ 
   }
 }
 
+// One Res2Net chunk of an SE-Res2Net block at the published widths (64 channels, 3 taps; prosody_encoder.py:188-202 + TDNNBlock :136-161) as ONE
+// launch: y = LayerNorm(relu(conv_3,dil(x + add) + bias)).  The three launches it replaces (im2col 3.2 us, a 998 x 64 x 192 GEMM 5.6 us, the row
+// LayerNorm 2.7 us: profiles/r06/r06fh_kernel_stats_frontend.txt) run 21 times per prompt, each waiting for the one before.
+// Block = 16 rows x 64 output channels on the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32, operand roles as gemm_f32.hip): wave w owns output channels
+// 16 w .. 16 w + 15 with their 192 weights in 48 registers per lane; the (x + add) rows with their halo sit in LDS ([row][68]: the 16 rows of a
+// fragment read start in 16 different 4-bank groups) and tap j of row m is simply row m + j dil of that tile -- no im2col; the relu'd 16 x 64
+// tile goes through LDS once so that a wave can normalise whole rows.  K order: (tap, 16-channel group, 4 lk + e), the same on both operands.
+// A first form on the vector ALU (lane = output channel, x rows read as wave-wide LDS broadcasts) took 8.5 us: 192 broadcast ds_read_b128 per
+// lane still move 1 KB each into registers (profiles/r06/r06fj_kernel_stats_frontend_valu_form.txt).
+constexpr int R2_C = 64, R2_K = 3, R2_ROWS = 16, R2_PITCH = R2_C + 4;
+// the reference's [out][in * k] weight as [tap][16-channel group][out][lk][4]: the lanes of a wave read their operand float4s as coalesced 1-KB requests
+__global__ void res2net_weight_image_kernel(const float* __restrict__ W, float* __restrict__ img) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= R2_C * R2_C * R2_K) return;
+  const int e = i & 3, lk = (i >> 2) & 3, n = (i >> 4) % R2_C, jg = i / (16 * R2_C), g = jg & 3, j = jg >> 2;
+  img[i] = W[(size_t)n * (R2_C * R2_K) + (16 * g + 4 * lk + e) * R2_K + j];
+}
+__global__ __launch_bounds__(256) void res2net_step_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ add, int ldadd, int T, int dil,
+                                                           const float* __restrict__ Wimg, const float* __restrict__ bias, const float* __restrict__ lnw,
+                                                           const float* __restrict__ lnb, float eps, float* __restrict__ out, int ldo) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];     // [R2_ROWS + 2 dil][R2_PITCH], then ys [R2_ROWS][R2_C + 1]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lk = lane >> 4;
+  const int t0 = blockIdx.x * R2_ROWS, nrows = R2_ROWS + 2 * dil;
+  float* ys = xs + nrows * R2_PITCH;
+  float4 w[R2_K * 4];
+  const float4* w4 = reinterpret_cast<const float4*>(Wimg) + (wave * 16 + l15) * 4 + lk;
+#pragma unroll
+  for (int q = 0; q < R2_K * 4; ++q) w[q] = w4[q * (R2_C * 4)];
+  for (int i = tid; i < nrows * (R2_C / 4); i += 256) {
+    const int r = i / (R2_C / 4), c4 = i % (R2_C / 4), t = t0 - dil + r;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t >= 0 && t < T) {
+      v = *reinterpret_cast<const float4*>(x + (size_t)t * ldx + 4 * c4);
+      if (add) {
+        const float4 a = *reinterpret_cast<const float4*>(add + (size_t)t * ldadd + 4 * c4);
+        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+      }
+    }
+    *reinterpret_cast<float4*>(xs + r * R2_PITCH + 4 * c4) = v;
+  }
+  __syncthreads();
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < R2_K; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 a = *reinterpret_cast<const float4*>(xs + (l15 + j * dil) * R2_PITCH + 16 * g + 4 * lk);
+      const float4 b = w[j * 4 + g];
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(b.x, a.x, acc, 0, 0, 0);      // C^T: lane holds out[row l15][channel 16 wave + 4 lk + i]
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(b.y, a.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(b.z, a.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(b.w, a.w, acc, 0, 0, 0);
+    }
+  {
+    const int n = wave * 16 + 4 * lk;
+    const float4 bv = *reinterpret_cast<const float4*>(bias + n);
+    float* yr = ys + l15 * (R2_C + 1) + n;
+    yr[0] = fmaxf(acc[0] + bv.x, 0.f); yr[1] = fmaxf(acc[1] + bv.y, 0.f); yr[2] = fmaxf(acc[2] + bv.z, 0.f); yr[3] = fmaxf(acc[3] + bv.w, 0.f);
+  }
+  __syncthreads();
+  const float gw = lnw[lane], gb = lnb[lane];
+#pragma unroll
+  for (int q = 0; q < R2_ROWS / 4; ++q) {
+    const int r = wave * (R2_ROWS / 4) + q, t = t0 + r;
+    if (t >= T) break;                            // (uniform per wave)
+    const float v = ys[r * (R2_C + 1) + lane];
+    const float mean = wave_sum(v) / (float)R2_C;
+    const float d = v - mean;
+    const float rstd = 1.0f / sqrtf(wave_sum(d * d) / (float)R2_C + eps);
+    out[(size_t)t * ldo + lane] = d * rstd * gw + gb;
+  }
+}
+
 __global__ void copy_cols_kernel(const float* __restrict__ x, int ldx, int T, int C, float* __restrict__ out, int ldo) {
   const size_t total = (size_t)T * C;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -267,6 +340,22 @@ hipError_t launch_scale_cols_add(const float* x, int ldx, const float* scale, co
 hipError_t launch_softmax_pool(const float* att, int lda, const float* x, int ldx, int T, int C, float eps, float* mean, float* stdv,
                                hipStream_t s) {
   hipLaunchKernelGGL(softmax_pool_kernel, dim3((C + COL_CX - 1) / COL_CX), dim3(COL_CX * COL_RY), 0, s, att, lda, x, ldx, T, C, eps, mean, stdv);
+  return hipGetLastError();
+}
+size_t res2net_weight_image_floats() { return (size_t)R2_C * R2_C * R2_K; }
+hipError_t launch_res2net_weight_image(const float* W, float* img, hipStream_t s) {
+  hipLaunchKernelGGL(res2net_weight_image_kernel, dim3((R2_C * R2_C * R2_K + 255) / 256), dim3(256), 0, s, W, img);
+  return hipGetLastError();
+}
+bool res2net_step_fits(int cin, int cout, int k, int dil) { return cin == R2_C && cout == R2_C && k == R2_K && dil >= 1 && dil <= 16; }
+hipError_t launch_res2net_step(const float* x, int ldx, const float* add, int ldadd, int T, int dil, const float* Wimg, const float* bias,
+                               const float* lnw, const float* lnb, float eps, float* out, int ldo, hipStream_t s) {
+  const float* W = Wimg;
+  if (T <= 0 || dil < 1 || dil > 16 || (ldx & 3) || (add && (ldadd & 3)) || ((uintptr_t)x & 15) || ((uintptr_t)add & 15) || ((uintptr_t)W & 15))
+    return hipErrorInvalidValue;
+  if (((uintptr_t)bias & 15)) return hipErrorInvalidValue;
+  const size_t lds = ((size_t)(R2_ROWS + 2 * dil) * R2_PITCH + (size_t)R2_ROWS * (R2_C + 1)) * 4;
+  hipLaunchKernelGGL(res2net_step_kernel, dim3((T + R2_ROWS - 1) / R2_ROWS), dim3(256), lds, s, x, ldx, add, ldadd, T, dil, W, bias, lnw, lnb, eps, out, ldo);
   return hipGetLastError();
 }
 hipError_t launch_gemv_f32(int epi, const GemmF32Params& p, hipStream_t s) {
