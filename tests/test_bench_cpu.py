@@ -50,3 +50,31 @@ def test_forward_flops_formula():
     import bench
     assert bench.fwd_flops(1, 1875) == pytest.approx(378_888_192 * 1875 + 90_112 * 1875 ** 2)
     assert bench.fwd_flops(8, 1125) == pytest.approx(8 * (378_888_192 * 1125 + 90_112 * 1125 ** 2))
+
+
+def test_frontend_bench_counts_the_encoder_flops_of_the_weights_it_loads():
+    """tools/frontend_bench.py prices the ECAPA encode at 2 flops per multiply-add of every convolution / linear: the count from the layer
+    list must equal the one from the state-dict shapes (every weight element is used once per frame, or once per prompt for the one-row
+    Linears: SE gates, the global-context columns of the attention TDNN, the final fc), for the published widths and for a second architecture."""
+    import importlib.util
+    import numpy as np
+    from lemas_tts_amd.model.layout import ProsodyArch, prosody_param_shapes
+    spec = importlib.util.spec_from_file_location("frontend_bench", os.path.join(ROOT, "tools", "frontend_bench.py"))
+    fb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fb)
+    other = ProsodyArch(channels=(96, 128, 128, 256), kernel_sizes=(3, 5, 3, 1), dilations=(2, 1, 3, 1), attention_channels=32,
+                        res2net_scale=4, se_channels=16, global_context=False, groups=(1, 1, 1, 1), embed_dim=64, input_dim=40)
+    for arch, T in ((ProsodyArch(), 998), (other, 77)):
+        want = 0
+        for name, shape in prosody_param_shapes(arch).items():
+            if not name.endswith("weight") or len(shape) != 3:
+                continue
+            n = int(np.prod(shape))
+            if "se_block" in name or name == "fc.weight":
+                want += 2 * n
+            elif name == "asp.tdnn.conv.weight" and arch.global_context:
+                want += 2 * T * (n // 3) + 2 * (2 * n // 3)
+            else:
+                want += 2 * T * n
+        assert fb.ecapa_flops(arch, T) == want, (fb.ecapa_flops(arch, T), want)
+    assert fb.ecapa_flops(ProsodyArch(), 998) == 9562013696     # the figure in DESIGN.md section 3 / profiles/r06/r06fk_frontend_bench.json

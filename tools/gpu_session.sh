@@ -11,6 +11,7 @@
 #   lines                        every bench line of the round's table (five workloads, fp8, bf16 configs4, the job, the N > 1 rehearsals)
 #   ab:<workloads,comma>:<reps>:<key=v,key=v>[:<key=v,...>...]      tools/e2e_ab.py arms on ONE engine, interleaved
 #   rocprof:<workload>           rocprofv3 --kernel-trace --stats over bench.py -> <TAG>_kernel_stats_<w>.txt
+#                                (STEPGAPS=1 in the environment: also tools/rocpd_step_gaps.py -> <TAG>_step_gaps_<w>.txt)
 #   pmc:<workload>               the PMC group passes (one group per pass, --no-phases) -> <TAG>_pmc_groups_<w>.txt
 #   traffic:<workload>           FETCH_SIZE / WRITE_SIZE passes -> <TAG>_pmc_traffic_<w>.txt
 #   timeline[:<workload>]        measurement build (-DLEMAS_PHASE_TIMESTAMPS) -> tools/timeline_step.py -> product build again
@@ -64,6 +65,7 @@ for step in "$@"; do
       w=${rest:-configs1}; rm -rf /tmp/prof_$w
       (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_$w -- python $R/bench.py --workload $w --no-cpu-baseline --no-clock-power --steps 4 > /tmp/prof_$w.out 2> /tmp/prof_$w.log)
       python tools/rocpd_summary.py "$(find /tmp/prof_$w -name '*_results.db' | head -1)" > "$O/${TAG}_kernel_stats_$w.txt"
+      [ -n "${STEPGAPS:-}" ] && python tools/rocpd_step_gaps.py "$(find /tmp/prof_$w -name '*_results.db' | head -1)" > "$O/${TAG}_step_gaps_$w.txt"
       tail -1 /tmp/prof_$w.out > "$O/${TAG}_bench_under_rocprof_$w.json"; head -14 "$O/${TAG}_kernel_stats_$w.txt" | cut -c1-70,110-175 ;;
     pmc)
       w=${rest:-configs1}; : > "$O/${TAG}_pmc_groups_$w.txt"
