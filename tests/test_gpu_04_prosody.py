@@ -57,6 +57,32 @@ def test_strict_load_and_prefix_stripping():
         ProsodyEncoder(state_dict=bad, device="cuda:0")
 
 
+@pytest.mark.parametrize("T", [1, 2, 15, 16, 17, 33, 63, 65, 130])
+def test_ecapa_published_widths_at_tile_edges_vs_oracle(T):
+    """the published architecture (the one-launch Res2Net chunks: 16-row tiles with a dilation halo of up to 4 rows; column statistics on
+    64 row lanes; the wave-per-output one-row Linears) at frame counts around every tile edge, against the oracle restatement"""
+    from oracle.prosody_oracle import OracleECAPA
+    arch = ProsodyArch()
+    sd = synth.synth_prosody_encoder_state_dict(17, arch)
+    enc = _encoder(17)
+    fb = torch.from_numpy(synth.synth_fbank(T + 100, T))[None]
+    ref = OracleECAPA(sd, arch).forward(fb)
+    out = enc(fb).cpu()
+    assert torch.isfinite(out).all()
+    assert float((out - ref).abs().max()) < 2e-5, float((out - ref).abs().max())
+
+
+def test_ecapa_is_deterministic_and_independent_of_what_ran_before():
+    """the same prompt twice, with a longer one in between (workspaces regrown, LDS tiles reused): bit-identical embeddings"""
+    enc = _encoder(17)
+    a = torch.from_numpy(synth.synth_fbank(3, 200))[None]
+    b = torch.from_numpy(synth.synth_fbank(4, 1500))[None]
+    e1 = enc(a).cpu().numpy()
+    enc(b)
+    e2 = enc(a).cpu().numpy()
+    np.testing.assert_array_equal(e1, e2)
+
+
 @pytest.mark.parametrize("n", [400, 16000, 160123, 150])
 def test_kaldi_fbank_vs_oracle(n):
     from oracle.prosody_oracle import kaldi_fbank_80
