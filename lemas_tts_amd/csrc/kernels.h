@@ -56,3 +56,9 @@ hipError_t launch_softmax_pool(const float* att, int lda, const float* x, int ld
 hipError_t launch_l2_normalize(const float* x, int n, float eps, float* out, hipStream_t s);
 hipError_t launch_kaldi_frames(const float* wav, int n, int frames, int win, int shift, int padded, float preemph, float* out, hipStream_t s);
 hipError_t launch_power(const float* spec, int rows, int nb, int lds_, int ldp, float* pw, hipStream_t s);
+// real FFT / inverse real FFT of STFT rows in LDS (fft_kernels.hip): N = 2^a 3^b 5^c, even, <= 8192; `tw` = N float2 exp(-2 pi i t / N)
+struct FftPlan { int n; int nrad; int rad[14]; };
+bool fft_plan_make(int n, FftPlan* plan);
+hipError_t fft_kernels_init(const FftPlan& plan);
+hipError_t launch_rfft_rows(const FftPlan& plan, const float* tw, const float* frames, int rows, float* spec, int ld, hipStream_t s);
+hipError_t launch_irfft_rows(const FftPlan& plan, const float* tw, const float* spec, int ld, int rows, const float* window, float* frames, hipStream_t s);

@@ -114,3 +114,34 @@ def test_path_as_model_is_refused():
     from lemas_tts_amd.uvr5 import mdx
     with pytest.raises(Exception):
         mdx.Inference.load_model(object.__new__(mdx.Inference), "Kim_Vocal_1.onnx")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_fft,hop", [(64, 16), (96, 24), (20, 5), (240, 60), (1000, 250), (1536, 384), (2048, 512), (6144, 1024), (7680, 1024),
+                                       (8192, 2048), (28, 7), (1792, 448)])
+def test_stft_engine_fft_and_gemm_forms_vs_torch(n_fft, hop):
+    """lemas_stft_forward / _inverse against torch.stft / torch.istft (the reference's arithmetic, multiprocess_cuda_infer.py:206-223) at
+    transform lengths the in-LDS FFT takes (2^a 3^b 5^c <= 8192: radix-4 / 2 / 3 / 5 stages in every mix, Kim_Vocal_1's 7680) and at lengths it
+    does not (28, 1792: a factor 7 -- the DFT as a GEMM); an ODD number of rows too (the FFT rides two real rows on one complex transform)."""
+    from lemas_tts_amd.engine import StftEngine
+    g = torch.Generator().manual_seed(n_fft)
+    win = torch.hann_window(n_fft, periodic=True)
+    eng = StftEngine(n_fft, hop, win, device="cuda:0")
+    for batch in (3, 2):
+        frames = 9
+        x = torch.randn(batch, hop * (frames - 1), generator=g)
+        ref = torch.stft(x, n_fft=n_fft, hop_length=hop, window=win, center=True, return_complex=True)
+        spec = eng.forward(x.to("cuda:0")).cpu()
+        assert spec.shape == ref.shape
+        scale = float(ref.abs().max())
+        assert float((spec - ref).abs().max()) < 2e-6 * scale * max(1.0, np.log2(n_fft) / 4), (n_fft, float((spec - ref).abs().max()), scale)
+        wav_ref = torch.istft(ref, n_fft=n_fft, hop_length=hop, window=win, center=True)
+        wav = eng.inverse(ref.to("cuda:0")).cpu()
+        assert wav.shape == wav_ref.shape
+        assert float((wav - wav_ref).abs().max()) < 1e-5, (n_fft, float((wav - wav_ref).abs().max()))
+        # irfft ignores the imaginary parts of the DC and Nyquist bins: so must both forms
+        dirty = ref.clone()
+        dirty[:, 0, :] += 0.5j
+        dirty[:, -1, :] -= 0.25j
+        wav2 = eng.inverse(dirty.to("cuda:0")).cpu()
+        assert float((wav2 - wav_ref).abs().max()) < 1e-5
