@@ -209,7 +209,8 @@ int64_t lemas_resample_out_len(const lemas_resample* r, int64_t samples);   /* c
 int lemas_resample_forward(lemas_resample* r, const float* wav, int32_t batch, int32_t samples, float* out, void* stream);
 
 /* ---- STFT / inverse STFT around the UVR5 MDX-Net prompt denoiser (uvr5/multiprocess_cuda_infer.py:206-223): torch.stft(n_fft, hop,
- * window, center=True, onesided) and torch.istft(..., center=True) as fp32 GEMMs.  `window` host [n_fft] (the reference passes
+ * window, center=True, onesided) and torch.istft(..., center=True): an in-LDS fp32 FFT for n_fft = 2^a 3^b 5^c <= 8192 (the denoiser's 7680),
+ * fp32 GEMMs against DFT bases for any other length.  `window` host [n_fft] (the reference passes
  * hann_window(n_fft, periodic=False)).  Spectrogram frames are [re(0..n_fft/2) | im(0..n_fft/2) | padding], ld = lemas_stft_ld().
  *   forward: wav device [B, samples] -> spec device [B, samples / hop + 1, ld]
  *   inverse: spec device [B, frames, ld] -> wav device [B, hop * (frames - 1)]  (imaginary parts of bins 0 and n_fft/2 are ignored) ---- */
