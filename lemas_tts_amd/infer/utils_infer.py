@@ -22,7 +22,7 @@ import torch
 import yaml
 
 from ..engine import VocosEngine
-from ..model.cfm import CFM
+from ..model.cfm import CFM, pad_rows
 from ..model.layout import DROPPED_ON_LOAD, DiTArch, VocosArch
 
 # module-level defaults of the reference (:68-81)
@@ -293,7 +293,7 @@ def _infer_lines(lines, group, model_obj, cond, ref_text, line_duration, nfe_ste
             cond_b = cond if cond.ndim == 2 and cond.shape[0] == nb else cond.expand(nb, *cond.shape[1:])
             y0 = None
             if noise is not None:
-                y0 = torch.nn.utils.rnn.pad_sequence([noise[g0 + j][0] for j in range(nb)], batch_first=True)
+                y0 = pad_rows([noise[g0 + j][0] for j in range(nb)], 0)
             pros = prosody_embeds
             if pros is not None and pros.shape[0] == 1:
                 pros = pros.expand(nb, -1)
