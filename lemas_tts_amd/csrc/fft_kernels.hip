@@ -161,9 +161,10 @@ bool fft_plan_make(int n, FftPlan* plan) {
   *plan = p;
   return true;
 }
-// the > 64 KB dynamic-LDS opt-in of both kernels: once per engine, never on a launch path
-hipError_t fft_kernels_init(const FftPlan& plan) {
-  const int lds = plan.n * 16;
+// the > 64 KB dynamic-LDS opt-in of both kernels: once per engine, never on a launch path.  Always the largest plan's footprint (the attribute
+// belongs to the kernel, not to the engine: a second engine with a shorter transform must not lower it under the first one's launches)
+hipError_t fft_kernels_init(const FftPlan&) {
+  const int lds = 8192 * 16;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rfft_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) return e;
   return hipFuncSetAttribute(reinterpret_cast<const void*>(irfft_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);

@@ -145,3 +145,22 @@ def test_stft_engine_fft_and_gemm_forms_vs_torch(n_fft, hop):
         dirty[:, -1, :] -= 0.25j
         wav2 = eng.inverse(dirty.to("cuda:0")).cpu()
         assert float((wav2 - wav_ref).abs().max()) < 1e-5
+
+
+@pytest.mark.gpu
+def test_two_stft_engines_of_different_lengths_side_by_side():
+    """the FFT kernels' > 64 KB LDS opt-in belongs to the kernel, not to an engine: creating a short-transform engine after a long one must not
+    break the long one's launches (and the other way round)"""
+    from lemas_tts_amd.engine import StftEngine
+    g = torch.Generator().manual_seed(1)
+    big = StftEngine(7680, 1024, torch.hann_window(7680, periodic=False), device="cuda:0")
+    small = StftEngine(64, 16, torch.hann_window(64, periodic=True), device="cuda:0")
+    big2 = StftEngine(8192, 2048, torch.hann_window(8192, periodic=True), device="cuda:0")
+    for eng, n_fft, hop, periodic in ((big, 7680, 1024, False), (small, 64, 16, True), (big2, 8192, 2048, True), (big, 7680, 1024, False)):
+        win = torch.hann_window(n_fft, periodic=periodic)
+        x = torch.randn(2, hop * 8, generator=g)
+        ref = torch.stft(x, n_fft=n_fft, hop_length=hop, window=win, center=True, return_complex=True)
+        spec = eng.forward(x.to("cuda:0")).cpu()
+        assert float((spec - ref).abs().max()) < 1e-5 * float(ref.abs().max())
+        rt = eng.inverse(spec.to("cuda:0")).cpu()
+        assert float((rt - x).abs().max()) < 2e-5
