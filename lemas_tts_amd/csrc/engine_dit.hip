@@ -914,14 +914,25 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
     return 0;
   };
 
-  const bool skew = fork && lane_skew != 0 && lanes == 2;
-  if (skew)
+  // lane_skew 1: every stage; 10 + S: ONCE per ODE step -- lane 1's first launch of block 0 waits for lane 0's stage S of block 0 (0 QK+V, 1 attention,
+  // 2 out-projection, 3 FF1, 4 FF2), after which the lanes run S + 1 stages apart without another edge
+  const bool skew = fork && lane_skew == 1 && lanes == 2;
+  const int skew_once = (fork && lane_skew >= 10 && lane_skew <= 14 && lanes == 2) ? lane_skew - 10 : -1;
+  if (skew || skew_once >= 0)
     for (auto& e : ev_skew)
       if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  int skew_k = 0;
+  int skew_k = 0, skew_l = 0;
   // around every launch of a block: lane 0 records "stage k done", lane 1 waits for it before its own stage k
-  auto skew_pre = [&](int ln, hipStream_t q) -> int { if (skew && ln == 1) HIP_TRY(hipStreamWaitEvent(q, ev_skew[skew_k & 7], 0)); return 0; };
-  auto skew_post = [&](int ln, hipStream_t q) -> int { if (skew && ln == 0) HIP_TRY(hipEventRecord(ev_skew[skew_k & 7], q)); ++skew_k; return 0; };
+  auto skew_pre = [&](int ln, hipStream_t q) -> int {
+    if (skew && ln == 1) HIP_TRY(hipStreamWaitEvent(q, ev_skew[skew_k & 7], 0));
+    if (skew_once >= 0 && ln == 1 && skew_l == 0 && skew_k == 0) HIP_TRY(hipStreamWaitEvent(q, ev_skew[skew_once], 0));
+    return 0;
+  };
+  auto skew_post = [&](int ln, hipStream_t q) -> int {
+    if ((skew || (skew_once >= 0 && skew_l == 0 && skew_k == skew_once)) && ln == 0) HIP_TRY(hipEventRecord(ev_skew[skew_k & 7], q));
+    ++skew_k;
+    return 0;
+  };
   // Ragged batch: the 128-row blocks that lie wholly in a sample's padding are not computed by the block chain (GemmParams::live_len; the
   // reference computes them and trims each sample to its duration afterwards, utils_infer.py:579-585).  Their x rows stay what the input
   // embedding made them, so the head below still emits finite (and unused) rows there.  bf16 chain without the LayerNorm options only.
@@ -936,6 +947,7 @@ int lemas_dit::enqueue_forward(hipStream_t s) {
   auto block = [&](int l, int ln) -> int {   // one DiTBlock (modules.py:627-641) on one lane's rows
     hipStream_t q = st[ln];
     skew_k = 0;
+    skew_l = l;
     const size_t r0 = (size_t)ln * rows;
     float* xres = d_xres.as<float>() + r0 * d;
     bf16_t* hbf = d_hbf.as<bf16_t>() + r0 * d;
